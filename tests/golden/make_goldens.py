@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box); the committed `*.npz` files are the data the tests use.  Nothing from the
+reference is copied: this script imports `models` and `loss_functions` from the path
+given on the command line, loads seeded weights through the reference's own
+`FAL_netB(data={'state_dict': ...})` path (models/FAL_netB.py:28-32) and records
+inputs -> outputs.
+
+Run-time shims (reference files untouched):
+  * `Tensor.cuda` / `Module.cuda` -> no-op (hard-coded `.cuda()` at FAL_netB.py:231,
+    loss_functions.py:11,73,81-91);
+  * a stub `torchvision.models.vgg19` that builds the cfg-"E" `features` Sequential with
+    the seeded weights of `fal_net_amd.synthetic.seeded_vgg19_state_dict`
+    (loss_functions.py:4,10 import torchvision and download ImageNet weights at import).
+The entry scripts themselves need tensorboardX/imageio/KITTI and cannot be imported;
+their `train()` bodies are re-played here call-for-call against the imported model and
+loss functions (Train_Stage1_K.py:233-262, Train_Stage2_K.py:247-329, Test_KITTI.py:287-300).
+
+usage: python tests/golden/make_goldens.py [--ref /root/reference]
+"""
+import argparse
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+from fal_net_amd import synthetic  # noqa: E402
+
+
+def install_shims():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+    def vgg19(pretrained=False, **kw):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M",
+               512, 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        m = types.SimpleNamespace(features=nn.Sequential(*layers))
+        sd = synthetic.seeded_vgg19_state_dict()
+        with torch.no_grad():
+            for idx in synthetic.VGG19_PC_CONVS:
+                m.features[idx].weight.copy_(sd[f"features.{idx}.weight"])
+                m.features[idx].bias.copy_(sd[f"features.{idx}.bias"])
+        return m
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.vgg19 = vgg19
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+
+
+def sample_idx(key, numel, k=16):
+    g = np.random.default_rng(zlib.crc32(("idx:" + key).encode()))
+    return g.integers(0, numel, size=min(k, numel))
+
+
+def np32(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    install_shims()
+    sys.path.insert(0, args.ref)
+    import models as ref_models  # noqa
+    import loss_functions as ref_loss  # noqa
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    def ref_model(n_levels):
+        sd = synthetic.seeded_falnetb_state_dict(n_levels)
+        return ref_models.FAL_netB({"state_dict": sd}, no_levels=n_levels)
+
+    # ---- G1: full forward incl. pan + masks, B=2 64x128, N=7 (full) and N=49 (strided) ----
+    for n_levels, stride in ((7, 1), (49, 2)):
+        left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=11, distinct=True)
+        m = ref_model(n_levels).eval()
+        with torch.no_grad():
+            pan, disp, maskL, maskR = m(left, mn, mx, ret_disp=True, ret_subocc=True, ret_pan=True)
+            flow = torch.ones(2, 1, 64, 128) * (mx.view(2, 1, 1, 1) / 100)
+            dlog0 = m.conv0(m.backbone(left, flow))
+        s = slice(None, None, stride)
+        np.savez(os.path.join(HERE, f"g1_forward_n{n_levels}.npz"),
+                 seed=11, max_disp=np32(mx), stride=stride, disp=np32(disp),
+                 p_im0=np32(pan)[:, :, s, s], maskL=np32(maskL)[:, :, s, s], maskR=np32(maskR)[:, :, s, s],
+                 dlog0=np32(dlog0)[:, :, ::4, ::4])
+        print("G1", n_levels, float(disp.mean()), float(pan.abs().mean()))
+
+    # ---- G2: one Stage-1 step (Train_Stage1_K.py:233-262), B=2 64x128 N=49 ----
+    def stage1(m, left, right, mx, a_p=0.01, a_sm=0.2 * 2 / 512, lr=1e-4):
+        groups = [{"params": m.bias_parameters(), "weight_decay": 0.0},
+                  {"params": m.weight_parameters(), "weight_decay": 0.0}]
+        opt = torch.optim.Adam(groups, lr=lr, betas=(0.5, 0.999))
+        m.train()
+        opt.zero_grad()
+        W = left.shape[3]
+        mn = mx * 2 / 300
+        rpan, ldisp = m(left, mn, mx, ret_disp=True, ret_pan=True, ret_subocc=False)
+        vgg_right = ref_loss.vgg(right)
+        rec = ref_loss.rec_loss_fnc(1, rpan, right, vgg_right, a_p)
+        sm = ref_loss.smoothness(left[:, :, :, int(0.20 * W)::], ldisp[:, :, :, int(0.20 * W)::], gamma=2)
+        loss = rec + a_sm * sm
+        loss.backward()
+        rec_d = {"loss": float(loss), "rec": float(rec), "sm": float(sm)}
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                rec_d["nograd:" + k] = 1.0
+                continue
+            g = p.grad.reshape(-1)
+            rec_d["gnorm:" + k] = float(g.norm())
+            rec_d["gsamp:" + k] = np32(g[sample_idx(k, g.numel())])
+        opt.step()
+        for k, p in m.named_parameters():
+            rec_d["after:" + k] = np32(p.reshape(-1)[sample_idx(k, p.numel())])
+        return rec_d, rpan, ldisp
+
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=21, distinct=True)
+    rec_d, rpan, ldisp = stage1(ref_model(49), left, right, mx)
+    np.savez(os.path.join(HERE, "g2_stage1_step.npz"), seed=21, max_disp=np32(mx), **rec_d)
+    print("G2", rec_d["loss"], rec_d["rec"], rec_d["sm"])
+
+    # ---- G3: Stage-2 loss scalars (Train_Stage2_K.py:247-329), teacher = same weights, N=7 ----
+    def stage2(m, fix, left, right, mx, a_p=0.01, a_sm=0.4 * 2 / 512, a_mr=1.0):
+        B, C, H, W = left.shape
+        mn = mx * 2 / 300
+        th = torch.zeros(B, 2, 3)
+        th[:, 0, 0] = 1
+        th[:, 1, 1] = 1
+        grid = F.affine_grid(th, [B, C, H, W], align_corners=True)
+        fg = grid.clone()
+        fg[:, :, :, 0] = -fg[:, :, :, 0]
+        gs = lambda t: F.grid_sample(t, fg, align_corners=True)
+        with torch.no_grad():
+            disp = fix(torch.cat((gs(left), right), 0), torch.cat((mn, mn), 0), torch.cat((mx, mx), 0),
+                       ret_disp=True, ret_pan=False, ret_subocc=False)
+            mldisp = gs(disp[0:B]).detach()
+            mrdisp = disp[B::].detach()
+        pan, disp, mask0, mask1 = m(torch.cat((left, gs(right)), 0), torch.cat((mn, mn), 0),
+                                    torch.cat((mx, mx), 0), ret_disp=True, ret_pan=True, ret_subocc=True)
+        rpan, lpan = pan[0:B], gs(pan[B::])
+        ldisp, rdisp = disp[0:B], gs(disp[B::])
+        lmask, rmask = mask0[0:B], gs(mask0[B::])
+        rlmask, lrmask = mask1[0:B], gs(mask1[B::])
+        vgg_right, vgg_left = ref_loss.vgg(right), ref_loss.vgg(left)
+        O_L = lmask * lrmask
+        O_L[:, :, :, 0:int(0.20 * W)] = 1
+        O_R = rmask * rlmask
+        O_R[:, :, :, int(0.80 * W)::] = 1
+        rec = (ref_loss.rec_loss_fnc(O_R, rpan, right, vgg_right, a_p) +
+               ref_loss.rec_loss_fnc(O_L, lpan, left, vgg_left, a_p)) / 2
+        sm = (ref_loss.smoothness(left[:, :, :, int(0.20 * W)::], ldisp[:, :, :, int(0.20 * W)::], gamma=2) +
+              ref_loss.smoothness(right[:, :, :, 0:int(0.80 * W)], rdisp[:, :, :, 0:int(0.80 * W)], gamma=2)) / 2
+        nmaxl = 1 / F.max_pool2d(mldisp, kernel_size=(H, W))
+        nmaxr = 1 / F.max_pool2d(mrdisp, kernel_size=(H, W))
+        mirror = (torch.mean(nmaxl * (1 - O_L)[:, :, :, int(0.20 * W)::] *
+                             torch.abs(ldisp - mldisp)[:, :, :, int(0.20 * W)::]) +
+                  torch.mean(nmaxr * (1 - O_R)[:, :, :, 0:int(0.80 * W)] *
+                             torch.abs(rdisp - mrdisp)[:, :, :, 0:int(0.80 * W)])) / 2
+        loss = rec + a_sm * sm + a_mr * mirror
+        loss.backward()
+        out = {"loss": float(loss), "rec": float(rec), "sm": float(sm), "mirror": float(mirror),
+               "O_L": np32(O_L), "O_R": np32(O_R), "ldisp": np32(ldisp), "rdisp": np32(rdisp)}
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                out["gnorm:" + k] = float(p.grad.norm())
+        return out
+
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=31, distinct=True)
+    out = stage2(ref_model(7).train(), ref_model(7).eval(), left, right, mx)
+    np.savez(os.path.join(HERE, "g3_stage2_step.npz"), seed=31, max_disp=np32(mx), **out)
+    print("G3", out["loss"], out["rec"], out["sm"], out["mirror"])
+
+    # ---- G4: config shape 256x512 N=49 B=1: strided outputs + Stage-1 scalars ----
+    left, right, mn, mx = synthetic.synthetic_pair(1, 256, 512, seed=1234)
+    rec_d, rpan, ldisp = stage1(ref_model(49), left, right, mx)
+    keep = {k: v for k, v in rec_d.items() if k in ("loss", "rec", "sm") or k.startswith("gnorm:")}
+    np.savez(os.path.join(HERE, "g4_config_256x512.npz"), seed=1234, max_disp=np32(mx),
+             disp=np32(ldisp)[:, :, ::8, ::8], p_im0=np32(rpan)[:, :, ::8, ::8], **keep)
+    print("G4", rec_d["loss"])
+
+    # ---- G5: ms_pp (Test_KITTI.py:287-300) on 96x320, N=49 ----
+    left, right, mn, mx = synthetic.synthetic_pair(1, 96, 320, seed=51)
+    m = ref_model(49).eval()
+    with torch.no_grad():
+        B, C, H, W = left.shape
+        th = torch.zeros(B, 2, 3)
+        th[:, 0, 0] = 1
+        th[:, 1, 1] = 1
+        fg = F.affine_grid(th, [B, C, H, W], align_corners=False)  # Test_KITTI.py:178 (defaults)
+        fg[:, :, :, 0] = -fg[:, :, :, 0]
+        disp = m(left, mn, mx, ret_disp=True, ret_subocc=False, ret_pan=False)
+        up = F.interpolate(F.grid_sample(left, fg, align_corners=False), scale_factor=2 / 3, mode="bilinear",
+                           align_corners=True)
+        d2 = m(up, mn, mx, ret_disp=True, ret_pan=False, ret_subocc=False)
+        d2 = (1 / (2 / 3)) * F.interpolate(d2, size=(H, W), mode="nearest")
+        d2 = F.grid_sample(d2, fg, align_corners=False)
+        norm = disp / (np.percentile(disp.detach().cpu().numpy(), 95) + 1e-6)
+        norm[norm > 1] = 1
+        pp = (1 - norm) * disp + norm * d2
+    np.savez(os.path.join(HERE, "g5_ms_pp.npz"), seed=51, max_disp=np32(mx), disp=np32(disp), ms_pp=np32(pp))
+    print("G5", float(pp.mean()))
+
+    # ---- G6: loss functions and metrics on tiny arrays ----
+    g = torch.Generator().manual_seed(61)
+    img = torch.rand(2, 3, 12, 20, generator=g) - 0.43
+    dsp = torch.rand(2, 1, 12, 20, generator=g) * 30 + 2
+    synth = torch.rand(2, 3, 16, 32, generator=g) - 0.43
+    label = torch.rand(2, 3, 16, 32, generator=g) - 0.43
+    mask = torch.rand(2, 1, 16, 32, generator=g)
+    dsp.requires_grad_(True)
+    synth.requires_grad_(True)
+    sm1 = ref_loss.smoothness(img, dsp, gamma=1)
+    sm2 = ref_loss.smoothness(img, dsp, gamma=2)
+    sm2.backward()
+    vl = ref_loss.vgg(label)
+    r_masked = ref_loss.rec_loss_fnc(mask, synth, label, vl, 0.01)
+    r_masked.backward()
+    r_one = ref_loss.rec_loss_fnc(1, synth.detach(), label, vl, 0.01)
+    r_l1 = ref_loss.rec_loss_fnc(mask, synth.detach(), label, None, 0.0)
+    import myUtils as ref_utils  # noqa
+    gt = np.random.default_rng(62).uniform(0, 90, size=(10, 1242)).astype(np.float32)
+    gt[gt < 20] = 0
+    pr = (gt + np.random.default_rng(63).normal(0, 3, size=gt.shape)).clip(0.5, 100).astype(np.float32)
+    errs = ref_utils.compute_kitti_errors(gt.copy(), pr.copy())
+    gd = np.random.default_rng(64).uniform(0, 60, size=(1, 8, 1242)).astype(np.float32)
+    gd[gd < 10] = 0
+    pd = np.random.default_rng(65).uniform(1, 60, size=(1, 8, 1242)).astype(np.float32)
+    tdep, pdep = ref_utils.disps_to_depths_kitti2015(gd, pd)
+    np.savez(os.path.join(HERE, "g6_losses_metrics.npz"),
+             img=np32(img), dsp=np32(dsp), sm_g1=float(sm1), sm_g2=float(sm2), sm_g2_grad=np32(dsp.grad),
+             synth=np32(synth), label=np32(label), mask=np32(mask), rec_masked=float(r_masked),
+             rec_masked_grad=np32(synth.grad), rec_one=float(r_one), rec_l1=float(r_l1),
+             vgg_label_means=np.array([float(v.mean()) for v in vl], dtype=np.float32),
+             gt=gt, pr=pr, kitti_errors=np.array(errs, dtype=np.float64),
+             gd=gd, pd=pd, gt_depth=np.asarray(tdep, dtype=np.float32), pred_depth=np.asarray(pdep, dtype=np.float32))
+    print("G6", float(sm2), float(r_masked), errs[0])
+
+    # ---- G7: odd size 75x250 (non-x2 nearest upsample, FAL_netB.py:58), disparity only ----
+    left, right, mn, mx = synthetic.synthetic_pair(1, 75, 250, seed=71)
+    with torch.no_grad():
+        disp = ref_model(49).eval()(left, mn, mx)
+    np.savez(os.path.join(HERE, "g7_odd_75x250.npz"), seed=71, max_disp=np32(mx), disp=np32(disp))
+    print("G7", float(disp.mean()))
+
+
+if __name__ == "__main__":
+    main()

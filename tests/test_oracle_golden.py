@@ -1,0 +1,156 @@
+"""Pin the CPU oracle against fixtures produced by the imported reference
+(tests/golden/make_goldens.py).  Runs anywhere (no GPU, no /root/reference)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from fal_net_amd import synthetic
+from oracle import falnet_oracle as O
+
+torch.set_num_threads(8)
+TOL = 1e-5  # restatement vs goldens at 1e-5
+# Warped outputs (p_im0, masks): the reference builds sample positions in fp32 *normalised*
+# coordinates (affine_grid + x_of, FAL_netB.py:231-246), which carries ~eps*(W-1)/2*|coord| ~ 3e-5..7e-5 px
+# of rounding noise at W=128..512; on white-noise images that is the same relative noise on the
+# bilinear blend.  The oracle's closed form d_n*(W-1)/W is the exact value of that expression,
+# so warped tensors are compared at 1e-4 (max-norm relative); scalars and disp stay at 1e-5.
+WARP_TOL = 1e-4
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def sample_idx(key, numel, k=16):
+    g = np.random.default_rng(zlib.crc32(("idx:" + key).encode()))
+    return g.integers(0, numel, size=min(k, numel))
+
+
+@pytest.mark.parametrize("n_levels", [7, 49])
+def test_g1_forward(golden_dir, n_levels):
+    g = load(golden_dir, f"g1_forward_n{n_levels}.npz")
+    st = int(g["stride"])
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    assert np.allclose(mx.numpy(), g["max_disp"])
+    sd = synthetic.seeded_falnetb_state_dict(n_levels)
+    with torch.no_grad():
+        out = O.falnet_forward(sd, left, mn, mx, True, True, True, return_dict=True)
+    s = slice(None, None, st)
+    assert rel(out["dlog0"].numpy()[:, :, ::4, ::4], g["dlog0"]) < TOL
+    assert rel(out["disp"].numpy(), g["disp"]) < TOL
+    assert rel(out["p_im0"].numpy()[:, :, s, s], g["p_im0"]) < WARP_TOL
+    assert rel(out["maskL"].numpy()[:, :, s, s], g["maskL"]) < WARP_TOL
+    assert rel(out["maskR"].numpy()[:, :, s, s], g["maskR"]) < WARP_TOL
+
+
+def _stage1(seed, B, H, W, n_levels, distinct):
+    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=seed, distinct=distinct)
+    params = O.leaf_params(synthetic.seeded_falnetb_state_dict(n_levels))
+    vsd = synthetic.seeded_vgg19_state_dict()
+    opt = O.OracleAdam(params)
+    return params, O.stage1_step(params, opt, vsd, left, right, mn, mx)
+
+
+def test_g2_stage1_step(golden_dir):
+    g = load(golden_dir, "g2_stage1_step.npz")
+    params, out = _stage1(int(g["seed"]), 2, 64, 128, 49, True)
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, k
+    nograd = sorted(k[7:] for k in g.files if k.startswith("nograd:"))
+    assert nograd == ["backbone.amask_conv.0.bias", "backbone.amask_conv.0.weight", "backbone.amask_conv.2.weight"]
+    for k, p in params.items():
+        if k in nograd:
+            assert out["grads"][k] is None
+            continue
+        gr = out["grads"][k].reshape(-1)
+        gn = float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - gn) / gn < 1e-4, k
+        idx = sample_idx(k, gr.numel())
+        assert np.abs(gr[idx].numpy() - g["gsamp:" + k]).max() <= 1e-4 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].numpy()
+        # Adam's first step moves every weight by ~lr*sign(g); compare the moved values
+        assert np.abs(after - g["after:" + k]).max() < 2e-5, k
+
+
+def test_g3_stage2_losses(golden_dir):
+    g = load(golden_dir, "g3_stage2_step.npz")
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    sd = synthetic.seeded_falnetb_state_dict(7)
+    params = O.leaf_params(sd)
+    vsd = synthetic.seeded_vgg19_state_dict()
+    out = O.stage2_losses(params, sd, vsd, left, right, mn, mx)
+    for k in ("loss", "rec", "sm", "mirror"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < 2e-5, k
+    for k in ("O_L", "O_R", "ldisp", "rdisp"):
+        assert rel(out[k].detach().numpy(), g[k]) < (WARP_TOL if k[0] == "O" else 2e-5), k
+    out["loss"].backward()
+    for k, p in params.items():
+        if p.grad is not None:
+            gn = float(g["gnorm:" + k])
+            assert abs(float(p.grad.norm()) - gn) / gn < 2e-4, k
+
+
+def test_g4_config_shape(golden_dir):
+    g = load(golden_dir, "g4_config_256x512.npz")
+    params, out = _stage1(int(g["seed"]), 1, 256, 512, 49, False)
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, k
+    assert rel(out["ldisp"].detach().numpy()[:, :, ::8, ::8], g["disp"]) < TOL
+    assert rel(out["rpan"].detach().numpy()[:, :, ::8, ::8], g["p_im0"]) < WARP_TOL
+    for k in params:
+        if ("gnorm:" + k) in g.files:
+            gn = float(g["gnorm:" + k])
+            # bias grads are 131072-term fp32 sums with cancellation: order noise ~2e-4
+            assert abs(float(out["grads"][k].norm()) - gn) / gn < 1e-3, k
+
+
+def test_g5_ms_pp(golden_dir):
+    g = load(golden_dir, "g5_ms_pp.npz")
+    left, right, mn, mx = synthetic.synthetic_pair(1, 96, 320, seed=int(g["seed"]))
+    sd = synthetic.seeded_falnetb_state_dict(49)
+    with torch.no_grad():
+        disp = O.falnet_forward(sd, left, mn, mx)
+        pp = O.ms_pp(sd, left, disp, mn, mx)
+    assert rel(disp.numpy(), g["disp"]) < TOL
+    assert rel(pp.numpy(), g["ms_pp"]) < 5e-5  # flip via grid_sample leaks ~1e-6 bilinear weights
+
+
+def test_g6_losses_and_metrics(golden_dir):
+    g = load(golden_dir, "g6_losses_metrics.npz")
+    vsd = synthetic.seeded_vgg19_state_dict()
+    img, dsp = torch.from_numpy(g["img"]), torch.from_numpy(g["dsp"]).requires_grad_(True)
+    assert abs(float(O.smoothness(img, dsp, 1)) - float(g["sm_g1"])) < 1e-5 * float(g["sm_g1"])
+    sm2 = O.smoothness(img, dsp, 2)
+    assert abs(float(sm2) - float(g["sm_g2"])) < 1e-5 * float(g["sm_g2"])
+    sm2.backward()
+    assert rel(dsp.grad.numpy(), g["sm_g2_grad"]) < 1e-5
+    synth = torch.from_numpy(g["synth"]).requires_grad_(True)
+    label, mask = torch.from_numpy(g["label"]), torch.from_numpy(g["mask"])
+    vl = O.vgg_forward(vsd, label)
+    assert np.allclose([float(v.mean()) for v in vl], g["vgg_label_means"], rtol=1e-5)
+    r = O.rec_loss_fnc(vsd, mask, synth, label, vl, 0.01)
+    assert abs(float(r) - float(g["rec_masked"])) < 1e-5 * float(g["rec_masked"])
+    r.backward()
+    assert rel(synth.grad.numpy(), g["rec_masked_grad"]) < 2e-5
+    assert abs(float(O.rec_loss_fnc(vsd, 1, synth.detach(), label, vl, 0.01)) - float(g["rec_one"])) < 1e-6
+    assert abs(float(O.rec_loss_fnc(vsd, mask, synth.detach(), label, None, 0.0)) - float(g["rec_l1"])) < 1e-6
+    errs = O.compute_kitti_errors(g["gt"], g["pr"])
+    assert np.allclose(errs, g["kitti_errors"], rtol=1e-6)
+    pd = O.disp_to_depth(g["pd"][0], focal=721.5377)
+    assert np.allclose(pd, g["pred_depth"][0], rtol=1e-6)
+
+
+def test_g7_odd_size(golden_dir):
+    g = load(golden_dir, "g7_odd_75x250.npz")
+    left, right, mn, mx = synthetic.synthetic_pair(1, 75, 250, seed=int(g["seed"]))
+    with torch.no_grad():
+        disp = O.falnet_forward(synthetic.seeded_falnetb_state_dict(49), left, mn, mx)
+    assert rel(disp.numpy(), g["disp"]) < TOL
