@@ -1,0 +1,53 @@
+"""Build libfalnet_hip.so (gfx950 code objects + C-ABI host stubs) in-tree with hipcc.
+
+`python -m fal_net_amd._build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU;
+the resulting .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libfalnet_hip.so")
+SOURCES = ["api.cpp", "med_head.hip", "losses.hip", "elementwise.hip", "conv.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "falnet_hip.h")]
+    jobs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src + ".o")
+        if force or _stale(obj, [path] + headers):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s + ".o") for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,121 @@
+"""ctypes binding of libfalnet_hip.so (the C-ABI declared in include/falnet_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, this raises.
+`import torch` happens first so that the HIP runtime the library binds to (soname
+libamdhip64.so.7) is the one PyTorch already loaded -- device pointers and streams are then
+shared between torch's caching allocator and these kernels.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
+OUT_NHWC, OUT_PLANAR_F32 = 0, 1
+CPAD = 32  # channel padding granule of NHWC tensors / packed weights (falnet_channel_pad)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfalnet_hip.so")
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sb", C.c_int64), ("sy", C.c_int64), ("sx", C.c_int64)]
+
+
+class Conv(C.Structure):
+    _fields_ = [("src", Src * 2), ("nsrc", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32),
+                ("weight", C.c_void_p), ("cin_total", C.c_int32), ("ntaps", C.c_int32),
+                ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("tap_w", C.c_int32 * 9),
+                ("w_taps", C.c_int32), ("w_rows", C.c_int32), ("isy", C.c_int32), ("isx", C.c_int32),
+                ("B", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32),
+                ("osy", C.c_int32), ("osx", C.c_int32), ("ooy", C.c_int32), ("oox", C.c_int32),
+                ("out", C.c_void_p), ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32),
+                ("out_cstride", C.c_int32), ("out_layout", C.c_int32), ("bias", C.c_void_p),
+                ("addend", C.c_void_p), ("act", C.c_int32), ("actout", C.c_void_p),
+                ("actout_kind", C.c_int32), ("dtype", C.c_int32)]
+
+
+class Wgrad(C.Structure):
+    _fields_ = [("src", Src * 2), ("nsrc", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32),
+                ("gout", C.c_void_p), ("gC", C.c_int32), ("ntaps", C.c_int32),
+                ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("isy", C.c_int32), ("isx", C.c_int32),
+                ("B", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("cin_total", C.c_int32),
+                ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+# name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/falnet_hip.h one to one
+SIGNATURES = {
+    "falnet_version": [],
+    "falnet_last_error": [],
+    "falnet_channel_pad": [_I],
+    "falnet_conv2d": [C.POINTER(Conv), _P],
+    "falnet_wgrad_workspace_bytes": [C.POINTER(Wgrad)],
+    "falnet_wgrad": [C.POINTER(Wgrad), _P],
+    "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
+    "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
+    "falnet_pack_weights": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "falnet_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "falnet_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "falnet_upsample_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "falnet_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "falnet_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "falnet_act_bwd": [_P, _P, _P, _L, _I, _I, _P],
+    "falnet_med_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "falnet_med_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "falnet_med_masks_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "falnet_l1_fwd": [_P, _P, _P, _I, _I, _L, _F, _P, _I, _P],
+    "falnet_l1_bwd": [_P, _P, _P, _I, _I, _L, _F, _P, _P, _I, _P],
+    "falnet_mse_fwd": [_P, _P, _L, _I, _F, _P, _I, _I, _P],
+    "falnet_mse_bwd": [_P, _P, _L, _I, _F, _P, _P, _I, _P],
+    "falnet_smooth_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
+    "falnet_smooth_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P],
+    "falnet_mask_mix": [_P, _P, _P, _P, _I, _I, _L, _P],
+    "falnet_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
+    "falnet_hflip": [_P, _P, _L, _I, _P],
+    "falnet_rowmax": [_P, _P, _I, _L, _P],
+}
+_RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `python -m fal_net_amd._build` "
+                "(there is no CPU or PyTorch fallback for the FAL_netB kernels)")
+        l = C.CDLL(_LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError here = header/library drift: fail loudly
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().falnet_last_error().decode(errors="replace")
+        raise RuntimeError(f"libfalnet_hip {what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported compute dtype {dt}")

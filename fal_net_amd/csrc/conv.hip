@@ -1,0 +1,587 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores (MFMA), forward / data-gradient / weight-gradient.
+//
+// Replaces every cuDNN conv2d call site of the hot path (models/FAL_netB.py:38,45,55,73,75,127,190;
+// loss_functions.py:21-29) and their autograd.  One gather kernel serves forward and dgrad: the GEMM is
+//   D[m, n] = sum_k A[m, k] * Bw[n, k],  m = output position, n = output channel, k = (tap, source, channel)
+// with A gathered on the fly from one or two NHWC sources (fused channel concat), optionally through a
+// nearest-neighbour upsample (fused F.interpolate), zero outside the image (padding=1), and a per-launch
+// tap table (stride, dgrad parity classes).  Both operands are staged K-contiguous in LDS in 64-byte rows
+// (32 bf16 / 16 f32 of K) padded to 80 B so that the 16-lane ds_read_b128 groups hit 16 distinct 16-B
+// slots; global->register->LDS double buffering, one barrier per K step.
+//   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate.
+//   f32 : v_mfma_f32_32x32x2_f32 (exact f32, the parity path); K is walked in a lane-half-permuted order
+//         (half h owns k in [8h, 8h+8)) so that each lane's operands are two ds_read_b128.
+// Wave tiling: 4 waves, 128 positions x {32,64,128} channels per workgroup.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CONV_THREADS 256
+#define CONV_BM 128
+#define ROWB 64   // K bytes per LDS row
+#define ROWP 80   // padded row pitch
+
+template <typename T> struct KC;
+template <> struct KC<float> { static constexpr int value = 16; };
+template <> struct KC<bf16_t> { static constexpr int value = 32; };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == FALNET_ACT_ELU) return v > 0.f ? v : (__expf(v) - 1.f);
+    if (act == FALNET_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+__device__ __forceinline__ float act_grad_from_out(float y, int kind) {
+    if (kind == FALNET_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (kind == FALNET_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+struct Frag { uint4 v[2]; };
+
+template <typename T, int MT, int NT, bool SWAP>
+__device__ __forceinline__ void mma_tile(const char* __restrict__ As, const char* __restrict__ Bs, int arow0, int brow0,
+                                         int lane, f32x16 (&acc)[MT][NT]) {
+    const int r = lane & 31, h = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const bf16x8*>(As + (arow0 + mt * 32 + r) * ROWP + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (brow0 + nt * 32 + r) * ROWP + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else {
+        float a[MT][8], b[NT][8];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4* p = reinterpret_cast<const float4*>(As + (arow0 + mt * 32 + r) * ROWP + h * 32);
+            const float4 x = p[0], y = p[1];
+            a[mt][0] = x.x; a[mt][1] = x.y; a[mt][2] = x.z; a[mt][3] = x.w;
+            a[mt][4] = y.x; a[mt][5] = y.y; a[mt][6] = y.z; a[mt][7] = y.w;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float4* p = reinterpret_cast<const float4*>(Bs + (brow0 + nt * 32 + r) * ROWP + h * 32);
+            const float4 x = p[0], y = p[1];
+            b[nt][0] = x.x; b[nt][1] = x.y; b[nt][2] = x.z; b[nt][3] = x.w;
+            b[nt][4] = y.x; b[nt][5] = y.y; b[nt][6] = y.z; b[nt][7] = y.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][s], a[mt][s], acc[mt][nt], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ fwd / dgrad
+template <typename T, int BN, bool SWAP>
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_conv_t p) {
+    constexpr int BM = CONV_BM;
+    constexpr int WAVES_N = BN >= 64 ? 2 : 1;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int A_LOADS = BM * 4 / CONV_THREADS;                        // 16-B segments per thread
+    constexpr int B_LOADS = (BN * 4 + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int KCV = KC<T>::value;
+    constexpr int EPS = 16 / sizeof(T);                                   // elements per 16-B segment
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWP + BM * 4];
+    auto Abuf = [&](int b) -> char* { return lds + b * (BM + BN) * ROWP; };
+    auto Bbuf = [&](int b) -> char* { return lds + b * (BM + BN) * ROWP + BM * ROWP; };
+    int* outpix = reinterpret_cast<int*>(lds + 2 * (BM + BN) * ROWP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t M = (int64_t)p.B * p.TH * p.TW;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int w_rows = p.w_rows;
+
+    // per-row output addresses (shared) and per-thread gather coordinates
+    if (tid < BM) {
+        const int64_t m = m0 + tid;
+        int o = -1;
+        if (m < M) {
+            const int tx = (int)(m % p.TW), ty = (int)((m / p.TW) % p.TH), b = (int)(m / ((int64_t)p.TW * p.TH));
+            const int oy = ty * p.osy + p.ooy, ox = tx * p.osx + p.oox;
+            if (oy < p.OH && ox < p.OW)
+                o = p.out_layout == FALNET_OUT_PLANAR_F32 ? (b * p.Cout * p.OH + oy) * p.OW + ox : (b * p.OH + oy) * p.OW + ox;
+        }
+        outpix[tid] = o;
+    }
+    int a_b[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int row = (tid + i * CONV_THREADS) >> 2;
+        const int64_t m = m0 + row;
+        if (m < M) {
+            a_x[i] = (int)(m % p.TW) * p.isx;
+            a_y[i] = (int)((m / p.TW) % p.TH) * p.isy;
+            a_b[i] = (int)(m / ((int64_t)p.TW * p.TH));
+        } else {
+            a_b[i] = -1;
+            a_x[i] = a_y[i] = 0;
+        }
+    }
+
+    int niter = 0;
+    for (int s = 0; s < p.nsrc; ++s) niter += p.ntaps * (p.src[s].C / KCV);
+
+    // K-walk state: source s, tap t, channel offset c0; srcoff = packed-weight offset of source s
+    int s_ = 0, t_ = 0, c0_ = 0, srcoff_ = 0;
+    uint4 areg[A_LOADS], breg[B_LOADS];
+
+    auto gload = [&]() {
+        const falnet_src_t& S = p.src[s_];
+        const int dy = p.tap_dy[t_], dx = p.tap_dx[t_];
+        const bool ups = (S.H != p.IH) || (S.W != p.IW);
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int seg = (tid + i * CONV_THREADS) & 3;
+            int vy = a_y[i] + dy, vx = a_x[i] + dx;
+            const bool ok = a_b[i] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                if (ups) {
+                    vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
+                    vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
+                }
+                const T* src = reinterpret_cast<const T*>(S.ptr) + (int64_t)a_b[i] * S.sb + (int64_t)vy * S.sy +
+                               (int64_t)vx * S.sx + c0_ + seg * EPS;
+                v = *reinterpret_cast<const uint4*>(src);
+            }
+            areg[i] = v;
+        }
+        const int64_t wk = (int64_t)p.tap_w[t_] * p.cin_total + srcoff_ + c0_;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            const int row = idx >> 2, seg = idx & 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < BN && n0 + row < w_rows) {
+                const T* w = reinterpret_cast<const T*>(p.weight) + (int64_t)(n0 + row) * p.w_taps * p.cin_total + wk + seg * EPS;
+                v = *reinterpret_cast<const uint4*>(w);
+            }
+            breg[i] = v;
+        }
+        // advance the K walk
+        c0_ += KCV;
+        if (c0_ >= S.C) {
+            c0_ = 0;
+            if (++t_ >= p.ntaps) {
+                t_ = 0;
+                srcoff_ += S.C;
+                ++s_;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            *reinterpret_cast<uint4*>(Abuf(buf) + (idx >> 2) * ROWP + (idx & 3) * 16) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            if ((idx >> 2) < BN) *reinterpret_cast<uint4*>(Bbuf(buf) + (idx >> 2) * ROWP + (idx & 3) * 16) = breg[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) gload();
+        mma_tile<T, MT, NT, SWAP>(Abuf(cur), Bbuf(cur), wm * WTM, wn * WTN, lane, acc);
+        if (it + 1 < niter) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: v = act(acc + bias + addend) * act'(actout) ----
+    const int r = lane & 31, h = lane >> 5;
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    if constexpr (!SWAP) {
+        T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wn * WTN + nt * 32 + r;
+            if (n >= p.Cout) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = wm * WTM + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    const int o = outpix[row];
+                    if (o < 0) continue;
+                    const int64_t off = (int64_t)o * p.out_cstride + n;
+                    float v = acc[mt][nt][j] + bias;
+                    if (addend) v += to_f32(addend[off]);
+                    v = apply_act(v, p.act);
+                    if (actout) v *= act_grad_from_out(to_f32(actout[off]), p.actout_kind);
+                    out[off] = from_f32<T>(v);
+                }
+        }
+    } else {
+        // swapped operands: D rows = channels, D columns (lanes) = positions -> planar f32 stores of
+        // 32 consecutive pixels per channel
+        float* out = reinterpret_cast<float*>(p.out);
+        const int64_t plane = (int64_t)p.OH * p.OW;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int o = outpix[wm * WTM + mt * 32 + r];
+            if (o < 0) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int n = n0 + wn * WTN + nt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (n >= p.Cout) continue;
+                    float v = acc[mt][nt][j] + (p.bias ? p.bias[n] : 0.f);
+                    v = apply_act(v, p.act);
+                    out[(int64_t)o + (int64_t)n * plane] = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// dW[co, tap, ci] = sum_p G[p, co] * In[nbr(p, tap), ci]: both operands are pixel-major (the contraction
+// index is the slow one), so the LDS tiles are [pixel][channel] and the MFMA operands are read transposed:
+//   bf16: ds_read_b64_tr_b16 (two per 8-element fragment);  f32: one ds_read_b32 per lane (A[m][k]: m on lanes).
+// Workgroup = 64 couts x 64 cins for one (tap, pixel split); 4 waves 2x2, 32x32 each; 64 pixels per K step.
+#define WG_BM 64
+#define WG_BN 64
+#define WG_KP 64
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_t p, int w_rows) {
+    constexpr int EPS = 16 / sizeof(T);
+    constexpr int ROW_ELEMS = 64;                          // channels per tile row
+    constexpr int SEGS = ROW_ELEMS / EPS;                  // 16-B segments per row (8 bf16 / 16 f32)
+    constexpr int PITCH = ROW_ELEMS * sizeof(T) + 16;      // bytes
+    constexpr int LOADS = WG_KP * SEGS / CONV_THREADS;     // per operand per thread (2 bf16 / 4 f32)
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * WG_KP * PITCH];
+    auto Gbuf = [&](int b) -> char* { return lds + b * 2 * WG_KP * PITCH; };
+    auto Ibuf = [&](int b) -> char* { return lds + b * 2 * WG_KP * PITCH + WG_KP * PITCH; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ci0 = blockIdx.x * WG_BN;   // packed input-channel offset (over all sources)
+    const int co0 = blockIdx.y * WG_BM;
+    const int tap = blockIdx.z % p.ntaps, split = blockIdx.z / p.ntaps;
+    const int dy = p.tap_dy[tap], dx = p.tap_dx[tap];
+    const int c_first = p.src[0].C;  // packed channels [0, c_first) come from source 0, the rest from source 1
+
+    const int64_t M = (int64_t)p.B * p.TH * p.TW;
+    const int64_t per = ((M + p.nsplit - 1) / p.nsplit + WG_KP - 1) / WG_KP * WG_KP;
+    const int64_t pbeg = (int64_t)split * per, pend = pbeg + per < M ? pbeg + per : M;
+    const int niter = pbeg < pend ? (int)((pend - pbeg + WG_KP - 1) / WG_KP) : 0;
+
+    uint4 greg[LOADS], ireg[LOADS];
+    int64_t pcur = pbeg;
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            const int row = idx / SEGS, seg = idx % SEGS;
+            const int64_t m = pcur + row;
+            uint4 g = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
+            if (m < pend) {
+                if (co0 + seg * EPS < p.gC)
+                    g = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.gout) + m * p.gC + co0 + seg * EPS);
+                const int tx = (int)(m % p.TW), ty = (int)((m / p.TW) % p.TH), b = (int)(m / ((int64_t)p.TW * p.TH));
+                int vy = ty * p.isy + dy, vx = tx * p.isx + dx;
+                const int cpk = ci0 + seg * EPS;  // packed channel of this 16-B segment
+                const falnet_src_t& S = p.src[cpk < c_first ? 0 : 1];
+                const int cloc = cpk < c_first ? cpk : cpk - c_first;
+                if (vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW && cpk < p.cin_total) {
+                    if ((S.H != p.IH) || (S.W != p.IW)) {
+                        vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
+                        vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
+                    }
+                    v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb +
+                                                        (int64_t)vy * S.sy + (int64_t)vx * S.sx + cloc);
+                }
+            }
+            greg[i] = g;
+            ireg[i] = v;
+        }
+        pcur += WG_KP;
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            const int row = idx / SEGS, seg = idx % SEGS;
+            *reinterpret_cast<uint4*>(Gbuf(buf) + row * PITCH + seg * 16) = greg[i];
+            *reinterpret_cast<uint4*>(Ibuf(buf) + row * PITCH + seg * 16) = ireg[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+
+    if (niter > 0) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < niter) gload();
+        const char* G = Gbuf(cur);
+        const char* I = Ibuf(cur);
+        if constexpr (sizeof(T) == 2) {
+            // lane group g16 = lane>>4: k-half = g16>>1, 16-channel block = g16&1; lane i=lane&15 supplies row q=i>>2, cols 4*(i&3)
+            const int i16 = lane & 15, g16 = lane >> 4;
+            const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
+#pragma unroll
+            for (int ks = 0; ks < WG_KP / 16; ++ks) {
+                const int krow = ks * 16 + kh * 8 + q;
+                const int acol = (wm * 32 + cb * 16 + pc * 4) * 2, bcol = (wn * 32 + cb * 16 + pc * 4) * 2;
+                typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + krow * PITCH + acol));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + (krow + 4) * PITCH + acol));
+                s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + krow * PITCH + bcol));
+                s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + (krow + 4) * PITCH + bcol));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+            }
+        } else {
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < WG_KP / 2; ++ks) {
+                const float a = *reinterpret_cast<const float*>(G + (ks * 2 + h) * PITCH + (wm * 32 + r) * 4);
+                const float b = *reinterpret_cast<const float*>(I + (ks * 2 + h) * PITCH + (wn * 32 + r) * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        }
+        if (it + 1 < niter) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // partial[split][tap][co][ci]
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + wn * 32 + r;
+    if (ci < p.cin_total) {
+        float* dst = p.partial + (((int64_t)split * p.ntaps + tap) * w_rows) * p.cin_total;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + wm * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[j];
+        }
+    }
+}
+
+// partial [nsplit][ntaps][w_rows][cin_total] -> OIHW f32, un-padding the (possibly two-group) channel axis
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int ntaps,
+                                                           int w_rows, int cin_total, float* __restrict__ grad, int cout,
+                                                           int cin, int c0_real, int c0_pad, int accumulate) {
+    const int64_t total = (int64_t)cout * cin * ntaps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % ntaps), ci = (int)((i / ntaps) % cin), co = (int)(i / ((int64_t)ntaps * cin));
+        const int cp = ci < c0_real ? ci : c0_pad + (ci - c0_real);
+        const int64_t slab = (int64_t)ntaps * w_rows * cin_total;
+        const float* src = partial + ((int64_t)t * w_rows + co) * cin_total + cp;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += src[k * slab];
+        grad[i] = accumulate ? grad[i] + s : s;
+    }
+}
+
+// db[c] += sum_p g[p, c];  blockIdx.y walks 256-channel chunks, threads = (pixel row group, channel)
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g, int64_t npix, int gC, int cout,
+                                                        float* __restrict__ db) {
+    __shared__ float red[256];
+    const int cw = gC < 256 ? gC : 256;         // channels handled per block (gC % 32 == 0, so 256 % cw == 0 or cw == 256)
+    const int rows = 256 / cw;
+    const int cl = threadIdx.x % cw, rr = threadIdx.x / cw;
+    const int c = blockIdx.y * 256 + cl;
+    float acc = 0.f;
+    if (c < gC)
+        for (int64_t pix = (int64_t)blockIdx.x * rows + rr; pix < npix; pix += (int64_t)gridDim.x * rows) acc += to_f32(g[pix * gC + c]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rr == 0) {
+        for (int k = 1; k < rows; ++k) acc += red[k * cw + cl];
+        if (c < cout) atomicAdd(db + c, acc);
+    }
+}
+
+// OIHW f32 -> packed operands (see falnet_hip.h)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int taps,
+                                                           int c0_real, int c0_pad, int cin_pad, int cout_pad,
+                                                           T* __restrict__ wf, T* __restrict__ wd) {
+    const int64_t total = (int64_t)cout_pad * taps * cin_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cp = (int)(i % cin_pad), t = (int)((i / cin_pad) % taps), co = (int)(i / ((int64_t)cin_pad * taps));
+        int ci = -1;
+        if (cp < c0_pad) {
+            if (cp < c0_real) ci = cp;
+        } else if (c0_real + (cp - c0_pad) < cin) {
+            ci = c0_real + (cp - c0_pad);
+        }
+        const float v = (co < cout && ci >= 0) ? w[((int64_t)co * cin + ci) * taps + t] : 0.f;
+        if (wf) wf[i] = from_f32<T>(v);
+        if (wd) wd[((int64_t)cp * taps + t) * cout_pad + co] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C-ABI
+static int check_src(const falnet_src_t& s, int kc, const char* who) {
+    FALNET_CHECK_ARG(s.ptr && s.C > 0 && s.C % kc == 0, "%s: source channels %d must be a positive multiple of %d", who, s.C, kc);
+    FALNET_CHECK_ARG(s.H > 0 && s.W > 0, "%s: empty source", who);
+    FALNET_CHECK_ARG((((uintptr_t)s.ptr) & 15) == 0, "%s: source pointer must be 16-B aligned", who);
+    return 0;
+}
+
+template <typename T, bool SWAP>
+static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t st) {
+    if (bn == 128)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, 128, SWAP>), grid, dim3(CONV_THREADS), 0, st, p);
+    else if (bn == 64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, 64, SWAP>), grid, dim3(CONV_THREADS), 0, st, p);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, 32, SWAP>), grid, dim3(CONV_THREADS), 0, st, p);
+}
+
+extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
+    FALNET_CHECK_ARG(pp, "conv2d: null descriptor");
+    const falnet_conv_t& p = *pp;
+    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16, "conv2d: bad dtype %d", p.dtype);
+    const int kc = p.dtype == FALNET_BF16 ? 32 : 16;
+    FALNET_CHECK_ARG(p.nsrc == 1 || p.nsrc == 2, "conv2d: nsrc=%d", p.nsrc);
+    int ctot = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        if (int r = check_src(p.src[s], kc, "conv2d")) return r;
+        ctot += p.src[s].C;
+    }
+    FALNET_CHECK_ARG(ctot <= p.cin_total, "conv2d: sources carry %d channels, packed weight row holds %d", ctot, p.cin_total);
+    FALNET_CHECK_ARG(p.ntaps >= 1 && p.ntaps <= 9 && p.w_taps >= 1, "conv2d: ntaps=%d", p.ntaps);
+    for (int t = 0; t < p.ntaps; ++t) FALNET_CHECK_ARG(p.tap_w[t] >= 0 && p.tap_w[t] < p.w_taps, "conv2d: tap_w[%d] out of range", t);
+    FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0 && p.IH > 0 && p.IW > 0 && p.OH > 0 && p.OW > 0, "conv2d: empty shape");
+    FALNET_CHECK_ARG(p.weight && p.out && p.Cout > 0 && p.w_rows >= p.Cout && p.w_rows % 32 == 0, "conv2d: bad weight/out (Cout=%d w_rows=%d)", p.Cout, p.w_rows);
+    FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
+    const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
+    FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");
+    const int bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (p.w_rows % 64 == 0 && p.Cout > 32 ? 64 : 32);
+    const int64_t M = (int64_t)p.B * p.TH * p.TW;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn));
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == FALNET_BF16) {
+        if (planar) launch_conv<bf16_t, true>(p, bn, grid, st);
+        else launch_conv<bf16_t, false>(p, bn, grid, st);
+    } else {
+        if (planar) launch_conv<float, true>(p, bn, grid, st);
+        else launch_conv<float, false>(p, bn, grid, st);
+    }
+    FALNET_RETURN_LAUNCH();
+}
+
+static inline int round32(int v) { return (v + 31) / 32 * 32; }
+
+extern "C" int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p) {
+    if (!p) return -1;
+    return (int64_t)p->nsplit * p->ntaps * round32(p->gC) * p->cin_total * (int64_t)sizeof(float);
+}
+
+extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
+    FALNET_CHECK_ARG(pp, "wgrad: null descriptor");
+    const falnet_wgrad_t& p = *pp;
+    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16, "wgrad: bad dtype %d", p.dtype);
+    FALNET_CHECK_ARG(p.nsrc == 1 || p.nsrc == 2, "wgrad: nsrc=%d", p.nsrc);
+    int ctot = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        if (int r = check_src(p.src[s], 32, "wgrad")) return r;
+        ctot += p.src[s].C;
+    }
+    FALNET_CHECK_ARG(ctot == p.cin_total, "wgrad: sources carry %d channels, cin_total=%d", ctot, p.cin_total);
+    FALNET_CHECK_ARG(p.gout && p.partial && p.gC > 0 && p.gC % 32 == 0 && p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= 9, "wgrad: bad argument");
+    FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0, "wgrad: empty shape");
+    const int w_rows = round32(p.gC);
+    const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);
+    if (p.dtype == FALNET_BF16)
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows);
+    else
+        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pad, int cin_total, float* grad,
+                                   int cout, int cin, int c0_real, int c0_pad, int accumulate, void* stream) {
+    FALNET_CHECK_ARG(partial && grad && nsplit >= 1 && ntaps >= 1 && cout > 0 && cin > 0 && cout <= cout_pad, "wgrad_reduce: bad argument");
+    FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_total, "wgrad_reduce: channel groups do not fit");
+    const int64_t total = (int64_t)cout * cin * ntaps;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, nsplit, ntaps, cout_pad,
+                       cin_total, grad, cout, cin, c0_real, c0_pad, accumulate);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db, int accumulate, int dtype,
+                                void* stream) {
+    FALNET_CHECK_ARG(g && db && npix > 0 && cout > 0 && cout <= gC, "bias_grad: bad argument");
+    FALNET_CHECK_ARG(gC % 32 == 0 && (gC >= 256 ? gC % 256 == 0 : 256 % gC == 0), "bias_grad: unsupported channel count %d", gC);
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * cout, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int rows = gC < 256 ? 256 / gC : 1;
+    int64_t gx = (npix + rows * 64 - 1) / (rows * 64);
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    const dim3 grid((unsigned)gx, (unsigned)((gC + 255) / 256));
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, npix, gC, cout, db);
+    else
+        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, npix, gC, cout, db);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_pack_weights(const float* w_oihw, int cout, int cin, int taps, int c0_real, int c0_pad,
+                                   int cin_pad_total, int cout_pad, void* wf, void* wd, int dtype, void* stream) {
+    FALNET_CHECK_ARG(w_oihw && (wf || wd) && cout > 0 && cin > 0 && taps >= 1, "pack_weights: bad argument");
+    FALNET_CHECK_ARG(cout_pad >= cout && cout_pad % 32 == 0 && cin_pad_total % 32 == 0, "pack_weights: pads must be multiples of 32");
+    FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_pad_total, "pack_weights: channel groups do not fit");
+    const int64_t total = (int64_t)cout_pad * taps * cin_pad_total;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, taps,
+                           c0_real, c0_pad, cin_pad_total, cout_pad, (bf16_t*)wf, (bf16_t*)wd);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, taps,
+                           c0_real, c0_pad, cin_pad_total, cout_pad, (float*)wf, (float*)wd);
+    FALNET_RETURN_LAUNCH();
+}

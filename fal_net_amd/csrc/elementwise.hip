@@ -1,0 +1,225 @@
+// Layout / resampling kernels around the NHWC conv stacks (gfx950, HBM-bound streaming).
+//   nchw_to_nhwc / nhwc_to_nchw : boundary between the reference's planar f32 API and the pixel-major
+//                                 compute layout (FAL_netB.py:200 input; loss_functions.py:36 VGG input)
+//   upsample_bwd                : adjoint of F.interpolate(mode='nearest') (FAL_netB.py:58)
+//   maxpool2 fwd/bwd            : torchvision VGG19 features[4,9,18] (loss_functions.py:21-29)
+#include "common.h"
+
+#define EW_THREADS 256
+static inline int ew_grid(int64_t n) {
+    int64_t g = (n + EW_THREADS - 1) / EW_THREADS;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// planar f32 -> NHWC T.  A 64-pixel x Cpad tile goes through LDS so that both the planar reads
+// (64 consecutive pixels per channel) and the NHWC writes (Cpad contiguous per pixel) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                  int C, int64_t HW, int Cpad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [64][Cpad+1]
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int ld = Cpad + 1;
+    for (int i = threadIdx.x; i < 64 * Cpad; i += blockDim.x) {
+        const int c = i >> 6, px = i & 63;
+        const int64_t p = p0 + px;
+        tile[px * ld + c] = (c < C && p < HW) ? src[((int64_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * Cpad; i += blockDim.x) {
+        const int px = i / Cpad, c = i % Cpad;
+        const int64_t p = p0 + px;
+        if (p < HW) dst[((int64_t)b * HW + p) * Cpad + c] = from_f32<T>(tile[px * ld + c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                                  int C, int64_t HW, int Cpad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);  // [64][Cpad+1]
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int ld = Cpad + 1;
+    for (int i = threadIdx.x; i < 64 * Cpad; i += blockDim.x) {
+        const int px = i / Cpad, c = i % Cpad;
+        const int64_t p = p0 + px;
+        tile[px * ld + c] = p < HW ? to_f32(src[((int64_t)b * HW + p) * Cpad + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * C; i += blockDim.x) {
+        const int c = i >> 6, px = i & 63;
+        const int64_t p = p0 + px;
+        if (p < HW) dst[((int64_t)b * C + c) * HW + p] = tile[px * ld + c];
+    }
+}
+
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }  // alpha = 1
+
+// nearest-upsample adjoint: source pixel (sy,sx) owns virtual rows [ceil(sy*IH/H), ceil((sy+1)*IH/H)) (the
+// set {vy : floor(vy*H/IH) == sy}); gather form, no atomics.  8 channels (one 16-B bf16 / two f32 vec) per thread.
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void upsample_bwd_kernel(const T* __restrict__ gup, T* __restrict__ gsrc,
+                                                                  const T* __restrict__ actout, int B, int IH, int IW,
+                                                                  int H, int W, int C) {
+    const int cg = C / 8;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * 8;
+        const int sx = (int)((i / cg) % W), sy = (int)((i / ((int64_t)cg * W)) % H), b = (int)(i / ((int64_t)cg * W * H));
+        const int vy0 = (sy * IH + H - 1) / H, vy1 = ((sy + 1) * IH + H - 1) / H;
+        const int vx0 = (sx * IW + W - 1) / W, vx1 = ((sx + 1) * IW + W - 1) / W;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int vy = vy0; vy < vy1; ++vy)
+            for (int vx = vx0; vx < vx1; ++vx) {
+                const T* g = gup + (((int64_t)b * IH + vy) * IW + vx) * C + c0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += to_f32(g[j]);
+            }
+        const int64_t o = (((int64_t)b * H + sy) * W + sx) * C + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[j];
+            if (actout) v *= elu_grad_from_out(to_f32(actout[o + j]));
+            gsrc[o + j] = from_f32<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                                  int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = (int64_t)B * OH * OW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), ox = (int)((i / C) % OW), oy = (int)((i / ((int64_t)C * OW)) % OH);
+        const int b = (int)(i / ((int64_t)C * OW * OH));
+        const T* p = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const float v = fmaxf(fmaxf(to_f32(p[0]), to_f32(p[C])), fmaxf(to_f32(p[(int64_t)W * C]), to_f32(p[(int64_t)W * C + C])));
+        y[i] = from_f32<T>(v);
+    }
+}
+
+// gx = gy routed to the FIRST max of the window in row-major order (aten max_pool2d_with_indices
+// tie rule), times relu'(x) (x is the ReLU output feeding the pool; x == 0 gets no gradient).
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                  T* __restrict__ gx, int B, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t total = (int64_t)B * OH * OW * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), ox = (int)((i / C) % OW), oy = (int)((i / ((int64_t)C * OW)) % OH);
+        const int b = (int)(i / ((int64_t)C * OW * OH));
+        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const int64_t off[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+        float best = to_f32(x[base]);
+        int arg = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const float v = to_f32(x[base + off[j]]);
+            if (v > best) {
+                best = v;
+                arg = j;
+            }
+        }
+        const float g = best > 0.f ? to_f32(gy[i]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gx[base + off[j]] = from_f32<T>(j == arg ? g : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                             T* __restrict__ gx, int64_t n, int kind) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float yy = to_f32(y[i]);
+        const float d = kind == FALNET_ACT_RELU ? (yy > 0.f ? 1.f : 0.f) : elu_grad_from_out(yy);
+        gx[i] = from_f32<T>(to_f32(g[i]) * d);
+    }
+}
+
+#define DISPATCH_T(dtype, KERNEL, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                                \
+        if ((dtype) == FALNET_BF16)                                                                                     \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<bf16_t>), grid, block, lds, (hipStream_t)stream, __VA_ARGS__);   \
+        else                                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<float>), grid, block, lds, (hipStream_t)stream, __VA_ARGS__);    \
+    } while (0)
+
+extern "C" int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cpad, int dtype,
+                                   void* stream) {
+    FALNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad <= 512, "nchw_to_nhwc: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    const dim3 grid((unsigned)((HW + 63) / 64), B);
+    const size_t lds = (size_t)64 * (Cpad + 1) * sizeof(float);
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, src, (bf16_t*)dst, C, HW, Cpad);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, src, (float*)dst, C, HW, Cpad);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cpad, int dtype,
+                                   void* stream) {
+    FALNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad <= 512, "nhwc_to_nchw: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    const dim3 grid((unsigned)((HW + 63) / 64), B);
+    const size_t lds = (size_t)64 * (Cpad + 1) * sizeof(float);
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, (const bf16_t*)src, dst, C, HW, Cpad);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, (const float*)src, dst, C, HW, Cpad);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_upsample_bwd(const void* gup, void* gsrc, const void* actout, int B, int IH, int IW, int H, int W,
+                                   int C, int dtype, void* stream) {
+    FALNET_CHECK_ARG(gup && gsrc && B > 0 && IH >= H && IW >= W && H > 0 && W > 0 && C % 8 == 0, "upsample_bwd: bad argument");
+    const int64_t total = (int64_t)B * H * W * (C / 8);
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)gup, (bf16_t*)gsrc, (const bf16_t*)actout, B, IH, IW, H, W, C);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)gup, (float*)gsrc, (const float*)actout, B, IH, IW, H, W, C);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    FALNET_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2_fwd: bad argument");
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)x, (float*)y, B, H, W, C);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy, void* gx, int B, int H, int W, int C,
+                                   int dtype, void* stream) {
+    (void)y;
+    FALNET_CHECK_ARG(x && gy && gx && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0,
+                     "maxpool2_bwd: bad argument (even H, W required)");
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, B, H, W, C);
+    else
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)x, (const float*)gy, (float*)gx, B, H, W, C);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_act_bwd(const void* g, const void* y, void* gx, int64_t n, int kind, int dtype, void* stream) {
+    FALNET_CHECK_ARG(g && y && gx && n > 0, "act_bwd: bad argument");
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)gx, n, kind);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           (const float*)g, (const float*)y, (float*)gx, n, kind);
+    FALNET_RETURN_LAUNCH();
+}

@@ -1,0 +1,320 @@
+// HBM-bound loss / optimiser kernels for gfx950 (reference: loss_functions.py:52-101,
+// Train_Stage1_K.py:180,248-262, Train_Stage2_K.py:248-253,319-324).  All f32 arithmetic.
+// Reductions: grid-stride partial sums in registers -> wave shuffle -> one LDS hop -> ONE float
+// atomic per workgroup on the scalar (grids capped at RED_BLOCKS so the single-address atomic
+// chain stays in the microsecond range; cdna guide G12).
+#include <math.h>
+#include "common.h"
+
+#define RED_THREADS 256
+#define RED_BLOCKS 512
+
+static inline int red_grid(int64_t work_items) {
+    int64_t g = (work_items + RED_THREADS - 1) / RED_THREADS;
+    return (int)(g < 1 ? 1 : (g > RED_BLOCKS ? RED_BLOCKS : g));
+}
+
+static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ L1 (loss_functions.py:53)
+__global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ mask, int C, int64_t HW,
+                                                             int64_t total, float scale, float* out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float d = fabsf(a[i] - b[i]);
+        if (mask) {
+            const int64_t bi = i / (C * HW), p = i % HW;
+            d *= mask[bi * HW + p];
+        }
+        acc += d;
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+
+__global__ __launch_bounds__(RED_THREADS) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ mask, int C, int64_t HW,
+                                                             int64_t total, float scale,
+                                                             const float* __restrict__ gscale, float* __restrict__ ga,
+                                                             int accumulate) {
+    const float gs = gscale ? gscale[0] * scale : scale;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        float g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+        if (mask) {
+            const int64_t bi = i / (C * HW), p = i % HW;
+            g *= mask[bi * HW + p];
+        }
+        ga[i] = accumulate ? ga[i] + g : g;
+    }
+}
+
+// ------------------------------------------------------------------ perceptual MSE on NHWC (loss_functions.py:61-65)
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              int64_t total, float scale, float* out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = to_f32(a[i]) - to_f32(b[i]);
+        acc += d * d;
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void mse_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                              int64_t total, float scale,
+                                                              const float* __restrict__ gscale, T* __restrict__ ga) {
+    const float gs = 2.f * scale * (gscale ? gscale[0] : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        ga[i] = from_f32<T>(gs * (to_f32(a[i]) - to_f32(b[i])));
+}
+
+// ------------------------------------------------------------------ edge-aware smoothness (loss_functions.py:70-101)
+struct SmoothArgs {
+    const float* img;
+    const float* disp;
+    int B, H, W, x0, x1;
+    float gamma;
+};
+
+__device__ __forceinline__ float gray_at(const SmoothArgs& s, int b, int y, int x) {
+    if (y < 0 || y >= s.H || x < s.x0 || x >= s.x1) return 0.f;  // zero padding applied AFTER the crop
+    const int64_t HW = (int64_t)s.H * s.W, o = (int64_t)y * s.W + x;
+    const float* im = s.img + (int64_t)b * 3 * HW;
+    return 0.299f * (im[o] + 0.411f) + 0.587f * (im[HW + o] + 0.432f) + 0.114f * (im[2 * HW + o] + 0.45f);
+}
+__device__ __forceinline__ float disp_at(const SmoothArgs& s, int b, int y, int x) {
+    if (y < 0 || y >= s.H || x < s.x0 || x >= s.x1) return 0.f;
+    return s.disp[((int64_t)b * s.H + y) * s.W + x];
+}
+__device__ __forceinline__ float wx_at(const SmoothArgs& s, int b, int y, int x) {  // exp(-gamma |dx_img|)
+    const float g = -gray_at(s, b, y, x - 1) + 2.f * gray_at(s, b, y, x) - gray_at(s, b, y, x + 1);
+    return __expf(-s.gamma * fabsf(g));
+}
+__device__ __forceinline__ float wy_at(const SmoothArgs& s, int b, int y, int x) {
+    const float g = -gray_at(s, b, y - 1, x) + 2.f * gray_at(s, b, y, x) - gray_at(s, b, y + 1, x);
+    return __expf(-s.gamma * fabsf(g));
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, float scale, float* out) {
+    __shared__ float red[16];
+    const int Wc = s.x1 - s.x0;
+    const int64_t total = (int64_t)s.B * s.H * Wc;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = s.x0 + (int)(i % Wc), y = (int)((i / Wc) % s.H), b = (int)(i / ((int64_t)Wc * s.H));
+        const float d = disp_at(s, b, y, x);
+        const float ax = fabsf(d - disp_at(s, b, y, x + 1)) + fabsf(d - disp_at(s, b, y, x - 1));
+        const float ay = fabsf(d - disp_at(s, b, y - 1, x)) + fabsf(d - disp_at(s, b, y + 1, x));
+        acc += ax * wx_at(s, b, y, x) + ay * wy_at(s, b, y, x);
+    }
+    const float r = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, r * scale);
+}
+
+// gather form of the adjoint: every pixel sums its own four terms and the one term each of its
+// four in-window neighbours holds on it.
+__global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, float scale,
+                                                                 const float* __restrict__ gscale,
+                                                                 float* __restrict__ gdisp, int accumulate) {
+    const float gs = scale * (gscale ? gscale[0] : 1.f);
+    const int64_t total = (int64_t)s.B * s.H * s.W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % s.W), y = (int)((i / s.W) % s.H), b = (int)(i / ((int64_t)s.W * s.H));
+        float g = 0.f;
+        if (x >= s.x0 && x < s.x1) {
+            const float d = disp_at(s, b, y, x);
+            const float dl = disp_at(s, b, y, x - 1), dr = disp_at(s, b, y, x + 1);
+            const float du = disp_at(s, b, y - 1, x), dd = disp_at(s, b, y + 1, x);
+            g += (sgn(d - dr) + sgn(d - dl)) * wx_at(s, b, y, x) + (sgn(d - du) + sgn(d - dd)) * wy_at(s, b, y, x);
+            if (x - 1 >= s.x0) g -= sgn(dl - d) * wx_at(s, b, y, x - 1);  // left pixel's dx_d  = d[x-1]-d[x]
+            if (x + 1 < s.x1) g -= sgn(dr - d) * wx_at(s, b, y, x + 1);   // right pixel's dx1_d = d[x+1]-d[x]
+            if (y - 1 >= 0) g -= sgn(du - d) * wy_at(s, b, y - 1, x);     // upper pixel's dy1_d = d[y-1]-d[y]
+            if (y + 1 < s.H) g -= sgn(dd - d) * wy_at(s, b, y + 1, x);    // lower pixel's dy_d  = d[y+1]-d[y]
+            g *= gs;
+        }
+        gdisp[i] = accumulate ? gdisp[i] + g : g;
+    }
+}
+
+// ------------------------------------------------------------------ mask mix (loss_functions.py:55)
+__global__ __launch_bounds__(RED_THREADS) void mask_mix_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ m, float* __restrict__ out,
+                                                               int C, int64_t HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bi = i / (C * HW), p = i % HW;
+        const float mv = m[bi * HW + p];
+        out[i] = mv * a[i] + (1.f - mv) * b[i];
+    }
+}
+
+// ------------------------------------------------------------------ fused flat Adam (torch.optim.Adam, Train_Stage1_K.py:180)
+// 7 f32 streams per element (read p,g,m,v; write p,m,v): 28 B/param, pure HBM streaming, float4 lanes.
+__global__ __launch_bounds__(RED_THREADS) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                           float step_size, float b1, float b2, float eps,
+                                                           float rsqrt_bc2, float grad_scale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x;
+        float* G = &gg.x;
+        float* M = &mm.x;
+        float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = G[j] * grad_scale;
+            M[j] = b1 * M[j] + (1.f - b1) * gr;
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+            P[j] -= step_size * M[j] / (sqrtf(V[j]) * rsqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float gr = g[i] * grad_scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gr, vi = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
+    }
+}
+
+// ------------------------------------------------------------------ flip / per-sample max (Train_Stage2_K.py:248-253,319)
+__global__ __launch_bounds__(RED_THREADS) void hflip_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int64_t total, int W) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        dst[i] = src[i - x + (W - 1 - x)];
+    }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void rowmax_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                             int64_t n) {
+    __shared__ float red[16];
+    const float* s = src + (int64_t)blockIdx.x * n;
+    float m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, s[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = red[0];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]);
+        out[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------ C-ABI
+extern "C" int falnet_l1_fwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW, float scale,
+                             float* out, int accumulate, void* stream) {
+    FALNET_CHECK_ARG(a && b && out && B > 0 && C > 0 && HW > 0, "l1_fwd: bad argument");
+    if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, mask, C, HW,
+                       total, scale, out);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_l1_bwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW, float scale,
+                             const float* gscale, float* ga, int accumulate, void* stream) {
+    FALNET_CHECK_ARG(a && b && ga && B > 0 && C > 0 && HW > 0, "l1_bwd: bad argument");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, mask, C,
+                       HW, total, scale, gscale, ga, accumulate);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, float* out,
+                              int accumulate, int dtype, void* stream) {
+    FALNET_CHECK_ARG(a && b && out && npix > 0 && Cpad > 0, "mse_fwd: bad argument");
+    if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
+    const int64_t total = npix * Cpad;
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(mse_fwd_kernel<bf16_t>, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)a, (const bf16_t*)b, total, scale, out);
+    else
+        hipLaunchKernelGGL(mse_fwd_kernel<float>, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                           (const float*)a, (const float*)b, total, scale, out);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, const float* gscale,
+                              void* ga, int dtype, void* stream) {
+    FALNET_CHECK_ARG(a && b && ga && npix > 0 && Cpad > 0, "mse_bwd: bad argument");
+    const int64_t total = npix * Cpad;
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(mse_bwd_kernel<bf16_t>, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                           (const bf16_t*)a, (const bf16_t*)b, total, scale, gscale, (bf16_t*)ga);
+    else
+        hipLaunchKernelGGL(mse_bwd_kernel<float>, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                           (const float*)a, (const float*)b, total, scale, gscale, (float*)ga);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma,
+                                 float scale, float* out, int accumulate, void* stream) {
+    FALNET_CHECK_ARG(img && disp && out && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd: bad argument");
+    if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
+    SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(red_grid((int64_t)B * H * (x1 - x0))), dim3(RED_THREADS), 0,
+                       (hipStream_t)stream, s, scale, out);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_smooth_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma,
+                                 float scale, const float* gscale, float* gdisp, int accumulate, void* stream) {
+    FALNET_CHECK_ARG(img && disp && gdisp && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_bwd: bad argument");
+    SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(red_grid((int64_t)B * H * W) * 4), dim3(RED_THREADS), 0,
+                       (hipStream_t)stream, s, scale, gscale, gdisp, accumulate);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, int B, int C, int64_t HW,
+                               void* stream) {
+    FALNET_CHECK_ARG(a && b && m && out && B > 0 && C > 0 && HW > 0, "mask_mix: bad argument");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(mask_mix_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, m, out,
+                       C, HW, total);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                float eps, int step, float grad_scale, void* stream) {
+    FALNET_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
+    FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-B aligned");
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)(lr / bc1), rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, step_size, b1,
+                       b2, eps, rsqrt_bc2, grad_scale);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stream) {
+    FALNET_CHECK_ARG(src && dst && src != dst && n_rows > 0 && W > 0, "hflip: bad argument (in-place not supported)");
+    const int64_t total = n_rows * W;
+    hipLaunchKernelGGL(hflip_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, src, dst, total, W);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream) {
+    FALNET_CHECK_ARG(src && out && B > 0 && n > 0, "rowmax: bad argument");
+    hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, src, out, n);
+    FALNET_RETURN_LAUNCH();
+}

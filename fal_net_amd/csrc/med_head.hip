@@ -1,0 +1,332 @@
+// Fused MED head for gfx950: softmax over the N disparity planes, expectation, plane-sweep warp,
+// second softmax and view blend in ONE pass over the logits (reference: models/FAL_netB.py:216-282,
+// ~1500 aten launches and an O(N^2) torch.cat there).
+//
+// Layout: everything planar f32 (the warp is a shift along the contiguous W axis).  One workgroup
+// owns one image row (b, y): the row of the left image (and, in backward, the per-pixel softmax
+// statistics and upstream gradients) is staged in LDS once and reused by all N planes; each lane owns
+// pixels x and walks the planes with a chunked online softmax (one rescale per 8 planes), so no
+// cross-lane reduction is needed and the only HBM traffic is the N logit rows, read once.
+// HBM-bound: algorithmic bytes (N+7)*HW*4 forward, (2N+7)*HW*4 backward per sample.
+#include <math.h>
+#include "common.h"
+
+#define HEAD_THREADS 256
+#define HEAD_MAXN 128
+#define CH 8  // planes per online-softmax chunk
+
+struct PlaneTab {  // per-sample plane table in LDS
+    float d[HEAD_MAXN];  // disparity of plane n in pixels (FAL_netB.py:223-225)
+    float a[HEAD_MAXN];  // fractional part of the shift s_n = d_n (W-1)/W
+    int k[HEAD_MAXN];    // integer part
+};
+
+__device__ __forceinline__ void build_plane_tab(PlaneTab& t, float mn, float mx, int N, int W) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float c = (float)n / (float)(N - 1);
+        const float d = mx * expf(logf(mx / mn) * (c - 1.0f));
+        const float s = d * (float)(W - 1) / (float)W;  // 2d/W normalised * (W-1)/2 (align_corners=True)
+        const float kf = floorf(s);
+        t.d[n] = d;
+        t.k[n] = (int)kf;
+        t.a[n] = s - kf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- forward
+// LDS: PlaneTab | left[3][W+2] (two trailing zeros: out-of-range taps read 0 without a branch)
+__global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
+    const float* __restrict__ max_disp, float* __restrict__ disp, float* __restrict__ p_im0,
+    float* __restrict__ stats, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    float* lrow = reinterpret_cast<float*>(smem + sizeof(PlaneTab));
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    const int WP = W + 2;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    const bool want_pan = p_im0 != nullptr;
+    if (want_pan) {
+        for (int i = threadIdx.x; i < 3 * WP; i += blockDim.x) {
+            const int c = i / WP, x = i % WP;
+            lrow[i] = x < W ? left[((int64_t)b * 3 + c) * HW + (int64_t)y * W + x] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float* Lrow = dlog0 + (int64_t)b * N * HW + (int64_t)y * W;
+
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        float m0 = -INFINITY, z0 = 0.f, dacc = 0.f;
+        float mw = -INFINITY, zw = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int n0 = 0; n0 < N; n0 += CH) {
+            float l0[CH], lw[CH];
+            float cm0 = -INFINITY, cmw = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int n = n0 + j;
+                if (n < N) {
+                    const float* Ln = Lrow + (int64_t)n * HW;
+                    l0[j] = Ln[x];
+                    const int i0 = x + tab.k[n];
+                    const float a = tab.a[n];
+                    const float t0 = i0 < W ? Ln[i0] : 0.f;           // zero padding: OOB logit is 0, not -inf
+                    const float t1 = i0 + 1 < W ? Ln[i0 + 1] : 0.f;   // (grid_sample padding_mode='zeros')
+                    lw[j] = (1.f - a) * t0 + a * t1;
+                } else {
+                    l0[j] = -INFINITY;
+                    lw[j] = -INFINITY;
+                }
+                cm0 = fmaxf(cm0, l0[j]);
+                cmw = fmaxf(cmw, lw[j]);
+            }
+            if (cm0 > m0) {
+                const float s = __expf(m0 - cm0);
+                z0 *= s;
+                dacc *= s;
+                m0 = cm0;
+            }
+            if (cmw > mw) {
+                const float s = __expf(mw - cmw);
+                zw *= s;
+                p0 *= s;
+                p1 *= s;
+                p2 *= s;
+                mw = cmw;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int n = n0 + j;
+                if (n < N) {
+                    const float e = __expf(l0[j] - m0);
+                    z0 += e;
+                    dacc += tab.d[n] * e;
+                    const float ew = __expf(lw[j] - mw);
+                    zw += ew;
+                    if (want_pan) {
+                        const int i0 = min(x + tab.k[n], W);
+                        const float a = tab.a[n];
+                        p0 += ew * ((1.f - a) * lrow[i0] + a * lrow[i0 + 1]);
+                        p1 += ew * ((1.f - a) * lrow[WP + i0] + a * lrow[WP + i0 + 1]);
+                        p2 += ew * ((1.f - a) * lrow[2 * WP + i0] + a * lrow[2 * WP + i0 + 1]);
+                    }
+                }
+            }
+        }
+        const int64_t pix = (int64_t)y * W + x;
+        if (disp) disp[(int64_t)b * HW + pix] = dacc / z0;
+        if (want_pan) {
+            const float r = 1.f / zw;
+            p_im0[((int64_t)b * 3 + 0) * HW + pix] = p0 * r;
+            p_im0[((int64_t)b * 3 + 1) * HW + pix] = p1 * r;
+            p_im0[((int64_t)b * 3 + 2) * HW + pix] = p2 * r;
+        }
+        if (stats) {
+            float* st = stats + (int64_t)b * 4 * HW + pix;
+            st[0] = m0;
+            st[HW] = z0;
+            st[2 * HW] = mw;
+            st[3 * HW] = zw;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward
+// grad_dlog0[n, x'] = (1-a) gwl_n(x'-k) + a gwl_n(x'-k-1) + gd(x') sm_n(x') (d_n - disp(x'))
+//   gwl_n(x) = Dprob_n(x) (sum_c gp_c(x) S_{c,n}(x) - q(x)),  q = sum_c gp_c p_c
+// Each (n, x') is owned by exactly one lane (gather form of the transposed warp): no atomics.
+// LDS rows (index x+1, one zero column in front and two behind):
+//   rowU[3] = gp_c / Zw, rowV = q / Zw, rowM = Mw   (at the *source* pixel x)
+__global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
+    const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
+    const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,
+    float* __restrict__ gdlog0, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    const int WP = W + 3;
+    float* rowU = reinterpret_cast<float*>(smem + sizeof(PlaneTab));  // [3][WP]
+    float* rowV = rowU + 3 * WP;
+    float* rowM = rowV + WP;
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t rowoff = (int64_t)y * W;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    const bool has_pan = gpan != nullptr, has_disp = gdisp != nullptr;
+    const float* st = stats + (int64_t)b * 4 * HW + rowoff;
+    if (has_pan) {
+        for (int i = threadIdx.x; i < WP; i += blockDim.x) {
+            const int x = i - 1;
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f, v = 0.f, m = 0.f;
+            if (x >= 0 && x < W) {
+                const float rz = 1.f / st[3 * HW + x];
+                const float g0 = gpan[((int64_t)b * 3 + 0) * HW + rowoff + x];
+                const float g1 = gpan[((int64_t)b * 3 + 1) * HW + rowoff + x];
+                const float g2 = gpan[((int64_t)b * 3 + 2) * HW + rowoff + x];
+                const float q = g0 * p_im0[((int64_t)b * 3 + 0) * HW + rowoff + x] +
+                                g1 * p_im0[((int64_t)b * 3 + 1) * HW + rowoff + x] +
+                                g2 * p_im0[((int64_t)b * 3 + 2) * HW + rowoff + x];
+                u0 = g0 * rz;
+                u1 = g1 * rz;
+                u2 = g2 * rz;
+                v = q * rz;
+                m = st[2 * HW + x];
+            }
+            rowU[i] = u0;
+            rowU[WP + i] = u1;
+            rowU[2 * WP + i] = u2;
+            rowV[i] = v;
+            rowM[i] = m;
+        }
+    }
+    __syncthreads();
+    const float* Lrow = dlog0 + (int64_t)b * N * HW + rowoff;
+    float* Grow = gdlog0 + (int64_t)b * N * HW + rowoff;
+
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        // per-pixel constants across planes
+        float lm[3], lc[3], lp[3];
+        if (has_pan) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* lr = left + ((int64_t)b * 3 + c) * HW + rowoff;
+                lm[c] = x > 0 ? lr[x - 1] : 0.f;
+                lc[c] = lr[x];
+                lp[c] = x + 1 < W ? lr[x + 1] : 0.f;
+            }
+        }
+        float m0 = 0.f, rz0 = 0.f, gd = 0.f, dsp = 0.f;
+        if (has_disp) {
+            m0 = st[x];
+            rz0 = 1.f / st[HW + x];
+            gd = gdisp[(int64_t)b * HW + rowoff + x];
+            dsp = disp[(int64_t)b * HW + rowoff + x];
+        }
+        for (int n = 0; n < N; ++n) {
+            const float* Ln = Lrow + (int64_t)n * HW;
+            const float Lc = Ln[x];
+            float g = 0.f;
+            if (has_pan) {
+                const int k = tab.k[n];
+                const float a = tab.a[n];
+                const float Lm = x > 0 ? Ln[x - 1] : 0.f;
+                const float Lp = x + 1 < W ? Ln[x + 1] : 0.f;
+                const int xa = x - k;  // source pixel whose first tap is x
+                if (xa >= 0) {         // xa <= W-1 always (k >= 0)
+                    const float wl = (1.f - a) * Lc + a * Lp;
+                    const float G = rowU[xa + 1] * ((1.f - a) * lc[0] + a * lp[0]) +
+                                    rowU[WP + xa + 1] * ((1.f - a) * lc[1] + a * lp[1]) +
+                                    rowU[2 * WP + xa + 1] * ((1.f - a) * lc[2] + a * lp[2]);
+                    g += (1.f - a) * __expf(wl - rowM[xa + 1]) * (G - rowV[xa + 1]);
+                }
+                const int xb = xa - 1;  // source pixel whose second tap is x
+                if (xb >= 0) {
+                    const float wl = (1.f - a) * Lm + a * Lc;
+                    const float G = rowU[xb + 1] * ((1.f - a) * lm[0] + a * lc[0]) +
+                                    rowU[WP + xb + 1] * ((1.f - a) * lm[1] + a * lc[1]) +
+                                    rowU[2 * WP + xb + 1] * ((1.f - a) * lm[2] + a * lc[2]);
+                    g += a * __expf(wl - rowM[xb + 1]) * (G - rowV[xb + 1]);
+                }
+            }
+            if (has_disp) g += gd * __expf(Lc - m0) * rz0 * (tab.d[n] - dsp);
+            Grow[(int64_t)n * HW + x] = g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- masks
+// maskR(x) = min(1, sum_n (1-a) sm_n(x+k) + a sm_n(x+k+1)),   sm = softmax(dlog0)        (FAL_netB.py:266-267)
+// maskL(x) = min(1, sum_n a Dprob_n(x-k-1) + (1-a) Dprob_n(x-k))  (shift by -s_n)         (FAL_netB.py:270-273)
+// Dprob_n(x) is rebuilt from its two logit taps and the saved (maxW, sumW): no N*HW workspace.
+__global__ __launch_bounds__(HEAD_THREADS) void med_masks_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ min_disp, const float* __restrict__ max_disp,
+    const float* __restrict__ stats, float* __restrict__ maskL, float* __restrict__ maskR, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    const int WP = W + 3;
+    float* rM0 = reinterpret_cast<float*>(smem + sizeof(PlaneTab));  // index x+1
+    float* rZ0 = rM0 + WP;   // 1/sum0, 0 outside the row
+    float* rMw = rZ0 + WP;
+    float* rZw = rMw + WP;   // 1/sumW, 0 outside
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t rowoff = (int64_t)y * W;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    const float* st = stats + (int64_t)b * 4 * HW + rowoff;
+    for (int i = threadIdx.x; i < WP; i += blockDim.x) {
+        const int x = i - 1;
+        const bool in = x >= 0 && x < W;
+        rM0[i] = in ? st[x] : 0.f;
+        rZ0[i] = in ? 1.f / st[HW + x] : 0.f;
+        rMw[i] = in ? st[2 * HW + x] : 0.f;
+        rZw[i] = in ? 1.f / st[3 * HW + x] : 0.f;
+    }
+    __syncthreads();
+    const float* Lrow = dlog0 + (int64_t)b * N * HW + rowoff;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        float mr = 0.f, ml = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* Ln = Lrow + (int64_t)n * HW;
+            const int k = tab.k[n];
+            const float a = tab.a[n];
+            // right mask: samples of softmax(dlog0)_n at x+k, x+k+1 (zero outside the image)
+            const int i0 = min(x + k, W), i1 = min(x + k + 1, W);
+            const float t0 = i0 < W ? Ln[i0] : 0.f, t1 = i1 < W ? Ln[i1] : 0.f;
+            mr += (1.f - a) * __expf(t0 - rM0[i0 + 1]) * rZ0[i0 + 1] + a * __expf(t1 - rM0[i1 + 1]) * rZ0[i1 + 1];
+            // left mask: samples of Dprob_n at x-k-1 and x-k
+            const float Lc = Ln[x];
+            const float Lm = x > 0 ? Ln[x - 1] : 0.f;
+            const float Lp = x + 1 < W ? Ln[x + 1] : 0.f;
+            const int xa = x - k, xb = xa - 1;
+            if (xa >= 0) ml += (1.f - a) * __expf((1.f - a) * Lc + a * Lp - rMw[xa + 1]) * rZw[xa + 1];
+            if (xb >= 0) ml += a * __expf((1.f - a) * Lm + a * Lc - rMw[xb + 1]) * rZw[xb + 1];
+        }
+        maskR[(int64_t)b * HW + rowoff + x] = fminf(mr, 1.f);
+        maskL[(int64_t)b * HW + rowoff + x] = fminf(ml, 1.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- C-ABI
+static int check_head(int B, int N, int H, int W) {
+    FALNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "med_head: empty shape B=%d H=%d W=%d", B, H, W);
+    FALNET_CHECK_ARG(N >= 2 && N <= HEAD_MAXN, "med_head: N=%d outside [2,%d]", N, HEAD_MAXN);
+    FALNET_CHECK_ARG((size_t)(W + 3) * 5 * 4 + sizeof(PlaneTab) <= 160 * 1024, "med_head: W=%d too wide for LDS", W);
+    return 0;
+}
+
+extern "C" int falnet_med_head_fwd(const float* dlog0, const float* left, const float* min_disp,
+                                   const float* max_disp, float* disp, float* p_im0, float* stats, int B, int N,
+                                   int H, int W, void* stream) {
+    if (int r = check_head(B, N, H, W)) return r;
+    FALNET_CHECK_ARG(dlog0 && min_disp && max_disp, "med_head_fwd: null input");
+    FALNET_CHECK_ARG(!p_im0 || left, "med_head_fwd: p_im0 requested without left image");
+    const size_t lds = sizeof(PlaneTab) + (size_t)3 * (W + 2) * sizeof(float);
+    hipLaunchKernelGGL(med_head_fwd_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
+                       min_disp, max_disp, disp, p_im0, stats, N, H, W);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_med_head_bwd(const float* dlog0, const float* left, const float* min_disp,
+                                   const float* max_disp, const float* disp, const float* p_im0,
+                                   const float* stats, const float* grad_disp, const float* grad_p_im0,
+                                   float* grad_dlog0, int B, int N, int H, int W, void* stream) {
+    if (int r = check_head(B, N, H, W)) return r;
+    FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && grad_dlog0, "med_head_bwd: null input");
+    FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd: grad_p_im0 needs left and p_im0");
+    FALNET_CHECK_ARG(!grad_disp || disp, "med_head_bwd: grad_disp needs disp");
+    const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
+    hipLaunchKernelGGL(med_head_bwd_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
+                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0, N, H, W);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp,
+                                    const float* stats, float* maskL, float* maskR, int B, int N, int H, int W,
+                                    void* stream) {
+    if (int r = check_head(B, N, H, W)) return r;
+    FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && maskL && maskR, "med_masks_fwd: null input");
+    const size_t lds = sizeof(PlaneTab) + (size_t)4 * (W + 3) * sizeof(float);
+    hipLaunchKernelGGL(med_masks_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, min_disp,
+                       max_disp, stats, maskL, maskR, N, H, W);
+    FALNET_RETURN_LAUNCH();
+}

@@ -1,0 +1,498 @@
+"""FAL_netB on MI355X: the reference's nn.Module surface over hand-written HIP kernels.
+
+Drop-in for `models.FAL_netB` of JuanLuisGonzalez/FAL_net (models/FAL_netB.py:28-32,179-297):
+same factory signature, same `forward(input_left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan)`
+contract and return ordering, same `state_dict` keys (51 tensors), same
+`weight_parameters()` / `bias_parameters()`.  Underneath there is no aten compute: the module owns a
+static *plan* per input shape -- pre-allocated NHWC activations and a list of libfalnet_hip.so
+launches (implicit-GEMM MFMA convolutions with fused bias/ELU/residual/concat/upsample, the fused MED
+head) -- and one autograd.Function whose backward replays the hand-written adjoint plan and deposits
+weight gradients straight into a flat f32 buffer that `p.grad` views alias (one RCCL all-reduce and one
+fused Adam launch operate on that buffer, see fal_net_amd/train.py).
+
+`compute_dtype`: torch.float32 (exact-f32 MFMA; the parity path, 1e-4 vs the reference) or
+torch.bfloat16 (bf16 MFMA with f32 accumulation; the throughput path).  Parameters, the MED head,
+losses and Adam stay f32 in both.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from ..ops import PackedConv, pad_c
+
+__all__ = ["FAL_netB"]
+
+
+def FAL_netB(data=None, no_levels=49, compute_dtype=None):
+    """Factory with the reference's signature (models/FAL_netB.py:28-32)."""
+    model = FAL_net(batchNorm=False, no_levels=no_levels, compute_dtype=compute_dtype)
+    if data is not None:
+        model.load_state_dict(data["state_dict"])
+    return model
+
+
+# ---- parameter holders mirroring the reference module tree (so state_dict keys match) ----
+def conv_elu(batchNorm, in_planes, out_planes, kernel_size=3, stride=1, pad=1):
+    assert not batchNorm, "FAL_netB is built with batchNorm=False (models/FAL_netB.py:29)"
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size, stride, pad, bias=True), nn.ELU(inplace=True))
+
+
+class deconv(nn.Module):
+    def __init__(self, in_planes, out_planes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, out_planes, 3, 1, 1, bias=False)
+
+
+class residual_block(nn.Module):
+    def __init__(self, in_planes):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
+
+
+def predict_amask(in_planes, out_planes):
+    # constructed but never executed by the reference (FAL_netB.py:128); kept for checkpoint compatibility
+    return nn.Sequential(nn.Conv2d(in_planes, in_planes // 2, 3, 1, 1, bias=True), nn.ELU(inplace=True),
+                         nn.Conv2d(in_planes // 2, out_planes, 3, 1, 1, bias=False), nn.Sigmoid())
+
+
+class BackBone(nn.Module):
+    """Parameter tree of the reference BackBone (FAL_netB.py:92-138); compute lives in FalnetPlan."""
+
+    def __init__(self, batchNorm=False, no_in=3, no_flow=1, no_out=64):
+        super().__init__()
+        self.conv0 = conv_elu(batchNorm, no_in, 32)
+        self.conv0_1 = residual_block(32)
+        self.conv1 = conv_elu(batchNorm, 32 + no_flow, 64, stride=2)
+        self.conv1_1 = residual_block(64)
+        self.conv2 = conv_elu(batchNorm, 64, 128, stride=2)
+        self.conv2_1 = residual_block(128)
+        self.conv3 = conv_elu(batchNorm, 128, 256, stride=2)
+        self.conv3_1 = residual_block(256)
+        self.conv4 = conv_elu(batchNorm, 256, 256, stride=2)
+        self.conv4_1 = residual_block(256)
+        self.conv5 = conv_elu(batchNorm, 256, 256, stride=2)
+        self.conv5_1 = residual_block(256)
+        self.conv6 = conv_elu(batchNorm, 256, 512, stride=2)
+        self.conv6_1 = residual_block(512)
+        self.deconv6 = deconv(512, 256)
+        self.iconv6 = conv_elu(batchNorm, 256 + 256, 256)
+        self.deconv5 = deconv(256, 128)
+        self.iconv5 = conv_elu(batchNorm, 128 + 256, 256)
+        self.deconv4 = deconv(256, 128)
+        self.iconv4 = conv_elu(batchNorm, 128 + 256, 256)
+        self.deconv3 = deconv(256, 128)
+        self.iconv3 = conv_elu(batchNorm, 128 + 128, 128)
+        self.deconv2 = deconv(128, 64)
+        self.iconv2 = conv_elu(batchNorm, 64 + 64, 64)
+        self.deconv1 = deconv(64, 64)
+        self.iconv1 = nn.Conv2d(32 + 64, no_out, 3, 1, 1, bias=False)
+        self.amask_conv = predict_amask(32 + 64, 1)
+        for m in self.modules():  # FAL_netB.py:131-138
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight.data)
+                if m.bias is not None:
+                    m.bias.data.zero_()
+
+
+# encoder level i: (stride-2 conv name, residual block name, channels)
+_ENC = [("conv0", "conv0_1", 32), ("conv1", "conv1_1", 64), ("conv2", "conv2_1", 128), ("conv3", "conv3_1", 256),
+        ("conv4", "conv4_1", 256), ("conv5", "conv5_1", 256), ("conv6", "conv6_1", 512)]
+# decoder level i (6..1): (deconv name, deconv Cout, iconv name, iconv Cout)
+_DEC = {6: ("deconv6", 256, "iconv6", 256), 5: ("deconv5", 128, "iconv5", 256), 4: ("deconv4", 128, "iconv4", 256),
+        3: ("deconv3", 128, "iconv3", 128), 2: ("deconv2", 64, "iconv2", 64), 1: ("deconv1", 64, "iconv1", None)}
+
+
+class FalnetPlan:
+    """Static launch plan of FAL_net.forward / backward for one (B, H, W, dtype, device)."""
+
+    WS_BYTES = 96 << 20  # wgrad split-K slab workspace
+
+    def __init__(self, model, B, H, W, dtype, device):
+        self.model, self.B, self.H, self.W, self.dtype, self.device = model, B, H, W, dtype, device
+        self.N = model.no_levels
+        self.generation = 0
+        self.buf = {}
+        self.fwd, self.bwd_head, self.bwd_body, self.pack = [], [], [], []
+        self._build()
+
+    # ---- helpers ----
+    def _act(self, name, h, w, c):
+        t = torch.empty(self.B, h, w, c, dtype=self.dtype, device=self.device)
+        self.buf[name] = t
+        return t
+
+    def _f32(self, name, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self.buf[name] = t
+        return t
+
+    def _conv_fwd(self, pc, srcs, IH, IW, out, act, addend=None, name=""):
+        B = self.B
+        OH, OW = out.shape[1], out.shape[2]
+        self.fwd.append(ops.conv_call(self.dtype, srcs, IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(pc.ksize), pc.taps,
+                                      pc.cout_pad, pc.stride, B, OH, OW, out, OH, OW, out.shape[3], out.shape[3],
+                                      bias=pc.bias, addend=addend, act=act, name="fwd " + name))
+
+    def _dgrad(self, pc, group, gout, gin, IH, IW, addend=None, actout=None, name=""):
+        """Append launches computing gin = dgrad_group(gout) [+ addend] [* elu'(actout)].
+        gin lives on the conv's (virtual) input grid IH x IW; gout on its output grid."""
+        B = self.B
+        OH, OW = gout.shape[1], gout.shape[2]
+        off = sum(pc.groups_pad[:group]) * pc.taps * pc.cout_pad
+        cg = pc.groups_pad[group]
+        kind = L.ACT_ELU if actout is not None else L.ACT_NONE
+        src = [ops.nhwc_src(gout)]
+        if pc.stride == 1:
+            self.bwd_body.append(ops.conv_call(
+                self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(pc.ksize), pc.taps, cg, 1, B, IH, IW,
+                gin, IH, IW, cg, gin.shape[3], addend=addend, actout=actout, actout_kind=kind,
+                weight_offset_elems=off, name="dgrad " + name))
+        else:
+            for py in range(2):
+                for px in range(2):
+                    th, tw = (IH - py + 1) // 2, (IW - px + 1) // 2
+                    if th <= 0 or tw <= 0:
+                        continue
+                    self.bwd_body.append(ops.conv_call(
+                        self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th,
+                        tw, gin, IH, IW, cg, gin.shape[3], out_step=(2, 2, py, px), addend=addend, actout=actout,
+                        actout_kind=kind, weight_offset_elems=off, name=f"dgrad{py}{px} " + name))
+
+    def _wgrad(self, pc, srcs, IH, IW, gout, name=""):
+        OH, OW = gout.shape[1], gout.shape[2]
+        gw = self.model._grad_view(pc.weight)
+        gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
+        call = ops.wgrad_calls(self.dtype, srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)],
+                               pc.stride, self.B, OH, OW, pc, gw, gb, self.buf["ws"], name="wgrad " + name)
+        self.bwd_body.append(lambda c=call: c(self._accumulate))
+
+    # ---- plan construction ----
+    def _build(self):
+        m, B, H, W, N, dt, dev = self.model, self.B, self.H, self.W, self.N, self.dtype, self.device
+        lib = L.lib()
+        code = L.dtype_code(dt)
+        pcs = m._packed
+        for pc in pcs.values():
+            pc.alloc(dt, dev)
+            self.pack.append(pc.pack_call())
+        self._f32("ws", self.WS_BYTES // 4)
+
+        # boundary tensors (planar f32)
+        left = self._f32("left", B, 3, H, W)
+        mn, mx = self._f32("min_disp", B), self._f32("max_disp", B)
+        flow = torch.zeros(B, pad_c(1), dtype=dt, device=dev)
+        self.buf["flow"] = flow
+        x0 = self._act("x0", H, W, pad_c(3))
+        self.fwd.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(left), L.ptr(x0), B, 3, H, W, pad_c(3), code))
+
+        # ---- encoder ----
+        sizes = [(H, W)]
+        for _ in range(6):
+            sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
+        a, h_, c = {}, {}, {}
+        for i, (cname, rname, ch) in enumerate(_ENC):
+            hh, ww = sizes[i]
+            a[i], h_[i], c[i] = self._act(f"a{i}", hh, ww, ch), self._act(f"h{i}", hh, ww, ch), self._act(f"c{i}", hh, ww, ch)
+            if i == 0:
+                srcs, ih, iw = [ops.nhwc_src(x0)], H, W
+            elif i == 1:
+                ih, iw = sizes[0]
+                srcs = [ops.nhwc_src(c[0]), ops.bcast_src(flow, ih, iw)]
+            else:
+                ih, iw = sizes[i - 1]
+                srcs = [ops.nhwc_src(c[i - 1])]
+            self._enc_srcs = getattr(self, "_enc_srcs", {})
+            self._enc_srcs[i] = (srcs, ih, iw)
+            self._conv_fwd(pcs[cname], srcs, ih, iw, a[i], L.ACT_ELU, name=cname)
+            self._conv_fwd(pcs[rname + ".conv1"], [ops.nhwc_src(a[i])], hh, ww, h_[i], L.ACT_ELU, name=rname + ".conv1")
+            self._conv_fwd(pcs[rname + ".conv2"], [ops.nhwc_src(h_[i])], hh, ww, c[i], L.ACT_ELU, addend=a[i],
+                           name=rname + ".conv2")
+        # ---- decoder ----
+        d, ic = {}, {7: c[6]}
+        for lvl in range(6, 0, -1):
+            dname, dch, iname, ich = _DEC[lvl]
+            hh, ww = sizes[lvl - 1]
+            below = ic[lvl + 1]  # tensor being upsampled (c6, then iconv outputs)
+            d[lvl] = self._act(f"d{lvl}", hh, ww, dch)
+            self._conv_fwd(pcs[dname], [ops.nhwc_src(below)], hh, ww, d[lvl], L.ACT_ELU, name=dname)
+            skip = c[lvl - 1]
+            if lvl > 1:
+                ic[lvl] = self._act(f"i{lvl}", hh, ww, ich)
+                self._conv_fwd(pcs[iname], [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, ic[lvl], L.ACT_ELU, name=iname)
+            else:
+                dlog = self._act("dlog", hh, ww, pad_c(N))
+                self._conv_fwd(pcs[iname], [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, dlog, L.ACT_NONE, name=iname)
+        # ---- 1x1 conv0 -> planar f32 logits, MED head ----
+        pc0 = pcs["conv0_1x1"]
+        dlog0 = self._f32("dlog0", B, N, H, W)
+        self.fwd.append(ops.conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
+                                      1, B, H, W, dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pc0.bias,
+                                      name="fwd conv0(1x1)"))
+        disp, pan, stats = self._f32("disp", B, 1, H, W), self._f32("p_im0", B, 3, H, W), self._f32("stats", B, 4, H, W)
+        maskL, maskR = self._f32("maskL", B, 1, H, W), self._f32("maskR", B, 1, H, W)
+        self.head_disp_only = ops.simple_call("falnet_med_head_fwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx),
+                                              L.ptr(disp), L.ptr(None), L.ptr(stats), B, N, H, W)
+        self.head_full = ops.simple_call("falnet_med_head_fwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx),
+                                         L.ptr(disp), L.ptr(pan), L.ptr(stats), B, N, H, W)
+        self.head_masks = ops.simple_call("falnet_med_masks_fwd", L.ptr(dlog0), L.ptr(mn), L.ptr(mx), L.ptr(stats),
+                                          L.ptr(maskL), L.ptr(maskR), B, N, H, W)
+
+        # =========================== backward plan ===========================
+        g_disp, g_pan = self._f32("g_disp", B, 1, H, W), self._f32("g_pan", B, 3, H, W)
+        g_dlog0 = self._f32("g_dlog0", B, N, H, W)
+
+        def head_bwd(has_disp, has_pan):
+            return ops.simple_call("falnet_med_head_bwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
+                                   L.ptr(pan), L.ptr(stats), L.ptr(g_disp if has_disp else None),
+                                   L.ptr(g_pan if has_pan else None), L.ptr(g_dlog0), B, N, H, W)
+        self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
+        G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, NHWC
+        self.bwd_body.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(g_dlog0), L.ptr(G0), B, N, H, W, pad_c(N), code))
+        self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
+        g_dlog = self._act("g_dlog", H, W, pad_c(N))
+        self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
+
+        gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], _ENC[i][2]) for i in range(7)}
+        # decoder, top (level 1) to bottom (level 6)
+        g_ipre = {1: g_dlog}  # gradient wrt the pre-activation of iconv{lvl} (iconv1 has no activation)
+        for lvl in range(1, 7):
+            dname, dch, iname, ich = _DEC[lvl]
+            hh, ww = sizes[lvl - 1]
+            below = ic[lvl + 1]
+            bh, bw = below.shape[1], below.shape[2]
+            pci, pcd = pcs[iname], pcs[dname]
+            skip = c[lvl - 1]
+            gi = g_ipre[lvl]
+            self._wgrad(pci, [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, gi, name=iname)
+            g_dpre = self._act(f"g_d{lvl}", hh, ww, dch)
+            self._dgrad(pci, 0, gi, g_dpre, hh, ww, actout=d[lvl], name=iname + "[deconv]")
+            self._dgrad(pci, 1, gi, gc[lvl - 1], hh, ww, name=iname + "[skip]")  # first writer of g_c{lvl-1}
+            self._wgrad(pcd, [ops.nhwc_src(below)], hh, ww, g_dpre, name=dname)
+            below_ch = below.shape[3]
+            if (bh, bw) == (hh, ww):  # degenerate: no resize
+                tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
+                self._dgrad(pcd, 0, g_dpre, tgt, hh, ww, actout=below, name=dname)
+            else:
+                g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
+                self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
+                tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
+                self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
+                                                     ww, bh, bw, below_ch, code))
+            if lvl < 6:
+                g_ipre[lvl + 1] = tgt
+        # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)
+        # encoder, bottom (level 6) to top (level 0)
+        for i in range(6, -1, -1):
+            cname, rname, ch = _ENC[i]
+            hh, ww = sizes[i]
+            gz = gc[i]
+            pr1, pr2, pcc = pcs[rname + ".conv1"], pcs[rname + ".conv2"], pcs[cname]
+            self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2")
+            g_h = self._act(f"g_h{i}", hh, ww, ch)
+            self._dgrad(pr2, 0, gz, g_h, hh, ww, actout=h_[i], name=rname + ".conv2")
+            self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1")
+            g_a = self._act(f"g_a{i}", hh, ww, ch)
+            self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
+            srcs, ih, iw = self._enc_srcs[i]
+            self._wgrad(pcc, srcs, ih, iw, g_a, name=cname)
+            if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
+                self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
+
+    # ---- execution ----
+    def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
+        b = self.buf
+        self.generation += 1
+        b["left"].copy_(left)
+        b["min_disp"].copy_(min_disp.reshape(-1))
+        b["max_disp"].copy_(max_disp.reshape(-1))
+        b["flow"][:, 0] = (b["max_disp"] / 100.0).to(self.dtype)  # FAL_netB.py:208-209
+        if repack:
+            for call in self.pack:
+                call()
+        for call in self.fwd:
+            call()
+        if ret_pan or ret_subocc:
+            self.head_full()
+        else:
+            self.head_disp_only()
+        if ret_subocc:
+            self.head_masks()
+        return self.generation
+
+    def run_backward(self, g_disp, g_pan):
+        b = self.buf
+        if g_disp is not None:
+            b["g_disp"].copy_(g_disp)
+        if g_pan is not None:
+            b["g_pan"].copy_(g_pan)
+        self._accumulate = self.model._begin_grad_accumulation()
+        self.head_bwd[(g_disp is not None, g_pan is not None)]()
+        for call in self.bwd_body:
+            call()
+        self.model._end_grad_accumulation()
+
+
+class _FalnetFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward = plan replay, backward = adjoint plan replay.
+    Parameter gradients are deposited directly into the model's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, model, plan, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, anchor):
+        gen = plan.run_forward(left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan)
+        ctx.plan, ctx.gen = plan, gen
+        b = plan.buf
+        outs = [b["p_im0"].clone() if ret_pan else None, b["disp"].clone() if ret_disp else None]
+        if ret_subocc:
+            outs += [b["maskL"].clone(), b["maskR"].clone()]
+        else:
+            outs += [None, None]
+        nd = [o for i, o in enumerate(outs) if o is not None and i >= 2]
+        ctx.mark_non_differentiable(*nd)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_pan, g_disp, g_ml, g_mr):
+        plan = ctx.plan
+        if plan.generation != ctx.gen:
+            raise RuntimeError("FAL_netB: the plan's activations were overwritten by a later forward of the same "
+                               "module and shape before backward ran")
+        if g_pan is not None or g_disp is not None:
+            plan.run_backward(None if g_disp is None else g_disp.contiguous(), None if g_pan is None else g_pan.contiguous())
+        return (None,) * 9
+
+
+class FAL_net(nn.Module):
+    def __init__(self, batchNorm, no_levels, compute_dtype=None):
+        super().__init__()
+        self.no_levels = no_levels
+        self.no_fac = 1
+        self.backbone = BackBone(batchNorm, no_in=3, no_flow=1, no_out=self.no_levels)
+        self.softmax = nn.Softmax(dim=1)
+        self.elu = nn.ELU(inplace=True)
+        self.sigmoid = nn.Sigmoid()
+        self.conv0 = nn.Conv2d(self.no_levels, self.no_fac * self.no_levels, 1, 1, 0, bias=True)  # FAL_netB.py:190
+        nn.init.kaiming_normal_(self.conv0.weight.data)
+        self.conv0.bias.data.zero_()
+        self.compute_dtype = compute_dtype or torch.float32
+        self._plans = {}
+        self._flat = self._flat_grad = None
+        self._anchor = None
+
+    def weight_parameters(self):
+        return [param for name, param in self.named_parameters() if "weight" in name]
+
+    def bias_parameters(self):
+        return [param for name, param in self.named_parameters() if "bias" in name]
+
+    # ---- flat parameter / gradient storage ----
+    def _trainable_named(self):
+        """Parameters that receive gradients (amask_conv never does: FAL_netB.py:128)."""
+        return [(n, p) for n, p in self.named_parameters() if "amask_conv" not in n]
+
+    def _ensure_flat(self, device):
+        named = self._trainable_named()
+        ok = (self._flat is not None and self._flat.device == device and
+              all(p.data_ptr() == self._flat.data_ptr() + off * 4 for (n, p), off in zip(named, self._offsets)))
+        if ok:
+            return
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in named]  # 16-B aligned slices
+        self._offsets = [sum(sizes[:i]) for i in range(len(sizes))]
+        total = sum(sizes)
+        flat = torch.zeros(total, dtype=torch.float32, device=device)
+        for (n, p), off in zip(named, self._offsets):
+            flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + p.numel()].view(p.shape)
+        for n, p in self.named_parameters():
+            if "amask_conv" in n and p.device != device:
+                p.data = p.data.to(device)
+        self._flat = flat
+        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self._gviews = {id(p): self._flat_grad[off:off + p.numel()].view(p.shape) for (n, p), off in zip(named, self._offsets)}
+        self._plans = {}
+        self._build_packed()
+
+    def flat_parameters(self):
+        return self._flat
+
+    def flat_gradients(self):
+        return self._flat_grad
+
+    def _grad_view(self, p):
+        return self._gviews[id(p)]
+
+    def _begin_grad_accumulation(self):
+        """Decide whether this backward accumulates into existing grads (p.grad already aliases the flat
+        buffer and was not reset) or starts fresh.  Mixed states are normalised to 'fresh + add'."""
+        named = self._trainable_named()
+        aliased = [p.grad is not None and p.grad.data_ptr() == self._gviews[id(p)].data_ptr() for _, p in named]
+        self._foreign = None
+        if all(aliased):
+            return 1
+        if any(p.grad is not None for _, p in named) and not all(aliased):
+            self._foreign = {id(p): p.grad for _, p in named if p.grad is not None}
+        return 0
+
+    def _end_grad_accumulation(self):
+        for _, p in self._trainable_named():
+            v = self._gviews[id(p)]
+            if self._foreign and id(p) in self._foreign and self._foreign[id(p)].data_ptr() != v.data_ptr():
+                v.add_(self._foreign[id(p)])
+            p.grad = v
+
+    def _build_packed(self):
+        bb = self.backbone
+        P = {}
+
+        def add(key, conv, groups, stride=1):
+            P[key] = PackedConv(key, conv.weight, conv.bias, groups, stride)
+        add("conv0", bb.conv0[0], [3])
+        add("conv1", bb.conv1[0], [32, 1], 2)
+        for i, cin in zip(range(2, 7), (64, 128, 256, 256, 256)):
+            add(f"conv{i}", getattr(bb, f"conv{i}")[0], [cin], 2)
+        for i, ch in enumerate((32, 64, 128, 256, 256, 256, 512)):
+            rb = getattr(bb, f"conv{i}_1")
+            add(f"conv{i}_1.conv1", rb.conv1, [ch])
+            add(f"conv{i}_1.conv2", rb.conv2, [ch])
+        for lvl, (dcin, g0, g1) in {6: (512, 256, 256), 5: (256, 128, 256), 4: (256, 128, 256), 3: (256, 128, 128),
+                                    2: (128, 64, 64)}.items():
+            add(f"deconv{lvl}", getattr(bb, f"deconv{lvl}").conv1, [dcin])
+            add(f"iconv{lvl}", getattr(bb, f"iconv{lvl}")[0], [g0, g1])
+        add("deconv1", bb.deconv1.conv1, [64])
+        add("iconv1", bb.iconv1, [64, 32])
+        add("conv0_1x1", self.conv0, [self.no_levels])
+        self._packed = P
+
+    def _plan(self, B, H, W, device):
+        self._ensure_flat(device)
+        key = (B, H, W, self.compute_dtype)
+        if key not in self._plans:
+            self._plans[key] = FalnetPlan(self, B, H, W, self.compute_dtype, device)
+        return self._plans[key]
+
+    def forward(self, input_left, min_disp, max_disp, ret_disp=True, ret_subocc=False, ret_pan=False):
+        """FAL_net.forward (FAL_netB.py:200-297).  Returns bare `disp` when only ret_disp, else the list
+        [p_im0][disp][maskL, maskR] in the reference's order."""
+        if not input_left.is_cuda:
+            raise RuntimeError("fal_net_amd.FAL_netB runs on an MI355X only (no CPU fallback); input is on " + str(input_left.device))
+        B, C, H, W = input_left.shape
+        plan = self._plan(B, H, W, input_left.device)
+        left = input_left.detach().to(torch.float32).contiguous()
+        if self._anchor is None or self._anchor.device != input_left.device:
+            self._anchor = torch.zeros(1, device=input_left.device, requires_grad=True)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._trainable_named())
+        anchor = self._anchor if need_grad else self._anchor.detach()
+        pan, disp, maskL, maskR = _FalnetFunction.apply(self, plan, left, min_disp.detach().float(), max_disp.detach().float(),
+                                                        ret_disp, ret_subocc, ret_pan, anchor)
+        if ret_disp and not ret_subocc and not ret_pan:
+            return disp
+        output = []
+        if ret_pan:
+            output.append(pan)
+        if ret_disp:
+            output.append(disp)
+        if ret_subocc:
+            output.append(maskL)
+            output.append(maskR)
+        return output

@@ -1,0 +1,199 @@
+"""Host-side launch descriptors for the libfalnet_hip.so kernels.
+
+Everything here is plumbing: it fills the C structs of include/falnet_hip.h from torch tensors
+(device memory + current stream come from PyTorch) and returns zero-argument callables, so a
+network is turned once into a static *plan* (a list of launches over pre-allocated buffers) and a
+step is just that list replayed -- no per-step allocation, no Python tensor math on the hot path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+CPAD = L.CPAD
+
+
+def pad_c(c):
+    return (c + CPAD - 1) // CPAD * CPAD
+
+
+def nhwc_src(t, C_used=None):
+    """falnet_src_t of a contiguous NHWC tensor (B,H,W,C)."""
+    B, H, W, Ct = t.shape
+    assert t.is_contiguous()
+    s = L.Src()
+    s.ptr, s.C, s.H, s.W = t.data_ptr(), (Ct if C_used is None else C_used), H, W
+    s.sb, s.sy, s.sx = H * W * Ct, W * Ct, Ct
+    return s
+
+
+def bcast_src(t, H, W):
+    """Per-sample constant (B,C) presented as an HxW image (pixel strides 0): the `flow` plane."""
+    B, Ct = t.shape
+    s = L.Src()
+    s.ptr, s.C, s.H, s.W = t.data_ptr(), Ct, H, W
+    s.sb, s.sy, s.sx = Ct, 0, 0
+    return s
+
+
+class PackedConv:
+    """One convolution's parameters plus its packed MFMA operands.
+
+    groups_real / groups_pad: input-channel groups (concat sources) and their padded sizes.
+    wf [cout_pad][taps][cin_pad]  forward operand; wd [cin_pad][taps][cout_pad]  dgrad operand.
+    """
+
+    def __init__(self, name, weight, bias, groups_real, stride=1):
+        self.name, self.weight, self.bias, self.stride = name, weight, bias, stride
+        self.cout, self.cin, kh, kw = weight.shape
+        assert sum(groups_real) == self.cin and len(groups_real) <= 2
+        self.taps = kh * kw
+        self.ksize = kh
+        self.groups_real = list(groups_real)
+        self.groups_pad = [pad_c(c) for c in groups_real]
+        self.cin_pad = sum(self.groups_pad)
+        self.cout_pad = pad_c(self.cout)
+        self.wf = self.wd = None
+        self._packed_version = None
+        self._dtype = None
+
+    def alloc(self, dtype, device):
+        if self.wf is None or self._dtype != dtype or self.wf.device != device:
+            self.wf = torch.zeros(self.cout_pad, self.taps, self.cin_pad, dtype=dtype, device=device)
+            self.wd = torch.zeros(self.cin_pad, self.taps, self.cout_pad, dtype=dtype, device=device)
+            self._dtype = dtype
+            self._packed_version = None
+
+    def pack_call(self, need_dgrad=True):
+        """Callable that (re)packs the f32 OIHW master weight into wf / wd."""
+        lib = L.lib()
+        c0_real = self.groups_real[0]
+        c0_pad = self.groups_pad[0] if len(self.groups_real) == 2 else self.cin_pad
+        if len(self.groups_real) == 1:
+            c0_real = self.cin
+        args = (L.ptr(self.weight), self.cout, self.cin, self.taps, c0_real, c0_pad, self.cin_pad, self.cout_pad,
+                L.ptr(self.wf), L.ptr(self.wd if need_dgrad else None), L.dtype_code(self._dtype))
+
+        def call():
+            L.check(lib.falnet_pack_weights(*args, L.stream_ptr()), "pack_weights " + self.name)
+        return call
+
+    def group_channels(self):
+        c0_real = self.groups_real[0] if len(self.groups_real) == 2 else self.cin
+        c0_pad = self.groups_pad[0] if len(self.groups_real) == 2 else self.cin_pad
+        return c0_real, c0_pad
+
+
+def fwd_taps(ksize):
+    if ksize == 1:
+        return [(0, 0, 0)]
+    return [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+
+
+def dgrad_taps_s1(ksize):
+    if ksize == 1:
+        return [(0, 0, 0)]
+    return [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+
+
+def dgrad_taps_s2(py, px):
+    """Taps feeding input pixels of parity (py, px) for a 3x3 stride-2 pad-1 conv: iy = 2*oy + kh - 1."""
+    taps = []
+    for kh in range(3):
+        if (py + 1 - kh) % 2:
+            continue
+        for kw in range(3):
+            if (px + 1 - kw) % 2:
+                continue
+            taps.append(((py + 1 - kh) // 2, (px + 1 - kw) // 2, kh * 3 + kw))
+    return taps
+
+
+def _fill_taps(d, taps):
+    d.ntaps = len(taps)
+    for i, (dy, dx, w) in enumerate(taps):
+        d.tap_dy[i], d.tap_dx[i] = dy, dx
+        if hasattr(d, "tap_w"):
+            d.tap_w[i] = w
+
+
+def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
+              Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
+              act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv"):
+    """Build one falnet_conv2d launch; returns a zero-argument callable."""
+    lib = L.lib()
+    d = L.Conv()
+    d.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.IH, d.IW = IH, IW
+    d.weight = weight.data_ptr() + weight_offset_elems * weight.element_size()
+    d.cin_total, d.w_taps, d.w_rows = cin_total, w_taps, w_rows
+    _fill_taps(d, taps)
+    d.isy = d.isx = stride_in
+    d.B, d.TH, d.TW = B, TH, TW
+    d.osy, d.osx, d.ooy, d.oox = out_step
+    d.out, d.OH, d.OW, d.Cout, d.out_cstride, d.out_layout = out.data_ptr(), OH, OW, Cout, out_cstride, out_layout
+    d.bias = 0 if bias is None else bias.data_ptr()
+    d.addend = 0 if addend is None else addend.data_ptr()
+    d.act = act
+    d.actout = 0 if actout is None else actout.data_ptr()
+    d.actout_kind = actout_kind
+    d.dtype = L.dtype_code(dtype)
+    ref = C.byref(d)
+    keep = (d, srcs, weight, out, bias, addend, actout)
+
+    def call(_keep=keep):
+        L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
+    return call
+
+
+def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, ws, target_wgs=1536,
+                name="wgrad"):
+    """Weight (+bias) gradient of one conv: split-K partial slabs in `ws`, then a reduce into the
+    OIHW f32 views `grad_w` / `grad_b`.  Returns a callable taking (accumulate)."""
+    lib = L.lib()
+    d = L.Wgrad()
+    d.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.IH, d.IW = IH, IW
+    gC = gout.shape[-1]
+    d.gout, d.gC = gout.data_ptr(), gC
+    _fill_taps(d, taps)
+    d.isy = d.isx = stride_in
+    d.B, d.TH, d.TW = B, TH, TW
+    d.cin_total = pc.cin_pad
+    M = B * TH * TW
+    tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
+    nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
+    slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
+    nsplit = max(1, min(nsplit, ws.numel() * 4 // slab))
+    d.nsplit = nsplit
+    d.partial = ws.data_ptr()
+    d.dtype = L.dtype_code(dtype)
+    assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
+    ref = C.byref(d)
+    c0_real, c0_pad = pc.group_channels()
+    red_args = (L.ptr(ws), nsplit, len(taps), pad_c(gC), pc.cin_pad, L.ptr(grad_w), pc.cout, pc.cin, c0_real, c0_pad)
+    npix = M
+    keep = (d, srcs, gout, grad_w, grad_b, ws)
+
+    def call(accumulate=0, _keep=keep):
+        st = L.stream_ptr()
+        L.check(lib.falnet_wgrad(ref, st), name)
+        L.check(lib.falnet_wgrad_reduce(*red_args, int(accumulate), st), name + " reduce")
+        if grad_b is not None:
+            L.check(lib.falnet_bias_grad(L.ptr(gout), npix, gC, pc.cout, L.ptr(grad_b), int(accumulate),
+                                         L.dtype_code(dtype), st), name + " bias")
+    return call
+
+
+def simple_call(fn_name, *args, name=None):
+    lib = L.lib()
+    fn = getattr(lib, fn_name)
+
+    def call():
+        L.check(fn(*args, L.stream_ptr()), name or fn_name)
+    return call

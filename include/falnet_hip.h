@@ -1,0 +1,209 @@
+/*
+ * falnet_hip.h -- C-ABI of libfalnet_hip.so: the MI355X (gfx950) kernels behind the
+ * FAL_netB hot path.
+ *
+ * The reference (JuanLuisGonzalez/FAL_net) has no native code: its "FFI" for this path is
+ * torch.nn.functional -> aten/cuDNN.  Each entry point below replaces the aten call sites
+ * named in its comment (paths relative to the reference root).  The library is loaded with
+ * ctypes by fal_net_amd/_lib.py; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain `extern "C"`, raw device pointers, explicit sizes; no torch types.
+ *   - every launch function takes the HIP stream (as void*) and enqueues only on it; it never
+ *     allocates, never synchronises and never touches the default stream.  Workspaces are
+ *     caller-owned (`*_workspace_bytes` queries).
+ *   - return value: 0 ok, <0 bad argument (see falnet_last_error()), >0 hipError_t.
+ *   - re-entrant: forward runs on the Python main thread, backward on autograd's thread.
+ *   - dtype enum: activations/weights are either FALNET_F32 (exact-f32 MFMA, parity path) or
+ *     FALNET_BF16 (bf16 MFMA, f32 accumulate; throughput path).  Reductions, losses, the MED
+ *     head and Adam are f32 in both.
+ *   - activation layout inside the network: NHWC ("pixel-major"), channels padded to a
+ *     multiple of falnet_channel_pad(dtype) with zeros.  The boundary tensors of the
+ *     reference API (images, disparity, synthesised view, MED logits) are planar NCHW f32.
+ */
+#ifndef FALNET_HIP_H
+#define FALNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FALNET_F32 = 0, FALNET_BF16 = 1 };
+enum { FALNET_ACT_NONE = 0, FALNET_ACT_ELU = 1, FALNET_ACT_RELU = 2 };
+enum { FALNET_OUT_NHWC = 0, FALNET_OUT_PLANAR_F32 = 1 };
+
+int falnet_version(void);
+const char* falnet_last_error(void);
+/* channel padding granule (elements) of NHWC tensors and packed weights: 32 for both dtypes */
+int falnet_channel_pad(int dtype);
+
+/* One input of a convolution: NHWC tensor (or a per-sample constant when sy = sx = 0). */
+typedef struct {
+    const void* ptr;
+    int32_t C;          /* channels consumed (multiple of the channel pad) */
+    int32_t H, W;       /* physical spatial size; != (IH, IW) means nearest-upsampled on the fly */
+    int64_t sb, sy, sx; /* element strides: sample, row, pixel */
+} falnet_src_t;
+
+/*
+ * Implicit-GEMM convolution on MFMA: out[p, co] = epilogue(sum_{tap, src, ci} in_src[nbr(p, tap), ci] * w[co, tap, ci]).
+ * One kernel serves
+ *   - forward 3x3 / 1x1, stride 1 / 2            (models/FAL_netB.py:38,45,55,73,75,127,190; loss_functions.py:21-29)
+ *   - the fused nearest upsample of `deconv`     (FAL_netB.py:58)   via src.H/W != IH/IW
+ *   - the fused channel concat                   (FAL_netB.py:145-173) via two sources
+ *   - data gradients (the autograd of the above): a dgrad is the same gather with another tap table;
+ *     stride-2 dgrad is 4 launches, one per output parity class.
+ * Tile space (TH x TW positions per sample): position (ty, tx) reads virtual input pixel
+ * (ty*isy + dy[t], tx*isx + dx[t]) for tap t (zero outside [0,IH)x[0,IW)) and writes output pixel
+ * (ty*osy + ooy, tx*osx + oox).
+ * Epilogue: v = acc + bias[co]; v += addend[p, co]; v = act(v); v *= act'(actout[p, co]); store.
+ */
+typedef struct {
+    falnet_src_t src[2];
+    int32_t nsrc;
+    int32_t IH, IW;            /* virtual input size */
+    const void* weight;        /* packed [CoutPad][ntaps_w][CinTot] in `dtype` (falnet_pack_weights) */
+    int32_t cin_total;         /* CinTot: row length per tap of the packed weight */
+    int32_t ntaps;             /* taps walked by this launch (<= 9) */
+    int32_t tap_dy[9], tap_dx[9], tap_w[9]; /* offsets and packed-weight tap index */
+    int32_t w_taps;            /* ntaps_w of the packed weight */
+    int32_t w_rows;            /* CoutPad: rows of the packed weight (multiple of 32) */
+    int32_t isy, isx;
+    int32_t B, TH, TW;
+    int32_t osy, osx, ooy, oox;
+    void* out;                 /* NHWC `dtype` [B][OH][OW][out_cstride] or planar f32 [B][Cout][OH][OW] */
+    int32_t OH, OW;
+    int32_t Cout;              /* channels written: NHWC -> padded count, planar -> real count */
+    int32_t out_cstride;
+    int32_t out_layout;
+    const float* bias;         /* [CoutPad] or NULL */
+    const void* addend;        /* NHWC like out, or NULL (may alias out: accumulate) */
+    int32_t act;               /* FALNET_ACT_* applied to v */
+    const void* actout;        /* NHWC like out: multiply by d act / d pre computed from the activation output */
+    int32_t actout_kind;       /* FALNET_ACT_ELU / RELU / NONE */
+    int32_t dtype;
+} falnet_conv_t;
+int falnet_conv2d(const falnet_conv_t* p, void* stream);
+
+/*
+ * Weight gradient (autograd of the conv2d call sites above):
+ *   dW[co, tap, ci] = sum_p gout[p, co] * in[nbr(p, tap), ci]
+ * split over pixel ranges into `nsplit` f32 partial slabs in the caller's workspace
+ * [nsplit][ntaps][CoutPad][CinTot], then falnet_wgrad_reduce sums the slabs into the
+ * OIHW f32 gradient (+= when accumulate).  `gout` is NHWC [B][TH][TW][gC] (tile space = the
+ * conv's output grid); sources/taps as in falnet_conv_t.
+ */
+typedef struct {
+    falnet_src_t src[2];
+    int32_t nsrc;
+    int32_t IH, IW;
+    const void* gout;
+    int32_t gC;                /* padded channel count of gout (CoutPad) */
+    int32_t ntaps;
+    int32_t tap_dy[9], tap_dx[9];
+    int32_t isy, isx;
+    int32_t B, TH, TW;
+    int32_t cin_total;
+    int32_t nsplit;
+    float* partial;            /* workspace */
+    int32_t dtype;
+} falnet_wgrad_t;
+int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p);
+int falnet_wgrad(const falnet_wgrad_t* p, void* stream);
+/* partial [nsplit][ntaps][CoutPad][CinTot] -> grad OIHW f32 [Cout][Cin][kh][kw] (taps in kh*kw+kw order) */
+/* channel groups as in falnet_pack_weights: packed column cp holds real channel cp (cp < c0_real) or
+ * c0_real + (cp - c0_pad) */
+int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pad, int cin_total,
+                        float* grad, int cout, int cin, int c0_real, int c0_pad, int accumulate, void* stream);
+/* db[co] (+)= sum_p g[p, co]; g NHWC [npix][gC], gC a multiple of 32 dividing 256 or a multiple of 256 */
+int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db,
+                     int accumulate, int dtype, void* stream);
+
+/*
+ * OIHW f32 master weights -> packed compute-dtype operands.
+ *   fwd  : wf[co][tap][ci]  (CoutPad x taps x CinPad), channel groups padded per source:
+ *          real input channels [0,c0) go to [0,c0), [c0,Cin) to [c0pad, ...)  (concat sources)
+ *   dgrad: wd[ci][tap][co]  (CinPad' x taps x CoutPad) -- the same numbers, transposed
+ */
+int falnet_pack_weights(const float* w_oihw, int cout, int cin, int taps,
+                        int c0_real, int c0_pad, int cin_pad_total, int cout_pad,
+                        void* wf, void* wd, int dtype, void* stream);
+
+/* planar NCHW f32 [B][C][H][W] -> NHWC `dtype` [B][H][W][Cpad] (zero padded).  Boundary of the
+ * reference API: input image (FAL_netB.py:200), VGG input (loss_functions.py:36), MED-head grads. */
+int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cpad,
+                        int dtype, void* stream);
+/* NHWC `dtype` [B][H][W][Cpad] -> planar NCHW f32 [B][C][H][W] (first C channels) */
+int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cpad,
+                        int dtype, void* stream);
+/* Adjoint of the fused nearest upsample (F.interpolate backward, FAL_netB.py:58):
+ * gsrc[b, sy, sx, c] = (sum over virtual pixels mapping to (sy,sx) of gup[b, vy, vx, c]) * elu'(actout) */
+int falnet_upsample_bwd(const void* gup, void* gsrc, const void* actout, int B, int IH, int IW,
+                        int H, int W, int C, int dtype, void* stream);
+/* 2x2/2 max pool on NHWC (torchvision VGG19 features[4,9,18]; loss_functions.py:21-29) and its adjoint */
+int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy, void* gx, int B, int H, int W, int C,
+                        int dtype, void* stream);
+/* maxpool2_bwd: x is the (ReLU) pool input; the gradient goes to the first maximum of each window
+ * (aten tie rule) and is zero where that maximum is 0 (fused relu'); H, W even. */
+/* gx = g * act'(y) elementwise on NHWC, act' from the activation OUTPUT y (ELU: y>0?1:y+1) */
+int falnet_act_bwd(const void* g, const void* y, void* gx, int64_t n, int kind, int dtype, void* stream);
+
+/*
+ * MED head (FAL_netB.py:216-282): per-pixel softmax over the N disparity planes, expectation ->
+ * disp; plane-sweep warp of the logits by d_n (W-1)/W pixels (2-tap, zero padded), second softmax,
+ * blend of the equally shifted left image -> p_im0.  All planar f32.
+ *   dlog0 [B][N][H][W], left [B][3][H][W], min_disp/max_disp [B]
+ *   disp [B][1][H][W] (or NULL), p_im0 [B][3][H][W] (or NULL)
+ *   stats [B][4][H][W]: (max0, sum0, maxW, sumW) of the two softmaxes, kept for backward (or NULL)
+ */
+int falnet_med_head_fwd(const float* dlog0, const float* left, const float* min_disp, const float* max_disp,
+                        float* disp, float* p_im0, float* stats, int B, int N, int H, int W, void* stream);
+/* grad_dlog0 [B][N][H][W] from grad_disp / grad_p_im0 (either may be NULL) */
+int falnet_med_head_bwd(const float* dlog0, const float* left, const float* min_disp, const float* max_disp,
+                        const float* disp, const float* p_im0, const float* stats,
+                        const float* grad_disp, const float* grad_p_im0, float* grad_dlog0,
+                        int B, int N, int H, int W, void* stream);
+/* occlusion masks (FAL_netB.py:264-273,291-292), no grad: maskR = min(1, sum_n shift_{+s_n}(softmax(dlog0)_n)),
+ * maskL = min(1, sum_n shift_{-s_n}(Dprob_n)).  Dprob is rebuilt from the logits and `stats`. */
+int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp, const float* stats,
+                         float* maskL, float* maskR, int B, int N, int H, int W, void* stream);
+
+/* ---- losses (loss_functions.py) ; all write/accumulate a scalar in `out` (f32, device) ---- */
+/* out[0] (+)= scale * sum(mask * |a - b|) ; mask NULL or [B][1][H][W] broadcast over C (loss_functions.py:53) */
+int falnet_l1_fwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW,
+                  float scale, float* out, int accumulate, void* stream);
+/* ga (+)= gscale[0] * scale * mask * sign(a - b) */
+int falnet_l1_bwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW,
+                  float scale, const float* gscale, float* ga, int accumulate, void* stream);
+/* perceptual term: out[0] (+)= scale * sum over real channels of (a-b)^2 on NHWC `dtype` (loss_functions.py:61-65) */
+int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, float* out,
+                   int accumulate, int dtype, void* stream);
+/* ga = gscale[0] * 2 * scale * (a - b) */
+int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, const float* gscale,
+                   void* ga, int dtype, void* stream);
+/* edge-aware smoothness on the column window [x0, x1) (loss_functions.py:70-101; crop at
+ * Train_Stage1_K.py:255): out[0] (+)= scale * sum(...). img [B][3][H][W], disp [B][1][H][W] planar f32 */
+int falnet_smooth_fwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1,
+                      float gamma, float scale, float* out, int accumulate, void* stream);
+int falnet_smooth_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1,
+                      float gamma, float scale, const float* gscale, float* gdisp, int accumulate, void* stream);
+/* mixing for masked perceptual input: out = m*a + (1-m)*b (loss_functions.py:55); and grad wrt a: ga = m*g */
+int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, int B, int C, int64_t HW, void* stream);
+
+/* Fused flat-buffer Adam (torch.optim.Adam semantics, Train_Stage1_K.py:180): p, g, m, v f32 [n];
+ * step_size = lr / (1 - b1^t), bias2 = sqrt(1 - b2^t) computed by the caller. */
+int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                     float eps, int step, float grad_scale, void* stream);
+
+/* horizontal flip of planar f32 [n_rows][W] (Train_Stage2_K.py:248-253 flip grid) */
+int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stream);
+/* per-sample max of planar f32 [B][n] -> out[B]  (F.max_pool2d(kernel=(H,W)), Train_Stage2_K.py:319) */
+int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,357 @@
+"""GPU parity tests, op level: every libfalnet_hip.so kernel against the CPU oracle / torch-CPU fp32
+on the same seeded inputs.  Calls go through the C-ABI (fal_net_amd.ops / _lib)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from fal_net_amd import _lib as L  # noqa: E402
+from fal_net_amd import ops  # noqa: E402
+from oracle import falnet_oracle as O  # noqa: E402
+
+DEV = "cuda"
+F32_TOL = 1e-4   # north_star gate for the exact-f32 path (relative, max-norm)
+BF16_TOL = 3e-2  # bf16 operands carry 8 significant bits; reported, not gated at 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def to_nhwc(x, dtype):
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, ops.pad_c(C), dtype=dtype, device=DEV)
+    xs = x.to(DEV).contiguous()
+    L.check(L.lib().falnet_nchw_to_nhwc(L.ptr(xs), L.ptr(out), B, C, H, W, ops.pad_c(C), L.dtype_code(dtype), L.stream_ptr()))
+    return out
+
+
+def to_nchw(t, C):
+    B, H, W, Cp = t.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=DEV)
+    L.check(L.lib().falnet_nhwc_to_nchw(L.ptr(t), L.ptr(out), B, C, H, W, Cp, L.dtype_code(t.dtype), L.stream_ptr()))
+    return out.cpu()
+
+
+def packed(w, b, groups, stride, dtype):
+    wp = torch.nn.Parameter(w.to(DEV))
+    bp = None if b is None else torch.nn.Parameter(b.to(DEV))
+    pc = ops.PackedConv("t", wp, bp, groups, stride)
+    pc.alloc(dtype, torch.device(DEV))
+    pc.pack_call()()
+    return pc
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip(dtype):
+    x = torch.randn(2, 5, 7, 70)
+    y = to_nchw(to_nhwc(x, dtype), 5)
+    assert rel(y, x) < (1e-7 if dtype == torch.float32 else 1e-2)
+    t = to_nhwc(x, dtype)
+    assert float(t[..., 5:].abs().max()) == 0.0  # padded channels are zero
+
+
+CONV_CASES = [
+    # B, Cin groups, Cout, H, W, stride, ksize, bias, act, residual
+    (2, [3], 32, 16, 24, 1, 3, True, L.ACT_ELU, False),
+    (1, [32], 32, 9, 13, 1, 3, False, L.ACT_ELU, True),
+    (2, [64], 128, 12, 20, 2, 3, True, L.ACT_ELU, False),
+    (1, [32], 64, 11, 15, 2, 3, True, L.ACT_ELU, False),      # odd sizes, stride 2
+    (2, [64, 32], 49, 8, 16, 1, 3, False, L.ACT_NONE, False),   # concat + Cout=49
+    (1, [128, 256], 256, 4, 8, 1, 3, True, L.ACT_ELU, False),   # bottleneck-like, M < tile
+    (2, [64], 64, 8, 8, 1, 3, True, L.ACT_RELU, False),         # VGG style
+    (1, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False),        # 1x1
+]
+
+
+def _conv_inputs(case, seed=0):
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    g = torch.Generator().manual_seed(seed)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in groups]
+    cin = sum(groups)
+    w = torch.randn(Cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    return xs, w, b
+
+
+def _ref_conv(case, xs, w, b, addend=None):
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=k // 2)
+    if addend is not None:
+        y = y + addend
+    if act == L.ACT_ELU:
+        y = F.elu(y)
+    elif act == L.ACT_RELU:
+        y = F.relu(y)
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case, dtype):
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    xs, w, b = _conv_inputs(case)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    addend = torch.randn(B, Cout, OH, OW) if res else None
+    ref = _ref_conv(case, xs, w, b, addend)
+    pc = packed(w, b, groups, stride, dtype)
+    srcs_t = [to_nhwc(x, dtype) for x in xs]
+    out = torch.full((B, OH, OW, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+    add_t = to_nhwc(addend, dtype) if res else None
+    bias_t = None
+    if b is not None:
+        bias_t = torch.zeros(pc.cout_pad, device=DEV)
+        bias_t[:Cout] = pc.bias.data
+    ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(k), pc.taps,
+                  pc.cout_pad, stride, B, OH, OW, out, OH, OW, pc.cout_pad, pc.cout_pad, bias=bias_t, addend=add_t,
+                  act=act)()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    if pc.cout_pad > Cout:
+        assert float(out[..., Cout:].float().abs().max()) == 0.0
+    got = to_nchw(out, Cout)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_planar_output(dtype):
+    case = (2, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False)
+    xs, w, b = _conv_inputs(case)
+    ref = _ref_conv(case, xs, w, b)
+    pc = packed(w, b, [49], 1, dtype)
+    src = to_nhwc(xs[0], dtype)
+    out = torch.full((2, 49, 6, 40), float("nan"), device=DEV)
+    ops.conv_call(dtype, [ops.nhwc_src(src)], 6, 40, pc.wf, pc.cin_pad, ops.fwd_taps(1), 1, pc.cout_pad, 1, 2, 6, 40, out,
+                  6, 40, 49, 0, out_layout=L.OUT_PLANAR_F32, bias=pc.bias)()
+    assert rel(out, ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fused_upsample(dtype):
+    """deconv: nearest resize to an arbitrary size then conv (FAL_netB.py:57-60), incl. non-x2 ratio."""
+    g = torch.Generator().manual_seed(3)
+    for (h, w, IH, IW) in ((4, 6, 8, 12), (6, 12, 11, 23)):
+        x = torch.randn(2, 64, h, w, generator=g)
+        wt = torch.randn(32, 64, 3, 3, generator=g) * 0.06
+        ref = F.elu(F.conv2d(F.interpolate(x, size=(IH, IW), mode="nearest"), wt, None, padding=1))
+        pc = packed(wt, None, [64], 1, dtype)
+        src = to_nhwc(x, dtype)
+        out = torch.empty(2, IH, IW, 32, dtype=dtype, device=DEV)
+        ops.conv_call(dtype, [ops.nhwc_src(src)], IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, 2, IH, IW,
+                      out, IH, IW, 32, 32, act=L.ACT_ELU)()
+        assert rel(to_nchw(out, 32), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES[:7])
+def test_conv_backward(case, dtype):
+    """dgrad (per concat group, stride 1 and the 4 stride-2 parity launches) and wgrad/bias-grad vs autograd."""
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    xs, w, b = _conv_inputs(case, seed=5)
+    xs = [x.requires_grad_(True) for x in xs]
+    w.requires_grad_(True)
+    if b is not None:
+        b.requires_grad_(True)
+    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=k // 2)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
+    y.backward(gy)
+    OH, OW = y.shape[2], y.shape[3]
+    pc = packed(w.detach(), None if b is None else b.detach(), groups, stride, dtype)
+    g_t = to_nhwc(gy, dtype)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    # dgrad per group
+    for gi, x in enumerate(xs):
+        cg = pc.groups_pad[gi]
+        gin = torch.full((B, H, W, cg), float("nan"), dtype=dtype, device=DEV)
+        off = sum(pc.groups_pad[:gi]) * pc.taps * pc.cout_pad
+        src = [ops.nhwc_src(g_t)]
+        if stride == 1:
+            ops.conv_call(dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(k), pc.taps, cg, 1, B, H, W, gin, H, W,
+                          cg, cg, weight_offset_elems=off)()
+        else:
+            for py in range(2):
+                for px in range(2):
+                    th, tw = (H - py + 1) // 2, (W - px + 1) // 2
+                    ops.conv_call(dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th,
+                                  tw, gin, H, W, cg, cg, out_step=(2, 2, py, px), weight_offset_elems=off)()
+        assert torch.isfinite(gin.float()).all()
+        assert rel(to_nchw(gin, groups[gi]), x.grad) < tol
+    # wgrad + bias grad
+    ws = torch.empty(8 << 20, device=DEV)
+    gw = torch.full(w.shape, float("nan"), device=DEV)
+    gb = torch.full((Cout,), float("nan"), device=DEV) if b is not None else None
+    srcs_t = [to_nhwc(x.detach(), dtype) for x in xs]
+    call = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, g_t,
+                           [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(k)], stride, B, OH, OW, pc, gw, gb, ws, target_wgs=64)
+    call(0)
+    assert rel(gw, w.grad) < tol
+    if b is not None:
+        assert rel(gb, b.grad) < tol
+    call(1)  # accumulate
+    assert rel(gw, 2 * w.grad) < tol
+
+
+def test_upsample_bwd_and_pool():
+    g = torch.Generator().manual_seed(9)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+        x = torch.randn(2, 32, 6, 12, generator=g, requires_grad=True)
+        y = F.elu(x)
+        up = F.interpolate(y, size=(11, 23), mode="nearest")
+        gu = torch.randn(up.shape, generator=g)
+        up.backward(gu)
+        gsrc = torch.empty(2, 6, 12, 32, dtype=dtype, device=DEV)
+        L.check(L.lib().falnet_upsample_bwd(L.ptr(to_nhwc(gu, dtype)), L.ptr(gsrc), L.ptr(to_nhwc(y.detach(), dtype)), 2, 11, 23,
+                                            6, 12, 32, L.dtype_code(dtype), L.stream_ptr()))
+        assert rel(to_nchw(gsrc, 32), x.grad) < tol * 5
+        # relu -> maxpool fwd/bwd
+        x = torch.randn(2, 64, 8, 12, generator=g, requires_grad=True)
+        r = F.relu(x)
+        p = F.max_pool2d(r, 2)
+        gp = torch.randn(p.shape, generator=g)
+        p.backward(gp)
+        rt = to_nhwc(r.detach(), dtype)
+        pt = torch.empty(2, 4, 6, 64, dtype=dtype, device=DEV)
+        L.check(L.lib().falnet_maxpool2_fwd(L.ptr(rt), L.ptr(pt), 2, 8, 12, 64, L.dtype_code(dtype), L.stream_ptr()))
+        assert rel(to_nchw(pt, 64), p) < tol
+        gx = torch.empty_like(rt)
+        L.check(L.lib().falnet_maxpool2_bwd(L.ptr(rt), L.ptr(pt), L.ptr(to_nhwc(gp, dtype)), L.ptr(gx), 2, 8, 12, 64,
+                                            L.dtype_code(dtype), L.stream_ptr()))
+        assert rel(to_nchw(gx, 64), x.grad) < tol
+
+
+HEAD_CASES = [(2, 7, 6, 40, 30.0), (2, 49, 4, 128, 300.0), (1, 49, 3, 512, 300.0), (1, 96, 2, 320, 300.0), (2, 33, 5, 77, 120.0)]
+
+
+@pytest.mark.parametrize("B,N,H,W,maxd", HEAD_CASES)
+def test_med_head(B, N, H, W, maxd):
+    g = torch.Generator().manual_seed(N * 1000 + W)
+    dlog0 = (torch.randn(B, N, H, W, generator=g) * 2.0).requires_grad_(True)
+    left = torch.rand(B, 3, H, W, generator=g) - 0.43
+    mx = torch.full((B, 1, 1), maxd) * (1 - 0.07 * torch.arange(B).view(B, 1, 1))
+    mn = mx * 2 / 300
+    out = O.med_head(dlog0, left, mn, mx, True, True, True)
+    gd = torch.randn(B, 1, H, W, generator=g)
+    gp = torch.randn(B, 3, H, W, generator=g)
+    ((out["disp"] * gd).sum() + (out["p_im0"] * gp).sum()).backward()
+
+    lib = L.lib()
+    d0, lf = dlog0.detach().to(DEV), left.to(DEV)
+    mnd, mxd = mn.reshape(-1).to(DEV), mx.reshape(-1).to(DEV)
+    disp, pan, st = (torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 3, H, W, device=DEV), torch.empty(B, 4, H, W, device=DEV))
+    L.check(lib.falnet_med_head_fwd(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st), B, N, H, W, L.stream_ptr()))
+    assert rel(disp, out["disp"]) < F32_TOL
+    assert rel(pan, out["p_im0"]) < F32_TOL
+    ml, mr = torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 1, H, W, device=DEV)
+    L.check(lib.falnet_med_masks_fwd(L.ptr(d0), L.ptr(mnd), L.ptr(mxd), L.ptr(st), L.ptr(ml), L.ptr(mr), B, N, H, W, L.stream_ptr()))
+    assert rel(ml, out["maskL"]) < F32_TOL
+    assert rel(mr, out["maskR"]) < F32_TOL
+    gl = torch.empty(B, N, H, W, device=DEV)
+    L.check(lib.falnet_med_head_bwd(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
+                                    L.ptr(gd.to(DEV)), L.ptr(gp.to(DEV)), L.ptr(gl), B, N, H, W, L.stream_ptr()))
+    assert rel(gl, dlog0.grad) < F32_TOL
+    # disparity-only backward
+    dlog0.grad = None
+    (O.med_head(dlog0, left, mn, mx)["disp"] * gd).sum().backward()
+    L.check(lib.falnet_med_head_bwd(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
+                                    L.ptr(gd.to(DEV)), L.ptr(None), L.ptr(gl), B, N, H, W, L.stream_ptr()))
+    assert rel(gl, dlog0.grad) < F32_TOL
+
+
+def test_med_head_linearity_full_size():
+    """Size-independent property at the benchmark shape: backward is linear in the upstream gradient and
+    p_im0 is a convex blend (|p| <= max|left|); disp within [min_disp, max_disp]."""
+    B, N, H, W = 2, 49, 256, 512
+    g = torch.Generator(device="cpu").manual_seed(1)
+    d0 = (torch.randn(B, N, H, W, generator=g) * 2).to(DEV)
+    lf = (torch.rand(B, 3, H, W, generator=g) - 0.43).to(DEV)
+    mx, mn = torch.full((B,), 300.0, device=DEV), torch.full((B,), 2.0, device=DEV)
+    lib = L.lib()
+    disp, pan, st = torch.empty(B, 1, H, W, device=DEV), torch.empty(B, 3, H, W, device=DEV), torch.empty(B, 4, H, W, device=DEV)
+    L.check(lib.falnet_med_head_fwd(L.ptr(d0), L.ptr(lf), L.ptr(mn), L.ptr(mx), L.ptr(disp), L.ptr(pan), L.ptr(st), B, N, H, W, L.stream_ptr()))
+    assert float(disp.min()) >= 2.0 - 1e-3 and float(disp.max()) <= 300.0 + 1e-3
+    assert float(pan.abs().max()) <= float(lf.abs().max()) + 1e-5
+    g1, g2 = torch.randn(B, 3, H, W, device=DEV), torch.randn(B, 3, H, W, device=DEV)
+    outs = []
+    for gp in (g1, g2, 2 * g1 - 3 * g2):
+        gl = torch.empty(B, N, H, W, device=DEV)
+        L.check(lib.falnet_med_head_bwd(L.ptr(d0), L.ptr(lf), L.ptr(mn), L.ptr(mx), L.ptr(disp), L.ptr(pan), L.ptr(st),
+                                        L.ptr(None), L.ptr(gp), L.ptr(gl), B, N, H, W, L.stream_ptr()))
+        outs.append(gl)
+    assert rel(outs[2], 2 * outs[0] - 3 * outs[1]) < 1e-4
+    # softmax gradients sum to zero over the planes at every pixel (up to the zero-padded border taps)
+    assert float(outs[0][:, :, :, : W // 4].sum(1).abs().max()) < 1e-3
+
+
+def test_losses():
+    g = torch.Generator().manual_seed(4)
+    lib = L.lib()
+    B, H, W = 2, 12, 40
+    a, b = torch.rand(B, 3, H, W, generator=g) - 0.4, torch.rand(B, 3, H, W, generator=g) - 0.4
+    m = torch.rand(B, 1, H, W, generator=g)
+    a.requires_grad_(True)
+    out = torch.zeros(1, device=DEV)
+    for mask in (None, m):
+        a.grad = None
+        ref = torch.mean((1 if mask is None else mask) * (a - b).abs())
+        ref.backward()
+        sc = 1.0 / (B * 3 * H * W)
+        L.check(lib.falnet_l1_fwd(L.ptr(a.detach().to(DEV)), L.ptr(b.to(DEV)), L.ptr(None if mask is None else mask.to(DEV)), B, 3,
+                                  H * W, sc, L.ptr(out), 0, L.stream_ptr()))
+        assert abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+        ga = torch.empty(B, 3, H, W, device=DEV)
+        L.check(lib.falnet_l1_bwd(L.ptr(a.detach().to(DEV)), L.ptr(b.to(DEV)), L.ptr(None if mask is None else mask.to(DEV)), B, 3,
+                                  H * W, sc, L.ptr(None), L.ptr(ga), 0, L.stream_ptr()))
+        assert rel(ga, a.grad) < 1e-5
+    # smoothness on a cropped window, both gammas
+    img = torch.rand(B, 3, H, W, generator=g) - 0.43
+    dsp = (torch.rand(B, 1, H, W, generator=g) * 30 + 2).requires_grad_(True)
+    for x0, x1, gamma in ((8, W, 2.0), (0, 32, 1.0)):
+        dsp.grad = None
+        ref = O.smoothness(img[:, :, :, x0:x1], dsp[:, :, :, x0:x1], gamma)
+        ref.backward()
+        sc = 1.0 / (B * H * (x1 - x0))
+        L.check(lib.falnet_smooth_fwd(L.ptr(img.to(DEV)), L.ptr(dsp.detach().to(DEV)), B, H, W, x0, x1, gamma, sc, L.ptr(out), 0, L.stream_ptr()))
+        assert abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+        gd = torch.empty(B, 1, H, W, device=DEV)
+        L.check(lib.falnet_smooth_bwd(L.ptr(img.to(DEV)), L.ptr(dsp.detach().to(DEV)), B, H, W, x0, x1, gamma, sc, L.ptr(None), L.ptr(gd), 0, L.stream_ptr()))
+        assert rel(gd, dsp.grad) < 1e-5
+    # mse on NHWC, flip, rowmax, mask mix
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        x, y = torch.randn(2, 40, 5, 9, generator=g), torch.randn(2, 40, 5, 9, generator=g)
+        xt, yt = to_nhwc(x, dtype), to_nhwc(y, dtype)
+        sc = 1.0 / x.numel()
+        L.check(lib.falnet_mse_fwd(L.ptr(xt), L.ptr(yt), 2 * 5 * 9, 64, sc, L.ptr(out), 0, L.dtype_code(dtype), L.stream_ptr()))
+        assert abs(float(out) - float(((x - y) ** 2).mean())) < tol * float(((x - y) ** 2).mean())
+        gx = torch.empty_like(xt)
+        L.check(lib.falnet_mse_bwd(L.ptr(xt), L.ptr(yt), 2 * 5 * 9, 64, sc, L.ptr(None), L.ptr(gx), L.dtype_code(dtype), L.stream_ptr()))
+        assert rel(to_nchw(gx, 40), 2 * sc * (x - y)) < tol
+    fl = torch.empty(B, 3, H, W, device=DEV)
+    L.check(lib.falnet_hflip(L.ptr(a.detach().to(DEV)), L.ptr(fl), B * 3 * H, W, L.stream_ptr()))
+    assert torch.equal(fl.cpu(), torch.flip(a.detach(), [3]))
+    rm = torch.empty(B, device=DEV)
+    L.check(lib.falnet_rowmax(L.ptr(dsp.detach().to(DEV)), L.ptr(rm), B, H * W, L.stream_ptr()))
+    assert torch.equal(rm.cpu(), dsp.detach().reshape(B, -1).max(1).values)
+    mix = torch.empty(B, 3, H, W, device=DEV)
+    L.check(lib.falnet_mask_mix(L.ptr(a.detach().to(DEV)), L.ptr(b.to(DEV)), L.ptr(m.to(DEV)), L.ptr(mix), B, 3, H * W, L.stream_ptr()))
+    assert rel(mix, m * a.detach() + (1 - m) * b) < 1e-6
+
+
+def test_adam_matches_torch():
+    g = torch.Generator().manual_seed(8)
+    n = 10007
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-4, betas=(0.5, 0.999))
+    npad = (n + 3) // 4 * 4
+    p, m, v, gg = (torch.zeros(npad, device=DEV) for _ in range(4))
+    p[:n] = p0.to(DEV)
+    for step in range(1, 4):
+        pt.grad = gr * step
+        opt.step()
+        gg[:n] = (gr * step).to(DEV)
+        L.check(L.lib().falnet_adam_step(L.ptr(p), L.ptr(gg), L.ptr(m), L.ptr(v), n, 1e-4, 0.5, 0.999, 1e-8, step, 1.0, L.stream_ptr()))
+    assert float((p[:n].cpu() - pt.detach()).abs().max()) < 1e-7
