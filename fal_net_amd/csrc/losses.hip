@@ -315,6 +315,6 @@ extern "C" int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W,
 
 extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream) {
     FALNET_CHECK_ARG(src && out && B > 0 && n > 0, "rowmax: bad argument");
-    hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, src, out, n);
+    hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(RED_THREADS), 0, (hipStream_t)stream, src, out, n);
     FALNET_RETURN_LAUNCH();
 }
