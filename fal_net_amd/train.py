@@ -1,0 +1,140 @@
+"""Step bodies of the reference's training scripts on the HIP-backed module, plus the two pieces the
+reference delegates to torch: the optimiser (torch.optim.Adam, Train_Stage1_K.py:180) as ONE fused launch
+over the model's flat parameter buffer, and data parallelism (nn.DataParallel, Train_Stage1_K.py:172) as
+one process per GPU with ONE RCCL all-reduce of the flat gradient buffer per step.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import _lib as L
+from .loss_functions import rec_loss_fnc, smoothness, vgg
+
+
+class FlatAdam:
+    """Adam(betas, eps, weight_decay=0) over `model.flat_parameters()` (torch.optim.Adam semantics).
+
+    Both of the reference's param groups (biases / weights, Train_Stage1_K.py:177-178) use weight_decay 0,
+    so one flat update is identical to the two-group optimiser.  amask_conv never receives gradients and
+    is skipped exactly like torch skips `grad is None` parameters."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.model, self.betas, self.eps = model, betas, eps
+        self.param_groups = [{"lr": lr}]
+        self.t = 0
+        self.m = self.v = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self, grad_scale=1.0):
+        flat, grad = self.model.flat_parameters(), self.model.flat_gradients()
+        if flat is None:
+            raise RuntimeError("FlatAdam.step before any forward/backward of the model")
+        if self.m is None or self.m.data_ptr() == 0 or self.m.numel() != flat.numel() or self.m.device != flat.device:
+            self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.t += 1
+        b1, b2 = self.betas
+        L.check(L.lib().falnet_adam_step(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(),
+                                         float(self.param_groups[0]["lr"]), b1, b2, self.eps, self.t, float(grad_scale),
+                                         L.stream_ptr()), "adam_step")
+
+
+def allreduce_gradients(model):
+    """The step's single collective: sum of the flat f32 gradient buffer over ranks (RCCL over xGMI).
+    Returns the scale (1/world) to fold into the optimiser."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(model.flat_gradients(), op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+    return 1.0
+
+
+def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0, max_disp_arg=300.0):
+    """One iteration of Train_Stage1_K.py:233-262 (forward, VGG, losses, backward, all-reduce, Adam).
+    Returns device scalars (no host sync)."""
+    opt.zero_grad()
+    W = left.shape[3]
+    min_disp = max_disp * min_disp_arg / max_disp_arg  # :237
+    rpan, ldisp = model(left, min_disp, max_disp, ret_disp=True, ret_pan=True, ret_subocc=False)  # :238
+    vgg_right = vgg(right) if a_p > 0 else None  # :241-244
+    rec_loss = rec_loss_fnc(1, rpan, right, vgg_right, a_p)  # :248
+    sm_loss = 0
+    if a_sm > 0:
+        c = int(0.20 * W)
+        sm_loss = smoothness(left[:, :, :, c:], ldisp[:, :, :, c:], gamma=2)  # :255
+    loss = rec_loss + a_sm * sm_loss  # :258
+    loss.backward()
+    scale = allreduce_gradients(model)
+    opt.step(scale)
+    return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
+            "rpan": rpan, "ldisp": ldisp}
+
+
+def hflip(x):
+    """Flip via index reversal; the reference's affine_grid + grid_sample flip equals it to <=8.4e-7
+    (Train_Stage2_K.py:248-253)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    L.check(L.lib().falnet_hflip(L.ptr(x), L.ptr(out), rows, x.shape[-1], L.stream_ptr()), "hflip")
+    return out
+
+
+class _Flip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return hflip(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hflip(g)
+
+
+def flip(x):
+    return _Flip.apply(x) if x.requires_grad else hflip(x)
+
+
+def stage2_step(model, fix_model, opt, left, right, max_disp, a_p=0.01, a_sm=0.4 * 2 / 512, a_mr=1.0,
+                min_disp_arg=2.0, max_disp_arg=300.0):
+    """One iteration of Train_Stage2_K.py:233-331: frozen teacher on (flip(left) | right), student on
+    (left | flip(right)) with occlusion masks, masked reconstruction, smoothness and mirror losses."""
+    opt.zero_grad()
+    B, C, H, W = left.shape
+    min_disp = max_disp * min_disp_arg / max_disp_arg
+    mn2, mx2 = torch.cat((min_disp, min_disp), 0), torch.cat((max_disp, max_disp), 0)
+    if a_mr > 0:
+        with torch.no_grad():  # :256-264
+            tdisp = fix_model(torch.cat((hflip(left), right), 0), mn2, mx2, ret_disp=True, ret_pan=False, ret_subocc=False)
+            mldisp, mrdisp = hflip(tdisp[0:B]), tdisp[B:].contiguous()
+    pan, disp, mask0, mask1 = model(torch.cat((left, hflip(right)), 0), mn2, mx2, ret_disp=True, ret_pan=True, ret_subocc=True)
+    rpan, lpan = pan[0:B], flip(pan[B:])
+    ldisp, rdisp = disp[0:B], flip(disp[B:])
+    lmask, rmask = mask0[0:B], hflip(mask0[B:])
+    rlmask, lrmask = mask1[0:B], hflip(mask1[B:])
+    vgg_right, vgg_left = (vgg(right), vgg(left)) if a_p > 0 else (None, None)
+    c2, c8 = int(0.20 * W), int(0.80 * W)
+    if a_mr == 0:
+        O_L = O_R = 1  # :300-302
+    else:
+        O_L = lmask * lrmask
+        O_L[:, :, :, 0:c2] = 1
+        O_R = rmask * rlmask
+        O_R[:, :, :, c8:] = 1
+    rec_loss = (rec_loss_fnc(O_R, rpan, right, vgg_right, a_p) + rec_loss_fnc(O_L, lpan, left, vgg_left, a_p)) / 2
+    sm_loss = 0
+    if a_sm > 0:
+        sm_loss = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
+                   smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
+    mirror_loss = 0
+    if a_mr > 0:  # :316-324 (small 1-channel maps; masked means stay in torch)
+        nmaxl = 1 / mldisp.reshape(B, -1).max(1).values.view(B, 1, 1, 1)
+        nmaxr = 1 / mrdisp.reshape(B, -1).max(1).values.view(B, 1, 1, 1)
+        mirror_loss = (torch.mean(nmaxl * (1 - O_L)[:, :, :, c2:] * torch.abs(ldisp - mldisp)[:, :, :, c2:]) +
+                       torch.mean(nmaxr * (1 - O_R)[:, :, :, 0:c8] * torch.abs(rdisp - mrdisp)[:, :, :, 0:c8])) / 2
+    loss = rec_loss + a_sm * sm_loss + a_mr * mirror_loss
+    loss.backward()
+    scale = allreduce_gradients(model)
+    opt.step(scale)
+    return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss, "mirror": mirror_loss, "ldisp": ldisp, "rdisp": rdisp,
+            "O_L": O_L, "O_R": O_R}

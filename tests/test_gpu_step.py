@@ -1,0 +1,153 @@
+"""GPU parity tests, step level: the Stage-1 / Stage-2 step bodies (model + VGG + losses + backward + fused Adam)
+against the golden fixtures recorded from the reference and against the CPU oracle."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fal_net_amd import loss_functions as LF  # noqa: E402
+from fal_net_amd import synthetic, train  # noqa: E402
+from fal_net_amd.models import FAL_netB  # noqa: E402
+from oracle import falnet_oracle as O  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-4  # north_star gate (f32 path): loss scalars and disparity maps within 1e-4 relative
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def sample_idx(key, numel, k=16):
+    g = np.random.default_rng(zlib.crc32(("idx:" + key).encode()))
+    return g.integers(0, numel, size=min(k, numel))
+
+
+def build(n_levels, dtype=torch.float32):
+    LF.set_compute_dtype(dtype)
+    m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(n_levels)}, no_levels=n_levels, compute_dtype=dtype)
+    return m.to(DEV)
+
+
+def test_stage1_step_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_stage1_step.npz"))
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    m = build(49).train()
+    opt = train.FlatAdam(m, lr=1e-4, betas=(0.5, 0.999))
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    out = train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, (k, float(out[k]), float(g[k]))
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    for k, p in m.named_parameters():
+        if "amask_conv" in k:
+            assert ("nograd:" + k) in g.files and p.grad is None
+            assert torch.equal(p.detach(), before[k])  # untouched by Adam, like torch's grad-is-None skip
+            continue
+        gr = grads[k].reshape(-1)
+        gn = float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - gn) / gn < 5e-4, k
+        idx = sample_idx(k, gr.numel())
+        assert np.abs(gr[idx].cpu().numpy() - g["gsamp:" + k]).max() <= 5e-4 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
+        assert np.abs(after - g["after:" + k]).max() < 2.5e-5, k  # first Adam step moves by ~lr=1e-4
+
+
+def test_stage1_config_shape_vs_golden(golden_dir):
+    """256x512, N=49 (BASELINE configs[0]/[1] shape), B=1: disparity map + loss scalars."""
+    g = np.load(os.path.join(golden_dir, "g4_config_256x512.npz"))
+    left, right, mn, mx = synthetic.synthetic_pair(1, 256, 512, seed=int(g["seed"]))
+    m = build(49).train()
+    opt = train.FlatAdam(m)
+    out = train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, (k, float(out[k]), float(g[k]))
+    assert rel(out["ldisp"][:, :, ::8, ::8], g["disp"]) < TOL
+    assert rel(out["rpan"][:, :, ::8, ::8], g["p_im0"]) < 2e-4
+    for k, p in m.named_parameters():
+        if ("gnorm:" + k) in g.files:
+            gn = float(g["gnorm:" + k])
+            assert abs(float(p.grad.norm()) - gn) / gn < 2e-3, k
+    # abs_rel of depth (myUtils.py:225 style) between HIP and reference disparities
+    d_ref, d_hip = 721.5377 * 0.54 / g["disp"], 721.5377 * 0.54 / out["ldisp"].detach()[:, :, ::8, ::8].cpu().numpy()
+    assert float(np.mean(np.abs(d_ref - d_hip) / d_ref)) < 1e-5
+
+
+def test_losses_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_losses_metrics.npz"))
+    LF.set_compute_dtype(torch.float32)
+    img, dsp = torch.from_numpy(g["img"]).to(DEV), torch.from_numpy(g["dsp"]).to(DEV).requires_grad_(True)
+    assert abs(float(LF.smoothness(img, dsp, 1)) - float(g["sm_g1"])) < 1e-5 * float(g["sm_g1"])
+    sm2 = LF.smoothness(img, dsp, 2)
+    assert abs(float(sm2) - float(g["sm_g2"])) < 1e-5 * float(g["sm_g2"])
+    sm2.backward()
+    assert rel(dsp.grad, g["sm_g2_grad"]) < 1e-5
+    synth = torch.from_numpy(g["synth"]).to(DEV).requires_grad_(True)
+    label, mask = torch.from_numpy(g["label"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    vl = LF.vgg(label)
+    assert np.allclose([float(v.float().mean()) for v in vl], g["vgg_label_means"], rtol=1e-4)
+    r = LF.rec_loss_fnc(mask, synth, label, vl, 0.01)
+    assert abs(float(r) - float(g["rec_masked"])) < TOL * float(g["rec_masked"])
+    r.backward()
+    assert rel(synth.grad, g["rec_masked_grad"]) < 2e-4
+    assert abs(float(LF.rec_loss_fnc(1, synth.detach(), label, vl, 0.01)) - float(g["rec_one"])) < TOL * float(g["rec_one"])
+    assert abs(float(LF.rec_loss_fnc(mask, synth.detach(), label, None, 0.0)) - float(g["rec_l1"])) < TOL * float(g["rec_l1"])
+
+
+def test_smoothness_column_window():
+    """The callers crop columns before the loss (Train_Stage1_K.py:255); the windowed kernel must equal the
+    loss on materialised crops, incl. gradients landing in the uncropped parent."""
+    gen = torch.Generator().manual_seed(5)
+    img = (torch.rand(2, 3, 16, 64, generator=gen) - 0.43).to(DEV)
+    dsp = (torch.rand(2, 1, 16, 64, generator=gen) * 40).to(DEV).requires_grad_(True)
+    a = LF.smoothness(img[:, :, :, 12:], dsp[:, :, :, 12:], gamma=2)
+    a.backward()
+    ga = dsp.grad.clone()
+    dsp.grad = None
+    ref = O.smoothness(img.cpu()[:, :, :, 12:], dsp.detach().cpu().requires_grad_(True)[:, :, :, 12:], gamma=2)
+    assert abs(float(a) - float(ref)) < 1e-5 * float(ref)
+    assert float(ga[:, :, :, :12].abs().max()) == 0.0
+    b = LF.smoothness(img[:, :, :, 12:].contiguous(), dsp[:, :, :, 12:].contiguous(), gamma=2)
+    b.backward()
+    assert rel(dsp.grad, ga) < 1e-6
+
+
+def test_stage2_step_vs_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_stage2_step.npz"))
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    m, fix = build(7).train(), build(7).eval()
+    opt = train.FlatAdam(m, lr=5e-5)
+    out = train.stage2_step(m, fix, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+    for k in ("loss", "rec", "sm", "mirror"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, (k, float(out[k]), float(g[k]))
+    for k in ("ldisp", "rdisp"):
+        assert rel(out[k], g[k]) < TOL, k
+    for k in ("O_L", "O_R"):
+        assert rel(out[k], g[k]) < 2e-4, k
+    for k, p in m.named_parameters():
+        if ("gnorm:" + k) in g.files:
+            gn = float(g["gnorm:" + k])
+            assert abs(float(p.grad.norm()) - gn) / gn < 1e-3, k
+
+
+def test_bf16_step_runs_and_tracks_f32():
+    """bf16 throughput path: same step, deviation reported (no 1e-4 gate; the reference is f32-only)."""
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=21, distinct=True)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = build(49, dt).train()
+        opt = train.FlatAdam(m)
+        out = train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+        res[dt] = (float(out["loss"]), out["ldisp"].clone(), m.flat_gradients().clone())
+    LF.set_compute_dtype(torch.float32)
+    l32, d32, g32 = res[torch.float32]
+    l16, d16, g16 = res[torch.bfloat16]
+    print("bf16 vs f32: loss rel", abs(l16 - l32) / l32, "disp rel", rel(d16, d32), "grad cos",
+          float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)))
+    assert abs(l16 - l32) / l32 < 2e-2
+    assert float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)) > 0.98
