@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: one Stage-1 training step of FAL_netB
+(Train_Stage1_K.py:233-262: model fwd -> VGG(right) -> L1+perceptual -> smoothness -> backward ->
+gradient all-reduce -> Adam) at 256x512, N=49, batch 8 per GPU, synthetic data, seeded weights.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `value` = stereo pairs/s over all ranks with inputs resident in HBM.
+`roofline` = the dominant kernel's achieved rate (algorithmic FLOPs / HIP-event time, from an instrumented
+pass after the timed region).  `cpu_baseline` = the CPU oracle (oracle/falnet_oracle.py: a torch-CPU
+restatement of the same step) timed on this host on a bounded sample -- the only use of oracle/ here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+class EventTimer:
+    """ops.TIMER hook: brackets every C-ABI launch with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def run(self, tag, flops, nbytes, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.records.append((tag, flops, nbytes, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(tag, {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+            a["bytes"] += nbytes
+            a["launches"] += 1
+        return agg
+
+
+def cpu_baseline(height, width, levels, sample_batch=1):
+    """Reported CPU baseline: the oracle's Stage-1 step (fp32, torch CPU) on a bounded sample.
+    Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get *slower* beyond that
+    (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
+    from fal_net_amd import synthetic
+    from oracle import falnet_oracle as O
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    left, right, mn, mx = synthetic.synthetic_pair(sample_batch, height, width, seed=1234)
+    params = O.leaf_params(synthetic.seeded_falnetb_state_dict(levels))
+    vsd = synthetic.seeded_vgg19_state_dict()
+    opt = O.OracleAdam(params)
+    t0 = time.time()
+    O.stage1_step(params, opt, vsd, left, right, mn, mx)
+    dt = time.time() - t0
+    return {"value": sample_batch / dt, "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 Stage-1 step (fwd+VGG+losses+bwd+Adam), B={sample_batch}, {height}x{width}, N={levels}, "
+                      f"fp32 torch-CPU oracle, {torch.get_num_threads()} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--levels", type=int, default=49)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+
+    from fal_net_amd import loss_functions as LF
+    from fal_net_amd import ops, synthetic, train
+    from fal_net_amd.models import FAL_netB
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    LF.set_compute_dtype(dtype)
+    model = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(args.levels)}, no_levels=args.levels,
+                     compute_dtype=dtype).to(dev).train()
+    opt = train.FlatAdam(model, lr=1e-4, betas=(0.5, 0.999))
+    left, right, mn, mx = synthetic.synthetic_pair(args.batch, args.height, args.width, seed=1234 + rank)
+    left, right, mx = left.to(dev), right.to(dev), mx.to(dev)  # inputs resident in HBM before the timed region
+
+    def step():
+        return train.stage1_step(model, opt, left, right, mx)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(out["loss"])
+    ms = elapsed * 1e3 / args.steps
+    pairs_per_s = world * args.batch * args.steps / elapsed
+
+    result = {
+        "metric": "stereo-pairs/sec Stage-1 step @256x512 N=49",
+        "value": pairs_per_s, "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+        "config": {"workload": f"Stage-1 training step (BASELINE configs[1]), batch {args.batch}/GPU, "
+                               f"{args.height}x{args.width}, N={args.levels}, seeded weights, seeded VGG19",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass (NOT part of the timed region): HIP events around every launch
+        timer = EventTimer()
+        ops.TIMER = timer
+        for _ in range(3):
+            step()
+        agg = timer.summary()
+        ops.TIMER = None
+        total_ms = sum(a["ms"] for a in agg.values()) / 3
+        dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
+        d = agg[dom_tag]
+        peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        mfma_ms = sum(a["ms"] for a in agg.values() if a["flops"] > 0) / 3
+        mfma_fl = sum(a["flops"] for a in agg.values()) / 3
+        result["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "kernel": dom_tag, "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+            "kernel_ms_per_step": d["ms"] / 3, "all_kernels_ms_per_step": total_ms,
+            "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,
+                                 "algorithmic_gflop_per_step": mfma_fl / 1e9},
+        }
+        heads = {t: a for t, a in agg.items() if t.startswith("falnet_med_head")}
+        if heads:
+            hb = sum(a["bytes"] for a in heads.values()) / 3
+            hms = sum(a["ms"] for a in heads.values()) / 3
+            result["roofline"]["med_head_hbm"] = {"bound": "hbm", "achieved": hb / (hms * 1e-3) / 1e9, "peak": 8000.0,
+                                                  "unit": "GB/s", "frac": hb / (hms * 1e-3) / 1e9 / 8000.0, "ms_per_step": hms}
+        result["kernel_breakdown_ms_per_step"] = {t: round(a["ms"] / 3, 4) for t, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.height, args.width, args.levels)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,7 +46,7 @@ class _VggPlan:
                 y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device)
                 self.fwd.append(ops.conv_call(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
                                               1, B, h, w, y, h, w, pc.cout, pc.cout, bias=pc.bias, act=L.ACT_RELU,
-                                              name=f"vgg conv{idx}"))
+                                              name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9))
                 acts.append((pc, cur, y, h, w))
                 cur = y
             pooled = torch.empty(B, h // 2, w // 2, cur.shape[3], dtype=dtype, device=device)
@@ -75,7 +75,8 @@ class _VggPlan:
                     # first conv: data gradient wrt the 3-channel image
                     gin = torch.empty(B, h, w, ops.pad_c(3), dtype=dtype, device=device)
                     self.bwd.append(ops.conv_call(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
-                                                  ops.pad_c(3), 1, B, h, w, gin, h, w, ops.pad_c(3), ops.pad_c(3), name="vgg dgrad0"))
+                                                  ops.pad_c(3), 1, B, h, w, gin, h, w, ops.pad_c(3), ops.pad_c(3), name="vgg dgrad0",
+                                                  flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.g_in = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
                     self.bwd.append(ops.simple_call("falnet_nhwc_to_nchw", L.ptr(gin), L.ptr(self.g_in), B, 3, H, W, ops.pad_c(3), code))
                     self.keep.append(gin)
@@ -87,7 +88,8 @@ class _VggPlan:
                     self.bwd.append(ops.conv_call(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
                                                   pc.cin_pad, 1, B, h, w, gin, h, w, pc.cin_pad, pc.cin_pad,
                                                   actout=None if from_pool else x,
-                                                  actout_kind=L.ACT_NONE if from_pool else L.ACT_RELU, name="vgg dgrad"))
+                                                  actout_kind=L.ACT_NONE if from_pool else L.ACT_RELU, name="vgg dgrad",
+                                                  flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.keep.append(gin)
                     g_next = gin
 

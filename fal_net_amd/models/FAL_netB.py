@@ -133,7 +133,8 @@ class FalnetPlan:
         OH, OW = out.shape[1], out.shape[2]
         self.fwd.append(ops.conv_call(self.dtype, srcs, IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(pc.ksize), pc.taps,
                                       pc.cout_pad, pc.stride, B, OH, OW, out, OH, OW, out.shape[3], out.shape[3],
-                                      bias=pc.bias, addend=addend, act=act, name="fwd " + name))
+                                      bias=pc.bias, addend=addend, act=act, name="fwd " + name,
+                                      flops=2 * B * OH * OW * pc.cout * pc.cin * pc.taps))
 
     def _dgrad(self, pc, group, gout, gin, IH, IW, addend=None, actout=None, name=""):
         """Append launches computing gin = dgrad_group(gout) [+ addend] [* elu'(actout)].
@@ -144,11 +145,12 @@ class FalnetPlan:
         cg = pc.groups_pad[group]
         kind = L.ACT_ELU if actout is not None else L.ACT_NONE
         src = [ops.nhwc_src(gout)]
+        fl1 = 2 * B * OH * OW * pc.cout * pc.groups_real[group]  # algorithmic flops per tap
         if pc.stride == 1:
             self.bwd_body.append(ops.conv_call(
                 self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(pc.ksize), pc.taps, cg, 1, B, IH, IW,
                 gin, IH, IW, cg, gin.shape[3], addend=addend, actout=actout, actout_kind=kind,
-                weight_offset_elems=off, name="dgrad " + name))
+                weight_offset_elems=off, name="dgrad " + name, flops=fl1 * pc.taps))
         else:
             for py in range(2):
                 for px in range(2):
@@ -158,14 +160,16 @@ class FalnetPlan:
                     self.bwd_body.append(ops.conv_call(
                         self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th,
                         tw, gin, IH, IW, cg, gin.shape[3], out_step=(2, 2, py, px), addend=addend, actout=actout,
-                        actout_kind=kind, weight_offset_elems=off, name=f"dgrad{py}{px} " + name))
+                        actout_kind=kind, weight_offset_elems=off, name=f"dgrad{py}{px} " + name,
+                        flops=fl1 * len(ops.dgrad_taps_s2(py, px))))
 
     def _wgrad(self, pc, srcs, IH, IW, gout, name=""):
         OH, OW = gout.shape[1], gout.shape[2]
         gw = self.model._grad_view(pc.weight)
         gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
         call = ops.wgrad_calls(self.dtype, srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)],
-                               pc.stride, self.B, OH, OW, pc, gw, gb, self.buf["ws"], name="wgrad " + name)
+                               pc.stride, self.B, OH, OW, pc, gw, gb, self.buf["ws"], name="wgrad " + name,
+                               flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps)
         self.bwd_body.append(lambda c=call: c(self._accumulate))
 
     # ---- plan construction ----
@@ -229,13 +233,14 @@ class FalnetPlan:
         dlog0 = self._f32("dlog0", B, N, H, W)
         self.fwd.append(ops.conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
                                       1, B, H, W, dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pc0.bias,
-                                      name="fwd conv0(1x1)"))
+                                      name="fwd conv0(1x1)", flops=2 * B * H * W * N * N))
         disp, pan, stats = self._f32("disp", B, 1, H, W), self._f32("p_im0", B, 3, H, W), self._f32("stats", B, 4, H, W)
         maskL, maskR = self._f32("maskL", B, 1, H, W), self._f32("maskR", B, 1, H, W)
         self.head_disp_only = ops.simple_call("falnet_med_head_fwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx),
                                               L.ptr(disp), L.ptr(None), L.ptr(stats), B, N, H, W)
         self.head_full = ops.simple_call("falnet_med_head_fwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx),
-                                         L.ptr(disp), L.ptr(pan), L.ptr(stats), B, N, H, W)
+                                         L.ptr(disp), L.ptr(pan), L.ptr(stats), B, N, H, W,
+                                         nbytes=(N + 7) * H * W * 4 * B)
         self.head_masks = ops.simple_call("falnet_med_masks_fwd", L.ptr(dlog0), L.ptr(mn), L.ptr(mx), L.ptr(stats),
                                           L.ptr(maskL), L.ptr(maskR), B, N, H, W)
 
@@ -246,7 +251,8 @@ class FalnetPlan:
         def head_bwd(has_disp, has_pan):
             return ops.simple_call("falnet_med_head_bwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
                                    L.ptr(pan), L.ptr(stats), L.ptr(g_disp if has_disp else None),
-                                   L.ptr(g_pan if has_pan else None), L.ptr(g_dlog0), B, N, H, W)
+                                   L.ptr(g_pan if has_pan else None), L.ptr(g_dlog0), B, N, H, W,
+                                   nbytes=(2 * N + 7) * H * W * 4 * B)
         self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
         G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, NHWC
         self.bwd_body.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(g_dlog0), L.ptr(G0), B, N, H, W, pad_c(N), code))

@@ -13,6 +13,27 @@ from . import _lib as L
 
 CPAD = L.CPAD
 
+# Optional launch timer (bench.py / profiling): object with run(tag, flops, bytes, launch).  None on the
+# product path: launches are then plain C-ABI calls.
+TIMER = None
+
+
+def _timed(tag, flops, nbytes, launch):
+    def call(*a):
+        t = TIMER
+        if t is None:
+            launch(*a)
+        else:
+            t.run(tag, flops, nbytes, lambda: launch(*a))
+    call.tag, call.flops, call.nbytes = tag, flops, nbytes
+    return call
+
+
+def conv_kernel_tag(dtype, w_rows, Cout, planar):
+    """Name of the conv_igemm_kernel instantiation falnet_conv2d dispatches to (conv.hip: falnet_conv2d)."""
+    bn = 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
+    return f"conv_igemm_kernel<{'bf16' if dtype == torch.bfloat16 else 'f32'},{bn},{'planar' if planar else 'nhwc'}>"
+
 
 def pad_c(c):
     return (c + CPAD - 1) // CPAD * CPAD
@@ -120,7 +141,7 @@ def _fill_taps(d, taps):
 
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
-              act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv"):
+              act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0):
     """Build one falnet_conv2d launch; returns a zero-argument callable."""
     lib = L.lib()
     d = L.Conv()
@@ -144,13 +165,13 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout)
 
-    def call(_keep=keep):
+    def launch(_keep=keep):
         L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
-    return call
+    return _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32), flops, 0, launch)
 
 
 def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, ws, target_wgs=1536,
-                name="wgrad"):
+                name="wgrad", flops=0):
     """Weight (+bias) gradient of one conv: split-K partial slabs in `ws`, then a reduce into the
     OIHW f32 views `grad_w` / `grad_b`.  Returns a callable taking (accumulate)."""
     lib = L.lib()
@@ -180,20 +201,30 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     npix = M
     keep = (d, srcs, gout, grad_w, grad_b, ws)
 
-    def call(accumulate=0, _keep=keep):
+    dname = "bf16" if dtype == torch.bfloat16 else "f32"
+
+    def k_wgrad(accumulate=0, _keep=keep):
+        L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
+
+    def k_reduce(accumulate=0):
         st = L.stream_ptr()
-        L.check(lib.falnet_wgrad(ref, st), name)
         L.check(lib.falnet_wgrad_reduce(*red_args, int(accumulate), st), name + " reduce")
         if grad_b is not None:
             L.check(lib.falnet_bias_grad(L.ptr(gout), npix, gC, pc.cout, L.ptr(grad_b), int(accumulate),
                                          L.dtype_code(dtype), st), name + " bias")
+    t_wgrad = _timed(f"wgrad_kernel<{dname}>", flops, 0, k_wgrad)
+    t_reduce = _timed("wgrad_reduce+bias_grad", 0, 0, k_reduce)
+
+    def call(accumulate=0):
+        t_wgrad(accumulate)
+        t_reduce(accumulate)
     return call
 
 
-def simple_call(fn_name, *args, name=None):
+def simple_call(fn_name, *args, name=None, nbytes=0):
     lib = L.lib()
     fn = getattr(lib, fn_name)
 
-    def call():
+    def launch():
         L.check(fn(*args, L.stream_ptr()), name or fn_name)
-    return call
+    return _timed(fn_name, 0, nbytes, launch)
