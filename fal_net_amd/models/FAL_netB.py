@@ -113,6 +113,8 @@ class FalnetPlan:
         self.model, self.B, self.H, self.W, self.dtype, self.device = model, B, H, W, dtype, device
         self.N = model.no_levels
         self.generation = 0
+        self.use_side_stream = True
+        self._side = self._side_stream = None
         self.buf = {}
         self.fwd, self.bwd_head, self.bwd_body, self.pack = [], [], [], []
         self._build()
@@ -170,7 +172,21 @@ class FalnetPlan:
         call = ops.wgrad_calls(self.dtype, srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)],
                                pc.stride, self.B, OH, OW, pc, gw, gb, self.buf["ws"], name="wgrad " + name,
                                flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps)
-        self.bwd_body.append(lambda c=call: c(self._accumulate))
+        # weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill
+        # the CUs that the small (latency-bound) dgrad launches leave idle.  Ordering: the side stream waits for
+        # the producer of `gout` (event on the main stream); run_backward joins the side stream at the end.
+        ev = torch.cuda.Event()
+
+        def run(c=call, ev=ev):
+            side = self._side_stream
+            if side is None:
+                c(self._accumulate)
+                return
+            ev.record()
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                c(self._accumulate)
+        self.bwd_body.append(run)
 
     # ---- plan construction ----
     def _build(self):
@@ -334,9 +350,19 @@ class FalnetPlan:
         if g_pan is not None:
             b["g_pan"].copy_(g_pan)
         self._accumulate = self.model._begin_grad_accumulation()
+        main = torch.cuda.current_stream()
+        if self.use_side_stream and ops.TIMER is None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side_stream = self._side
+            self._side_stream.wait_stream(main)  # the previous step's Adam / repack must not be overtaken
+        else:
+            self._side_stream = None
         self.head_bwd[(g_disp is not None, g_pan is not None)]()
         for call in self.bwd_body:
             call()
+        if self._side_stream is not None:
+            main.wait_stream(self._side_stream)
         self.model._end_grad_accumulation()
 
 
