@@ -33,7 +33,7 @@ class Conv(C.Structure):
                 ("out", C.c_void_p), ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32),
                 ("out_cstride", C.c_int32), ("out_layout", C.c_int32), ("bias", C.c_void_p),
                 ("addend", C.c_void_p), ("act", C.c_int32), ("actout", C.c_void_p),
-                ("actout_kind", C.c_int32), ("dtype", C.c_int32)]
+                ("actout_kind", C.c_int32), ("dtype", C.c_int32), ("variant", C.c_int32)]
 
 
 class Wgrad(C.Structure):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "falnet_version": [],
     "falnet_last_error": [],
     "falnet_channel_pad": [_I],
+    "falnet_debug_set": [_I, _I],
     "falnet_conv2d": [C.POINTER(Conv), _P],
     "falnet_wgrad_workspace_bytes": [C.POINTER(Wgrad)],
     "falnet_wgrad": [C.POINTER(Wgrad), _P],

@@ -12,6 +12,7 @@
 //   f32 : v_mfma_f32_32x32x2_f32 (exact f32, the parity path); K is walked in a lane-half-permuted order
 //         (half h owns k in [8h, 8h+8)) so that each lane's operands are two ds_read_b128.
 // Wave tiling: 4 waves, 128 positions x {32,64,128} channels per workgroup.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,7 +38,94 @@ __device__ __forceinline__ float act_grad_from_out(float y, int kind) {
     return 1.f;
 }
 
-struct Frag { uint4 v[2]; };
+
+// ---- vectorised epilogue ------------------------------------------------------------------------------
+// The MFMA C/D layout puts one channel on each lane, so a direct store is 2 B (bf16) per lane: store-issue
+// bound.  Instead every wave stages one 32-row accumulator slab at a time through its private LDS area
+// (f32, pitch NT*32+4 floats) and then owns (row, 8-channel segment) pieces: bias / residual / activation /
+// activation-gradient are applied on 8 values and written with 16-B stores; addend / actout come in 16-B loads.
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+    uint4 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const {
+        const unsigned w = (&v.x)[i >> 1];
+        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+    __device__ __forceinline__ void set8(const float (&f)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t lo = (bf16_t)f[2 * i], hi = (bf16_t)f[2 * i + 1];
+            (&v.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+        }
+    }
+};
+template <> struct Vec8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = reinterpret_cast<const float4*>(p)[0]; b = reinterpret_cast<const float4*>(p)[1]; }
+    __device__ __forceinline__ void store(float* p) const { reinterpret_cast<float4*>(p)[0] = a; reinterpret_cast<float4*>(p)[1] = b; }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? (&a.x)[i] : (&b.x)[i - 4]; }
+    __device__ __forceinline__ void set8(const float (&f)[8]) {
+        a = make_float4(f[0], f[1], f[2], f[3]);
+        b = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+
+// RowOff: functor row(0..31 of slab mt) -> element offset of the output pixel's channel 0, or -1
+template <typename T, int MT, int NT, typename RowOff>
+__device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], float* stage, int nbase, int lane,
+                                              RowOff rowoff) {
+    constexpr int PITCHF = NT * 32 + 4;
+    constexpr int CS = NT * 4;          // 8-channel segments per row
+    constexpr int RPP = 64 / CS;        // rows per pass
+    const int r = lane & 31, h = lane >> 5;
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    T* out = reinterpret_cast<T*>(p.out);
+    const int cs = lane % CS, rsub = lane / CS;
+    const int n = nbase + cs * 8;
+    float bias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && n < p.Cout) ? p.bias[n + i] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) stage[((j & 3) + 8 * (j >> 2) + 4 * h) * PITCHF + nt * 32 + r] = acc[mt][nt][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int row = ps * RPP + rsub;
+            const int64_t o = rowoff(mt, row);
+            if (o >= 0 && n < p.Cout) {
+                const float4 x0 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8);
+                const float4 x1 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8 + 4);
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const int64_t off = o + n;
+                Vec8<T> t;
+                if (addend) {
+                    t.load(addend + off);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += t.get(i);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] + bias[i], p.act);
+                if (actout) {
+                    t.load(actout + off);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= act_grad_from_out(t.get(i), p.actout_kind);
+                }
+                t.set8(v);
+                t.store(out + off);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 template <typename T, int MT, int NT, bool SWAP>
 __device__ __forceinline__ void mma_tile(const char* __restrict__ As, const char* __restrict__ Bs, int arow0, int brow0,
@@ -224,30 +312,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
 
     // ---- epilogue: v = act(acc + bias + addend) * act'(actout) ----
     const int r = lane & 31, h = lane >> 5;
-    const T* addend = reinterpret_cast<const T*>(p.addend);
-    const T* actout = reinterpret_cast<const T*>(p.actout);
     if constexpr (!SWAP) {
-        T* out = reinterpret_cast<T*>(p.out);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + wn * WTN + nt * 32 + r;
-            if (n >= p.Cout) continue;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int row = wm * WTM + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                    const int o = outpix[row];
-                    if (o < 0) continue;
-                    const int64_t off = (int64_t)o * p.out_cstride + n;
-                    float v = acc[mt][nt][j] + bias;
-                    if (addend) v += to_f32(addend[off]);
-                    v = apply_act(v, p.act);
-                    if (actout) v *= act_grad_from_out(to_f32(actout[off]), p.actout_kind);
-                    out[off] = from_f32<T>(v);
-                }
-        }
+        // outpix lives behind the A/B buffers; the dead A/B area becomes the per-wave staging slabs
+        float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
+        static_assert(4 * 32 * (NT * 32 + 4) * 4 <= 2 * (BM + BN) * ROWP, "staging must fit in the A/B buffers");
+        const int cstride = p.out_cstride;
+        epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, [&](int mt, int row) -> int64_t {
+            const int o = outpix[wm * WTM + mt * 32 + row];
+            return o < 0 ? (int64_t)-1 : (int64_t)o * cstride;
+        });
     } else {
         // swapped operands: D rows = channels, D columns (lanes) = positions -> planar f32 stores of
         // 32 consecutive pixels per channel
@@ -268,6 +341,283 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
                     out[(int64_t)o + (int64_t)n * plane] = v;
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 3x3 halo-patch kernel
+// Dense 3x3 stride-1 convolutions (forward, stride-1 dgrad, fused upsample / concat included) on large images:
+// a workgroup owns an 8x32 block of output positions (M = 256) x BN channels.  For every K chunk (KCB bytes of
+// input channels of one source) the (8+2)x(32+2) input halo patch is staged in LDS ONCE and re-used by all 9
+// taps (the generic gather kernel re-fetches it per tap); the packed weights stream through LDS per tap group.
+//   mode P (TPS=1): one tap per barrier, double-buffered weight tile, next chunk's patch prefetched in 9 slices
+//                   (one per tap) behind the MFMAs; used when there is enough K per tap (KCB = 128 B).
+//   mode S (TPS=9): small-channel layers (C = 32): patch + all 9 taps' weights in one stage, several
+//                   workgroups per CU overlap each other.
+// One 32-position MFMA row tile = one image row of the block, so A-fragment rows are consecutive patch pixels
+// (pitch KCB+16 B: conflict-free ds_read_b128, as in the gather kernel).
+template <typename T, int KCB, int MT, int NT, bool SWAP_>
+__device__ __forceinline__ void mma_rows(const char* const (&arow)[MT], const char* const (&brow)[NT], int h,
+                                         f32x16 (&acc)[MT][NT]) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < KCB / 32; ++ks) {
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(brow[nt] + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    } else {
+        constexpr int HB = KCB / 2;  // bytes of K owned by one lane half
+#pragma unroll
+        for (int q = 0; q < HB / 16; ++q) {
+            float4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(arow[mt] + h * HB + q * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(brow[nt] + h * HB + q * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32((&a[mt].x)[e], (&b[nt].x)[e], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+#define PT_TH 8
+#define PT_TW 32
+#define PT_PW (PT_TW + 2)
+#define PT_NPIX ((PT_TH + 2) * PT_PW)
+
+template <typename T, int BN, int KCB, int TPS, bool ADB>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falnet_conv_t p, int tiles_x, int tiles_y) {
+    constexpr int PITCH = KCB + 16;
+    constexpr int SEGS = KCB / 16;
+    constexpr int KCV = KCB / (int)sizeof(T);
+    constexpr int EPS = 16 / (int)sizeof(T);
+    constexpr int WAVES_N = BN >= 128 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int MT = PT_TH / WAVES_M;
+    constexpr int WTN = BN / WAVES_N, NT = WTN / 32;
+    constexpr bool PIPE = TPS < 9;  // mode P
+    constexpr int A_BYTES = PT_NPIX * PITCH, B_BYTES = TPS * BN * PITCH;
+    constexpr int ROWL = PT_PW * SEGS;                                   // 16-B loads per patch row
+    constexpr int A_SLOTS = (ROWL + CONV_THREADS - 1) / CONV_THREADS;    // per thread per patch row
+    constexpr int BL = BN * SEGS;                                        // 16-B loads per weight tap tile
+    constexpr int B_SLOTS = (BL + CONV_THREADS - 1) / CONV_THREADS;
+    __shared__ __attribute__((aligned(16))) char lds[(ADB ? 2 : 1) * A_BYTES + (PIPE ? 2 : 1) * B_BYTES];
+    auto Abuf = [&](int b) -> char* { return lds + (ADB ? b : 0) * A_BYTES; };
+    auto Bbuf = [&](int b) -> char* { return lds + (ADB ? 2 : 1) * A_BYTES + (PIPE ? b : 0) * B_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int r = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int tix = bid % tiles_x;
+    bid /= tiles_x;
+    const int tiy = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ty0 = tiy * PT_TH, tx0 = tix * PT_TW;
+    const int n0 = blockIdx.y * BN;
+
+    int nchunks = 0;
+    for (int s = 0; s < p.nsrc; ++s) nchunks += p.src[s].C / KCV;
+
+    // ---- loop-invariant per-thread load descriptors (no divisions / 64-bit multiplies in the main loop) ----
+    // patch row slots: this thread's (column, segment) inside ANY patch row, per source (upsampling differs)
+    int a_lds[A_SLOTS];            // byte offset inside a patch row in LDS, -1 = no slot
+    int a_goff[A_SLOTS][2];        // element offset (px*sx + seg*EPS) per source, -1 = outside the image (zero fill)
+#pragma unroll
+    for (int u = 0; u < A_SLOTS; ++u) {
+        const int idx = tid + u * CONV_THREADS;
+        a_lds[u] = -1;
+        a_goff[u][0] = a_goff[u][1] = -1;
+        if (idx < ROWL) {
+            const int pc = idx / SEGS, seg = idx % SEGS;
+            a_lds[u] = pc * PITCH + seg * 16;
+            const int vx = tx0 - 1 + pc;
+            if (vx >= 0 && vx < p.IW) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (s < p.nsrc) {
+                        const falnet_src_t& S = p.src[s];
+                        int px = vx;
+                        if (S.W != p.IW) px = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
+                        a_goff[u][s] = px * (int)S.sx + seg * EPS;
+                    }
+                }
+            }
+        }
+    }
+    // weight tile slots: (row, segment) of one tap tile
+    int b_lds[B_SLOTS];
+    int64_t b_goff[B_SLOTS];
+#pragma unroll
+    for (int u = 0; u < B_SLOTS; ++u) {
+        const int idx = tid + u * CONV_THREADS;
+        b_lds[u] = -1;
+        b_goff[u] = 0;
+        if (idx < BL) {
+            const int row = idx / SEGS, seg = idx % SEGS;
+            if (n0 + row < p.w_rows) {
+                b_lds[u] = row * PITCH + seg * 16;
+                b_goff[u] = (int64_t)(n0 + row) * p.w_taps * p.cin_total + seg * EPS;
+            } else {
+                b_lds[u] = -2 - (row * PITCH + seg * 16);  // zero-fill slot
+            }
+        }
+    }
+
+    // one patch row `pr` of source s / channel offset c0 -> registers
+    auto patch_row_load = [&](int pr, int s, int c0, uint4 (&regs)[A_SLOTS]) {
+        const falnet_src_t& S = p.src[s];
+        int vy = ty0 - 1 + pr;
+        const bool rowok = pr < PT_TH + 2 && vy >= 0 && vy < p.IH;
+        if (S.H != p.IH) vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
+        const T* base = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + (int64_t)vy * S.sy + c0;
+#pragma unroll
+        for (int u = 0; u < A_SLOTS; ++u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int go = a_goff[u][s];
+            if (rowok && go >= 0) v = *reinterpret_cast<const uint4*>(base + go);
+            regs[u] = v;
+        }
+    };
+    auto patch_row_store = [&](char* A, int pr, const uint4 (&regs)[A_SLOTS]) {
+        if (pr < PT_TH + 2) {
+#pragma unroll
+            for (int u = 0; u < A_SLOTS; ++u)
+                if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(A + pr * (PT_PW * PITCH) + a_lds[u]) = regs[u];
+        }
+    };
+    auto w_tile_load = [&](int tap, int kofs, uint4 (&regs)[B_SLOTS]) {
+        const T* base = reinterpret_cast<const T*>(p.weight) + (int64_t)p.tap_w[tap] * p.cin_total + kofs;
+#pragma unroll
+        for (int u = 0; u < B_SLOTS; ++u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b_lds[u] >= 0) v = *reinterpret_cast<const uint4*>(base + b_goff[u]);
+            regs[u] = v;
+        }
+    };
+    auto w_tile_store = [&](char* B, const uint4 (&regs)[B_SLOTS]) {
+#pragma unroll
+        for (int u = 0; u < B_SLOTS; ++u) {
+            if (b_lds[u] >= 0) *reinterpret_cast<uint4*>(B + b_lds[u]) = regs[u];
+            else if (b_lds[u] < -1) *reinterpret_cast<uint4*>(B + (-2 - b_lds[u])) = make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+
+    const int a_lane = (wm * MT + 1) * PT_PW + (r + 1);  // patch pixel of (first row of this wave, lane column), tap (0,0)
+    const int b_lane = (wn * WTN + r) * PITCH;
+    auto compute_tap = [&](const char* A, const char* Btile, int t) {
+        const int doff = (p.tap_dy[t] * PT_PW + p.tap_dx[t]) * PITCH;  // wave-uniform
+        const char* arow[MT];
+        const char* brow[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (a_lane + mt * PT_PW) * PITCH + doff;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) brow[nt] = Btile + b_lane + nt * 32 * PITCH;
+        mma_rows<T, KCB, MT, NT, false>(arow, brow, h, acc);
+    };
+
+    // K walk over chunks: (source, channel offset, packed-weight offset)
+    int s_ = 0, c0_ = 0, kofs_ = 0;
+    auto advance = [&](int& s, int& c0, int& kofs) {
+        c0 += KCV;
+        kofs += KCV;
+        if (c0 >= p.src[s].C) {
+            c0 = 0;
+            ++s;
+        }
+    };
+    auto load_whole_patch = [&](char* A, int s, int c0) {
+        for (int pr = 0; pr < PT_TH + 2; ++pr) {
+            uint4 regs[A_SLOTS];
+            patch_row_load(pr, s, c0, regs);
+            patch_row_store(A, pr, regs);
+        }
+    };
+
+    if constexpr (!PIPE) {
+        for (int c = 0; c < nchunks; ++c) {
+            if (c > 0) __syncthreads();
+            load_whole_patch(Abuf(0), s_, c0_);
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) {
+                uint4 regs[B_SLOTS];
+                w_tile_load(tt, kofs_, regs);
+                w_tile_store(Bbuf(0) + tt * BN * PITCH, regs);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) compute_tap(Abuf(0), Bbuf(0) + tt * BN * PITCH, tt);
+            advance(s_, c0_, kofs_);
+        }
+    } else {
+        // prologue: patch of chunk 0 and the weight tile of (chunk 0, tap 0)
+        load_whole_patch(Abuf(0), s_, c0_);
+        {
+            uint4 regs[B_SLOTS];
+            w_tile_load(0, kofs_, regs);
+            w_tile_store(Bbuf(0), regs);
+        }
+        __syncthreads();
+        int sn = s_, c0n = c0_, kofsn = kofs_;  // next chunk
+        advance(sn, c0n, kofsn);
+        const int niter = nchunks * 9;
+        int c = 0, g = 0;
+        for (int it = 0; it < niter; ++it) {
+            const bool more = it + 1 < niter;
+            const bool next_chunk = ADB && (c + 1 < nchunks);
+            uint4 breg[B_SLOTS], areg0[A_SLOTS], areg1[A_SLOTS];
+            if (more) w_tile_load(g == 8 ? 0 : g + 1, g == 8 ? kofsn : kofs_, breg);
+            if (next_chunk) {  // 10 patch rows over 9 taps: tap g brings row g, tap 8 also row 9
+                patch_row_load(g, sn, c0n, areg0);
+                if (g == 8) patch_row_load(9, sn, c0n, areg1);
+            }
+            compute_tap(Abuf(c & 1), Bbuf(it & 1), g);
+            if (more) w_tile_store(Bbuf((it + 1) & 1), breg);
+            if (next_chunk) {
+                patch_row_store(Abuf((c + 1) & 1), g, areg0);
+                if (g == 8) patch_row_store(Abuf((c + 1) & 1), 9, areg1);
+            }
+            __syncthreads();
+            if (++g == 9) {
+                g = 0;
+                ++c;
+                s_ = sn;
+                c0_ = c0n;
+                kofs_ = kofsn;
+                advance(sn, c0n, kofsn);
+            }
+        }
+    }
+
+    // ---- epilogue (same contract as the gather kernel): per-wave LDS staging, 16-B stores ----
+    __syncthreads();  // every wave is done with the A/B buffers
+    {
+        float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
+        static_assert(4 * 32 * (NT * 32 + 4) * 4 <= (ADB ? 2 : 1) * A_BYTES + (PIPE ? 2 : 1) * B_BYTES, "staging must fit in the LDS buffers");
+        const int cstride = p.out_cstride;
+        epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, [&](int mt, int row) -> int64_t {
+            const int y = ty0 + wm * MT + mt, x = tx0 + row;
+            return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
+        });
     }
 }
 
@@ -478,6 +828,19 @@ static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t s
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, 32, SWAP>), grid, dim3(CONV_THREADS), 0, st, p);
 }
 
+// A/B switch for tests and profiling: FALNET_DISABLE_PATCH=1 routes every launch to the gather kernel
+static bool g_disable_patch = [] { const char* e = getenv("FALNET_DISABLE_PATCH"); return e && e[0] == '1'; }();
+// K bytes per chunk of the pipelined patch kernel: 128 (1 workgroup/CU), 64 (2 workgroups/CU), 0 = mode S only
+static int g_patch_kcb = [] { const char* e = getenv("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
+
+// tuning/profiling switches (tools/bench_conv.py); not part of the product path
+extern "C" int falnet_debug_set(int key, int value) {
+    if (key == 0) g_disable_patch = value != 0;
+    else if (key == 1) g_patch_kcb = value;
+    else return -1;
+    return 0;
+}
+
 extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG(pp, "conv2d: null descriptor");
     const falnet_conv_t& p = *pp;
@@ -497,10 +860,66 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");
+    hipStream_t st = (hipStream_t)stream;
+    // ---- kernel variant: 0 heuristic, 1 gather, 2 patch/128-B chunks, 3 patch/64-B chunks, 4 patch mode S ----
+    bool dense3x3 = !planar && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
+                    p.TH == p.OH && p.TW == p.OW && p.TH == p.IH && p.TW == p.IW && p.TW >= 16;
+    for (int t = 0; t < p.ntaps && dense3x3; ++t) dense3x3 = p.tap_dy[t] >= -1 && p.tap_dy[t] <= 1 && p.tap_dx[t] >= -1 && p.tap_dx[t] <= 1;
+    const int esz = p.dtype == FALNET_BF16 ? 2 : 4;
+    bool c128 = true;  // every source is a whole number of 128-B channel chunks
+    for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
+    int variant = p.variant;
+    if (g_disable_patch) variant = 1;
+    FALNET_CHECK_ARG(variant >= 0 && variant <= 4, "conv2d: unknown variant %d", variant);
+    if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || (variant == 3 && ctot / (64 / esz) < 2))) {
+        falnet_set_error("conv2d: variant %d not applicable to this launch", variant);
+        return -2;
+    }
+    if (variant == 0) {
+        if (!dense3x3 || p.TW < 32) variant = 1;
+        else if (c128 && g_patch_kcb == 128) variant = 2;
+        else if (ctot / (64 / esz) >= 2 && g_patch_kcb != 0) variant = 3;
+        else variant = 4;
+    }
+    if (variant >= 2) {
+        const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + PT_TH - 1) / PT_TH;
+        const unsigned gx = (unsigned)(p.B * tiles_x * tiles_y);
+        const bool bn128 = p.w_rows % 128 == 0 && p.Cout > 64 && gx >= 256;
+        const bool bn64 = p.w_rows % 64 == 0 && p.Cout > 32;
+        const bool multi = ctot / (128 / esz) > 1;
+#define LAUNCH_PATCH(T, BN, KCB, TPS, ADB)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_patch_kernel<T, BN, KCB, TPS, ADB>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)), \
+                       dim3(CONV_THREADS), 0, st, p, tiles_x, tiles_y)
+#define DISPATCH_PATCH(T)                                                                        \
+    do {                                                                                         \
+        if (variant == 2) {                                                                      \
+            if (multi) {                                                                         \
+                if (bn128) LAUNCH_PATCH(T, 128, 128, 1, true);                                   \
+                else if (bn64) LAUNCH_PATCH(T, 64, 128, 1, true);                                \
+                else LAUNCH_PATCH(T, 32, 128, 1, true);                                          \
+            } else {                                                                             \
+                if (bn128) LAUNCH_PATCH(T, 128, 128, 1, false);                                  \
+                else if (bn64) LAUNCH_PATCH(T, 64, 128, 1, false);                               \
+                else LAUNCH_PATCH(T, 32, 128, 1, false);                                         \
+            }                                                                                    \
+        } else if (variant == 3) {                                                               \
+            if (bn128) LAUNCH_PATCH(T, 128, 64, 1, true);                                        \
+            else if (bn64) LAUNCH_PATCH(T, 64, 64, 1, true);                                     \
+            else LAUNCH_PATCH(T, 32, 64, 1, true);                                               \
+        } else {                                                                                 \
+            if (bn64) LAUNCH_PATCH(T, 64, 64, 9, false);                                         \
+            else LAUNCH_PATCH(T, 32, 64, 9, false);                                              \
+        }                                                                                        \
+    } while (0)
+        if (p.dtype == FALNET_BF16) DISPATCH_PATCH(bf16_t);
+        else DISPATCH_PATCH(float);
+#undef DISPATCH_PATCH
+#undef LAUNCH_PATCH
+        FALNET_RETURN_LAUNCH();
+    }
     const int bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (p.w_rows % 64 == 0 && p.Cout > 32 ? 64 : 32);
     const int64_t M = (int64_t)p.B * p.TH * p.TW;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn));
-    hipStream_t st = (hipStream_t)stream;
     if (p.dtype == FALNET_BF16) {
         if (planar) launch_conv<bf16_t, true>(p, bn, grid, st);
         else launch_conv<bf16_t, false>(p, bn, grid, st);

@@ -6,6 +6,7 @@ network is turned once into a static *plan* (a list of launches over pre-allocat
 step is just that list replayed -- no per-step allocation, no Python tensor math on the hot path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -16,6 +17,9 @@ CPAD = L.CPAD
 # Optional launch timer (bench.py / profiling): object with run(tag, flops, bytes, launch).  None on the
 # product path: launches are then plain C-ABI calls.
 TIMER = None
+# Plan-build-time kernel selection: every conv launch tries the applicable kernel variants a few times on its
+# own (scratch) buffers and keeps the fastest (static plan => decided once).  FALNET_AUTOTUNE=0 disables.
+AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 
 
 def _timed(tag, flops, nbytes, launch):
@@ -29,10 +33,13 @@ def _timed(tag, flops, nbytes, launch):
     return call
 
 
-def conv_kernel_tag(dtype, w_rows, Cout, planar):
-    """Name of the conv_igemm_kernel instantiation falnet_conv2d dispatches to (conv.hip: falnet_conv2d)."""
+def conv_kernel_tag(dtype, w_rows, Cout, planar, variant=1):
+    """Kernel family falnet_conv2d dispatches to (conv.hip: falnet_conv2d), for the bench's per-family totals."""
+    dn = 'bf16' if dtype == torch.bfloat16 else 'f32'
+    if variant >= 2:
+        return f"conv3x3_patch_kernel<{dn},{ {2: 'kcb128', 3: 'kcb64', 4: 'single-stage'}[variant]}>"
     bn = 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
-    return f"conv_igemm_kernel<{'bf16' if dtype == torch.bfloat16 else 'f32'},{bn},{'planar' if planar else 'nhwc'}>"
+    return f"conv_igemm_kernel<{dn},{bn},{'planar' if planar else 'nhwc'}>"
 
 
 def pad_c(c):
@@ -162,12 +169,36 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.actout = 0 if actout is None else actout.data_ptr()
     d.actout_kind = actout_kind
     d.dtype = L.dtype_code(dtype)
+    d.variant = 0
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout)
+    if AUTOTUNE and len(taps) == 9 and stride_in == 1 and out_layout == L.OUT_NHWC and out.is_cuda:
+        d.variant = _autotune_conv(lib, d, ref)
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
-    return _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32), flops, 0, launch)
+    call = _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32, d.variant), flops, 0, launch)
+    call.desc, call.ref = d, ref
+    return call
+
+
+def _autotune_conv(lib, d, ref, reps=3):
+    best, best_t = 0, None
+    st = L.stream_ptr()
+    for v in (1, 2, 3, 4):
+        d.variant = v
+        if lib.falnet_conv2d(ref, st) != 0:  # -2: variant not applicable to this launch
+            continue
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.falnet_conv2d(ref, st)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if best_t is None or t < best_t:
+            best, best_t = v, t
+    return best
 
 
 def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, ws, target_wgs=1536,

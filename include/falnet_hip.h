@@ -38,6 +38,9 @@ int falnet_version(void);
 const char* falnet_last_error(void);
 /* channel padding granule (elements) of NHWC tensors and packed weights: 32 for both dtypes */
 int falnet_channel_pad(int dtype);
+/* tuning switches for tools/bench_conv.py (kernel A/B inside one process): key 0 = force the gather conv
+ * kernel, key 1 = K bytes per chunk of the halo-patch kernel (128 / 64 / 0) */
+int falnet_debug_set(int key, int value);
 
 /* One input of a convolution: NHWC tensor (or a per-sample constant when sy = sx = 0). */
 typedef struct {
@@ -84,6 +87,8 @@ typedef struct {
     const void* actout;        /* NHWC like out: multiply by d act / d pre computed from the activation output */
     int32_t actout_kind;       /* FALNET_ACT_ELU / RELU / NONE */
     int32_t dtype;
+    int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
+                                  4 halo-patch single-stage; -2 is returned when the variant does not apply */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
 

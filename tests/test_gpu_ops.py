@@ -65,6 +65,17 @@ CONV_CASES = [
     (2, [64], 64, 8, 8, 1, 3, True, L.ACT_RELU, False),         # VGG style
     (1, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False),        # 1x1
 ]
+# W >= 32, dense 3x3 stride 1 -> the halo-patch kernel (conv.hip: conv3x3_patch_kernel), every instantiation
+PATCH_CASES = [
+    (2, [32], 32, 12, 40, 1, 3, True, L.ACT_ELU, True),         # mode S, BN=32, ragged tiles
+    (1, [64, 32], 49, 10, 70, 1, 3, False, L.ACT_NONE, False),  # mode S, BN=64, concat, Cout=49
+    (2, [64], 64, 9, 33, 1, 3, True, L.ACT_ELU, False),         # mode P single chunk (bf16) / two chunks (f32), BN=64
+    (1, [128], 256, 8, 64, 1, 3, True, L.ACT_ELU, False),       # mode P multi chunk, BN=64
+    (1, [128, 256], 256, 16, 32, 1, 3, True, L.ACT_ELU, False), # mode P, two sources
+    (2, [64], 128, 128, 256, 1, 3, True, L.ACT_RELU, False),    # BN=128 (>=256 tiles), single chunk in bf16
+    (2, [128], 128, 128, 256, 1, 3, False, L.ACT_ELU, True),    # BN=128, double-buffered patch
+    (1, [32], 96, 16, 48, 1, 3, False, L.ACT_NONE, False),      # Cout=96 (N=96 planes)
+]
 
 
 def _conv_inputs(case, seed=0):
@@ -90,7 +101,7 @@ def _ref_conv(case, xs, w, b, addend=None):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + PATCH_CASES)
 def test_conv_forward(case, dtype):
     B, groups, Cout, H, W, stride, k, bias, act, res = case
     xs, w, b = _conv_inputs(case)
@@ -134,7 +145,7 @@ def test_conv_planar_output(dtype):
 def test_conv_fused_upsample(dtype):
     """deconv: nearest resize to an arbitrary size then conv (FAL_netB.py:57-60), incl. non-x2 ratio."""
     g = torch.Generator().manual_seed(3)
-    for (h, w, IH, IW) in ((4, 6, 8, 12), (6, 12, 11, 23)):
+    for (h, w, IH, IW) in ((4, 6, 8, 12), (6, 12, 11, 23), (16, 24, 32, 48), (9, 20, 17, 39)):
         x = torch.randn(2, 64, h, w, generator=g)
         wt = torch.randn(32, 64, 3, 3, generator=g) * 0.06
         ref = F.elu(F.conv2d(F.interpolate(x, size=(IH, IW), mode="nearest"), wt, None, padding=1))
@@ -147,7 +158,7 @@ def test_conv_fused_upsample(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", CONV_CASES[:7])
+@pytest.mark.parametrize("case", CONV_CASES[:7] + PATCH_CASES[:5] + PATCH_CASES[7:])
 def test_conv_backward(case, dtype):
     """dgrad (per concat group, stride 1 and the 4 stride-2 parity launches) and wgrad/bias-grad vs autograd."""
     B, groups, Cout, H, W, stride, k, bias, act, res = case

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of the conv kernels (forward launches of the hot layers of FAL_netB / VGG19 at
+B=8, 256x512): interleaved rounds of the kernel variants inside ONE process (cdna guide rule 24), HIP-event
+timing, algorithmic TFLOP/s.  Tuning tool only."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from fal_net_amd import _lib as L, ops
+
+DEV = "cuda"
+dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+B = 8
+LAYERS = [  # name, groups, Cout, H, W, upsample_from
+    ("conv0_1 32->32 @256x512", [32], 32, 256, 512, None),
+    ("deconv1 64->64 @256x512 (up)", [64], 64, 256, 512, (128, 256)),
+    ("iconv1 64+32->49 @256x512", [64, 32], 49, 256, 512, None),
+    ("vgg 64->64 @256x512", [64], 64, 256, 512, None),
+    ("conv1_1 64->64 @128x256", [64], 64, 128, 256, None),
+    ("iconv2 64+64->64 @128x256", [64, 64], 64, 128, 256, None),
+    ("vgg 128->128 @128x256", [128], 128, 128, 256, None),
+    ("conv2_1 128->128 @64x128", [128], 128, 64, 128, None),
+    ("vgg 256->256 @64x128", [256], 256, 64, 128, None),
+    ("conv3_1 256->256 @32x64", [256], 256, 32, 64, None),
+    ("iconv4 128+256->256 @32x64", [128, 256], 256, 32, 64, None),
+    ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
+]
+VARIANTS = [("gather", 1), ("patch128", 2), ("patch64", 3), ("modeS", 4)]
+lib = L.lib()
+for name, groups, cout, H, W, up in LAYERS:
+    cin = sum(groups)
+    w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=DEV) * 0.05)
+    pc = ops.PackedConv("t", w, None, groups, 1)
+    pc.alloc(dtype, torch.device(DEV))
+    pc.pack_call()()
+    srcs_t = []
+    for g in groups:
+        h, ww = up if up else (H, W)
+        srcs_t.append(torch.randn(B, h, ww, ops.pad_c(g), device=DEV).to(dtype))
+    out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
+    ops.AUTOTUNE = False
+    call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
+                         H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU)
+    flops = 2.0 * B * H * W * cout * cin * 9
+    times = {v: [] for v, _ in VARIANTS}
+    ref = None
+    for rnd in range(6):
+        for v, var in VARIANTS:
+            call.desc.variant = var
+            if lib.falnet_conv2d(call.ref, L.stream_ptr()) != 0:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd > 0:
+                times[v].append(e0.elapsed_time(e1) / 5)
+            if rnd == 0:
+                if ref is None:
+                    ref = out.float().clone()
+                else:
+                    assert float((out.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), (name, v)
+    line = f"{name:34s}"
+    for v, _ in VARIANTS:
+        if not times[v]:
+            line += f" | {v}     n/a            "
+            continue
+        t = sorted(times[v])[len(times[v]) // 2]
+        line += f" | {v} {t*1e3:7.1f}us {flops/t/1e9:7.1f}TF"
+    print(line, flush=True)
