@@ -754,19 +754,231 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_
     }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, halo-patch form
+// Dense 3x3 stride-1 layers (the bulk of the weight-gradient FLOPs): a workgroup owns a 32x32 (cout x cin)
+// channel block for ALL nine taps and walks a range of 4x32-position patches.  Per patch the gout rows
+// [128 px][32 cout] and the input halo [6x34 px][32 cin] are staged ONCE in LDS (the per-tap kernel re-read both
+// nine times); wave w contracts image row w of the patch (K = 32 positions) into its nine 32x32 accumulators,
+// operands read transposed (bf16: ds_read_b64_tr_b16) as in wgrad_kernel.  The four waves' accumulators are
+// summed through LDS at the end and the workgroup writes ONE f32 slab [9][32][32] into
+// partial[split][tap][co][ci].  Next patch is prefetched into registers behind the MFMAs.
+#define WP_TH 4
+#define WP_TW 32
+#define WP_PW (WP_TW + 2)
+#define WP_NPIX ((WP_TH + 2) * WP_PW)
+
+template <typename T>
+__global__ __launch_bounds__(CONV_THREADS) void wgrad3x3_patch_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+                                                                      int patches_per_split) {
+    constexpr int EPS = 16 / (int)sizeof(T);
+    constexpr int ROWB_ = 32 * (int)sizeof(T);      // bytes of 32 channels
+    constexpr int SEGS = ROWB_ / 16;                // 4 (bf16) / 8 (f32)
+    constexpr int PITCH = ROWB_ + 16;
+    constexpr int G_BYTES = WP_TH * WP_TW * PITCH, I_BYTES = WP_NPIX * PITCH;
+    constexpr int G_SLOTS = (WP_TH * WP_TW * SEGS + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int IROWL = WP_PW * SEGS;             // 16-B loads per halo row
+    constexpr int I_SLOTS = ((WP_TH + 2) * IROWL + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int STAGE_BYTES = 2 * (G_BYTES + I_BYTES);
+    constexpr int RED_BYTES = 9 * 16 * 64 * 4;      // one wave's accumulators
+    __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+    auto Gbuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES); };
+    auto Ibuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES) + G_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
+    const int c_first = p.src[0].C;
+    const int si = ci0 < c_first ? 0 : 1;
+    const falnet_src_t S = p.src[si];
+    const int cloc = ci0 < c_first ? ci0 : ci0 - c_first;
+    const bool ups = S.H != p.IH || S.W != p.IW;
+    const int npatch = p.B * tiles_x * tiles_y;
+    const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
+
+    // loop-invariant slot descriptors
+    int g_lds[G_SLOTS], g_col[G_SLOTS], g_row[G_SLOTS], g_seg[G_SLOTS];
+#pragma unroll
+    for (int u = 0; u < G_SLOTS; ++u) {
+        const int idx = tid + u * CONV_THREADS;
+        const int pix = idx / SEGS;
+        g_seg[u] = idx % SEGS;
+        g_row[u] = pix / WP_TW;
+        g_col[u] = pix % WP_TW;
+        g_lds[u] = idx < WP_TH * WP_TW * SEGS ? pix * PITCH + g_seg[u] * 16 : -1;
+    }
+    int i_lds[I_SLOTS], i_row[I_SLOTS], i_col[I_SLOTS], i_seg[I_SLOTS];
+#pragma unroll
+    for (int u = 0; u < I_SLOTS; ++u) {
+        const int idx = tid + u * CONV_THREADS;
+        const int pix = idx / SEGS;
+        i_seg[u] = idx % SEGS;
+        i_row[u] = pix / WP_PW;
+        i_col[u] = pix % WP_PW;
+        i_lds[u] = idx < WP_NPIX * SEGS ? pix * PITCH + i_seg[u] * 16 : -1;
+    }
+
+    uint4 greg[G_SLOTS], ireg[I_SLOTS];
+    auto gload = [&](int patch) {
+        int q = patch;
+        const int tix = q % tiles_x;
+        q /= tiles_x;
+        const int tiy = q % tiles_y;
+        const int b = q / tiles_y;
+        const int y0 = tiy * WP_TH, x0 = tix * WP_TW;
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int y = y0 + g_row[u], x = x0 + g_col[u];
+            if (g_lds[u] >= 0 && y < p.TH && x < p.TW && co0 + g_seg[u] * EPS < p.gC)
+                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)b * p.TH + y) * p.TW + x) * p.gC + co0 + g_seg[u] * EPS);
+            greg[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < I_SLOTS; ++u) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            int vy = y0 - 1 + i_row[u], vx = x0 - 1 + i_col[u];
+            if (i_lds[u] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) {
+                if (ups) {
+                    vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
+                    vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
+                }
+                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + (int64_t)vy * S.sy + (int64_t)vx * S.sx +
+                                                    cloc + i_seg[u] * EPS);
+            }
+            ireg[u] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u)
+            if (g_lds[u] >= 0) *reinterpret_cast<uint4*>(Gbuf(buf) + g_lds[u]) = greg[u];
+#pragma unroll
+        for (int u = 0; u < I_SLOTS; ++u)
+            if (i_lds[u] >= 0) *reinterpret_cast<uint4*>(Ibuf(buf) + i_lds[u]) = ireg[u];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    if (pbeg < pend) {
+        gload(pbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int patch = pbeg; patch < pend; ++patch) {
+        const int cur = (patch - pbeg) & 1;
+        if (patch + 1 < pend) gload(patch + 1);
+        const char* G = Gbuf(cur) + wave * WP_TW * PITCH;              // this wave's image row of gout
+        const char* I = Ibuf(cur);
+        if constexpr (sizeof(T) == 2) {
+            const int i16 = lane & 15, g16 = lane >> 4;
+            const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
+            typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+            const int col = (cb * 16 + pc * 4) * 2;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int krow = ks * 16 + kh * 8 + q;
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + krow * PITCH + col));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + (krow + 4) * PITCH + col));
+                const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int prow = (wave + 1 + p.tap_dy[t]) * WP_PW + 1 + p.tap_dx[t] + krow;
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + prow * PITCH + col));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + (prow + 4) * PITCH + col));
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        } else {
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll 4
+            for (int ks = 0; ks < 16; ++ks) {
+                const float a = *reinterpret_cast<const float*>(G + (ks * 2 + h) * PITCH + r * 4);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int prow = (wave + 1 + p.tap_dy[t]) * WP_PW + 1 + p.tap_dx[t] + ks * 2 + h;
+                    const float bb = *reinterpret_cast<const float*>(I + prow * PITCH + r * 4);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (patch + 1 < pend) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // sum the four waves' accumulators through LDS (staging buffers are dead now), wave 0 writes the slab
+    float* red = reinterpret_cast<float*>(lds);
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) red[(t * 16 + j) * 64 + lane] = acc[t][j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[t][j] += red[(t * 16 + j) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const int r = lane & 31, h = lane >> 5;
+        const int ci = ci0 + r;
+        if (ci < p.cin_total) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float* dst = p.partial + (((int64_t)split * 9 + t) * w_rows) * p.cin_total;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = co0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[t][j];
+                }
+            }
+        }
+    }
+}
+
 // partial [nsplit][ntaps][w_rows][cin_total] -> OIHW f32, un-padding the (possibly two-group) channel axis
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int ntaps,
                                                            int w_rows, int cin_total, float* __restrict__ grad, int cout,
-                                                           int cin, int c0_real, int c0_pad, int accumulate) {
-    const int64_t total = (int64_t)cout * cin * ntaps;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i % ntaps), ci = (int)((i / ntaps) % cin), co = (int)(i / ((int64_t)ntaps * cin));
-        const int cp = ci < c0_real ? ci : c0_pad + (ci - c0_real);
-        const int64_t slab = (int64_t)ntaps * w_rows * cin_total;
-        const float* src = partial + ((int64_t)t * w_rows + co) * cin_total + cp;
+                                                           int cin, int c0_real, int c0_pad, int use_atomics) {
+    // block = (output channel co, 64 packed input channels); blockIdx.z = slab group.  Reads are coalesced along
+    // the packed channel axis; the [tap][ci] -> [ci][tap] transposition goes through LDS so that the OIHW
+    // writes are contiguous runs of ntaps*64 floats.
+    __shared__ float tile[64 * 9];
+    const int co = blockIdx.x, cp0 = blockIdx.y * 64;
+    const int ngroups = gridDim.z, grp = blockIdx.z;
+    const int s0 = (int)((int64_t)nsplit * grp / ngroups), s1 = (int)((int64_t)nsplit * (grp + 1) / ngroups);
+    const int64_t slab = (int64_t)ntaps * w_rows * cin_total;
+    for (int e = threadIdx.x; e < ntaps * 64; e += blockDim.x) {
+        const int t = e / 64, cl = e % 64;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += src[k * slab];
-        grad[i] = accumulate ? grad[i] + s : s;
+        if (cp0 + cl < cin_total) {
+            const float* src = partial + ((int64_t)t * w_rows + co) * cin_total + cp0 + cl;
+            for (int k = s0; k < s1; ++k) s += src[k * slab];
+        }
+        tile[cl * ntaps + t] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ntaps * 64; e += blockDim.x) {
+        const int cl = e / ntaps, t = e % ntaps;
+        const int cp = cp0 + cl;
+        int ci = -1;
+        if (cp < c0_pad) {
+            if (cp < c0_real) ci = cp;
+        } else if (c0_real + (cp - c0_pad) < cin) {
+            ci = c0_real + (cp - c0_pad);
+        }
+        if (ci >= 0) {
+            float* dst = grad + ((int64_t)co * cin + ci) * ntaps + t;
+            if (use_atomics) atomicAdd(dst, tile[e]);
+            else *dst = tile[e];
+        }
     }
 }
 
@@ -951,6 +1163,20 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     FALNET_CHECK_ARG(p.gout && p.partial && p.gC > 0 && p.gC % 32 == 0 && p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= 9, "wgrad: bad argument");
     FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0, "wgrad: empty shape");
     const int w_rows = round32(p.gC);
+    // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
+    bool dense = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
+    for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] >= -1 && p.tap_dy[t] <= 1 && p.tap_dx[t] >= -1 && p.tap_dx[t] <= 1;
+    if (dense) {
+        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
+        const int npatch = p.B * tiles_x * tiles_y;
+        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
+        const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
+        if (p.dtype == FALNET_BF16)
+            hipLaunchKernelGGL(wgrad3x3_patch_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+        else
+            hipLaunchKernelGGL(wgrad3x3_patch_kernel<float>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+        FALNET_RETURN_LAUNCH();
+    }
     const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);
     if (p.dtype == FALNET_BF16)
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows);
@@ -961,12 +1187,20 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
 
 extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pad, int cin_total, float* grad,
                                    int cout, int cin, int c0_real, int c0_pad, int accumulate, void* stream) {
-    FALNET_CHECK_ARG(partial && grad && nsplit >= 1 && ntaps >= 1 && cout > 0 && cin > 0 && cout <= cout_pad, "wgrad_reduce: bad argument");
+    FALNET_CHECK_ARG(partial && grad && nsplit >= 1 && ntaps >= 1 && ntaps <= 9 && cout > 0 && cin > 0 && cout <= cout_pad, "wgrad_reduce: bad argument");
     FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_total, "wgrad_reduce: channel groups do not fit");
-    const int64_t total = (int64_t)cout * cin * ntaps;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, nsplit, ntaps, cout_pad,
-                       cin_total, grad, cout, cin, c0_real, c0_pad, accumulate);
+    // slab groups: enough blocks to fill the chip when the weight tensor is small and the slab count large
+    const int blocks = cout * ((cin_total + 63) / 64);
+    int groups = 1;
+    if (nsplit >= 16 && blocks < 1024) groups = (1024 + blocks - 1) / blocks;
+    if (groups > nsplit / 8) groups = nsplit / 8 > 0 ? nsplit / 8 : 1;
+    const int use_atomics = (groups > 1 || accumulate) ? 1 : 0;
+    if (groups > 1 && !accumulate) {
+        hipError_t e = hipMemsetAsync(grad, 0, sizeof(float) * (size_t)cout * cin * ntaps, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cout, (cin_total + 63) / 64, groups), dim3(256), 0, (hipStream_t)stream, partial,
+                       nsplit, ntaps, cout_pad, cin_total, grad, cout, cin, c0_real, c0_pad, use_atomics);
     FALNET_RETURN_LAUNCH();
 }
 

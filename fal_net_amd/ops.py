@@ -218,13 +218,20 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     d.B, d.TH, d.TW = B, TH, TW
     d.cin_total = pc.cin_pad
     M = B * TH * TW
-    tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
-    nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
     slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
+    dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
+    if dense:
+        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32)
+        npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+        nsplit = max(1, min((768 + tiles - 1) // tiles, npatch))
+    else:
+        tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
+        nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
     nsplit = max(1, min(nsplit, ws.numel() * 4 // slab))
     d.nsplit = nsplit
     d.partial = ws.data_ptr()
     d.dtype = L.dtype_code(dtype)
+    d.variant = 0
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
     c0_real, c0_pad = pc.group_channels()
@@ -243,7 +250,7 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
         if grad_b is not None:
             L.check(lib.falnet_bias_grad(L.ptr(gout), npix, gC, pc.cout, L.ptr(grad_b), int(accumulate),
                                          L.dtype_code(dtype), st), name + " bias")
-    t_wgrad = _timed(f"wgrad_kernel<{dname}>", flops, 0, k_wgrad)
+    t_wgrad = _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, k_wgrad)
     t_reduce = _timed("wgrad_reduce+bias_grad", 0, 0, k_reduce)
 
     def call(accumulate=0):

@@ -114,6 +114,7 @@ typedef struct {
     int32_t nsplit;
     float* partial;            /* workspace */
     int32_t dtype;
+    int32_t variant;           /* 0 heuristic, 1 force the per-tap kernel */
 } falnet_wgrad_t;
 int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p);
 int falnet_wgrad(const falnet_wgrad_t* p, void* stream);
