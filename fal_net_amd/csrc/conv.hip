@@ -227,11 +227,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
         }
     }
 
-    int niter = 0;
-    for (int s = 0; s < p.nsrc; ++s) niter += p.ntaps * (p.src[s].C / KCV);
+    int niter_all = 0;
+    for (int s = 0; s < p.nsrc; ++s) niter_all += p.ntaps * (p.src[s].C / KCV);
+    // split-K: blockIdx.z owns K iterations [it0, it1); partial sums go to an f32 workspace with atomics
+    const int it0 = (int)((int64_t)niter_all * blockIdx.z / gridDim.z), it1 = (int)((int64_t)niter_all * (blockIdx.z + 1) / gridDim.z);
+    const int niter = it1 - it0;
 
     // K-walk state: source s, tap t, channel offset c0; srcoff = packed-weight offset of source s
     int s_ = 0, t_ = 0, c0_ = 0, srcoff_ = 0;
+    for (int i = 0; i < it0; ++i) {  // fast-forward to this split's first iteration (scalar, <= a few hundred steps)
+        c0_ += KCV;
+        if (c0_ >= p.src[s_].C) {
+            c0_ = 0;
+            if (++t_ >= p.ntaps) {
+                t_ = 0;
+                srcoff_ += p.src[s_].C;
+                ++s_;
+            }
+        }
+    }
     uint4 areg[A_LOADS], breg[B_LOADS];
 
     auto gload = [&]() {
@@ -299,8 +313,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
-    gload();
-    lstore(0);
+    if (niter > 0) {
+        gload();
+        lstore(0);
+    }
     __syncthreads();
     for (int it = 0; it < niter; ++it) {
         const int cur = it & 1;
@@ -312,6 +328,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
 
     // ---- epilogue: v = act(acc + bias + addend) * act'(actout) ----
     const int r = lane & 31, h = lane >> 5;
+    if (gridDim.z > 1) {
+        // split-K partial: raw accumulators into ws[m][n] (f32 atomics: 32 lanes = 128 contiguous bytes per row)
+        if constexpr (!SWAP) {
+            float* ws = p.splitk_ws;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + wn * WTN + nt * 32 + r;
+                if (n >= p.w_rows) continue;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int64_t m = m0 + wm * WTM + mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                        if (m < M) atomicAdd(ws + m * p.w_rows + n, acc[mt][nt][j]);
+                    }
+            }
+        }
+        return;
+    }
     if constexpr (!SWAP) {
         // outpix lives behind the A/B buffers; the dead A/B area becomes the per-wave staging slabs
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
@@ -341,6 +376,44 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
                     out[(int64_t)o + (int64_t)n * plane] = v;
                 }
         }
+    }
+}
+
+// split-K epilogue: ws[m][n] (f32 sums) -> bias / residual / activation / activation-gradient -> NHWC output
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_t p) {
+    const int segs = p.Cout / 8;
+    const int64_t M = (int64_t)p.B * p.TH * p.TW;
+    const int64_t total = M * segs;
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int seg = (int)(i % segs);
+        const int64_t m = i / segs;
+        const int tx = (int)(m % p.TW), ty = (int)((m / p.TW) % p.TH), b = (int)(m / ((int64_t)p.TW * p.TH));
+        const int oy = ty * p.osy + p.ooy, ox = tx * p.osx + p.oox;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        const int n = seg * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(p.splitk_ws + m * p.w_rows + n);
+        const float4 x1 = *reinterpret_cast<const float4*>(p.splitk_ws + m * p.w_rows + n + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const int64_t off = (((int64_t)b * p.OH + oy) * p.OW + ox) * p.out_cstride + n;
+        Vec8<T> t;
+        if (addend) {
+            t.load(addend + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += t.get(k);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k] + (p.bias ? p.bias[n + k] : 0.f), p.act);
+        if (actout) {
+            t.load(actout + off);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= act_grad_from_out(t.get(k), p.actout_kind);
+        }
+        t.set8(v);
+        t.store(out + off);
     }
 }
 
@@ -982,23 +1055,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// db[c] += sum_p g[p, c];  blockIdx.y walks 256-channel chunks, threads = (pixel row group, channel)
+// db[c] += sum_p g[p, c]: every thread owns one 8-channel segment (16-B bf16 / 32-B f32 loads) and strides over
+// pixels; rows of threads are summed through LDS, one atomic per channel per block.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g, int64_t npix, int gC, int cout,
                                                         float* __restrict__ db) {
-    __shared__ float red[256];
-    const int cw = gC < 256 ? gC : 256;         // channels handled per block (gC % 32 == 0, so 256 % cw == 0 or cw == 256)
-    const int rows = 256 / cw;
-    const int cl = threadIdx.x % cw, rr = threadIdx.x / cw;
-    const int c = blockIdx.y * 256 + cl;
-    float acc = 0.f;
-    if (c < gC)
-        for (int64_t pix = (int64_t)blockIdx.x * rows + rr; pix < npix; pix += (int64_t)gridDim.x * rows) acc += to_f32(g[pix * gC + c]);
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (rr == 0) {
-        for (int k = 1; k < rows; ++k) acc += red[k * cw + cl];
-        if (c < cout) atomicAdd(db + c, acc);
+    __shared__ float red[256 * 8];
+    const int segs = gC / 8;                       // gC is a multiple of 32
+    const int spb = segs < 256 ? segs : 256;       // segments handled per block pass
+    const int rows = 256 / spb;
+    const int sl = threadIdx.x % spb, rr = threadIdx.x / spb;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int seg = blockIdx.y * spb + sl; seg < segs; seg += gridDim.y * spb) {
+        for (int64_t pix = (int64_t)blockIdx.x * rows + rr; pix < npix; pix += (int64_t)gridDim.x * rows) {
+            Vec8<T> v;
+            v.load(g + pix * gC + seg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v.get(i);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+        __syncthreads();
+        if (rr == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = 0.f;
+                for (int k = 0; k < rows; ++k) t += red[(k * spb + sl) * 8 + i];
+                if (seg * 8 + i < cout) atomicAdd(db + seg * 8 + i, t);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     }
 }
 
@@ -1131,13 +1219,26 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     }
     const int bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (p.w_rows % 64 == 0 && p.Cout > 32 ? 64 : 32);
     const int64_t M = (int64_t)p.B * p.TH * p.TW;
-    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn));
+    int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    if (ksplit > 1) {
+        FALNET_CHECK_ARG(!planar && p.splitk_ws && p.Cout % 8 == 0, "conv2d: split-K needs an NHWC output and a workspace");
+        FALNET_CHECK_ARG(M * p.w_rows * 4 <= p.splitk_ws_bytes, "conv2d: split-K workspace too small (%lld needed)", (long long)(M * p.w_rows * 4));
+        hipError_t e = hipMemsetAsync(p.splitk_ws, 0, (size_t)(M * p.w_rows * 4), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn), (unsigned)ksplit);
     if (p.dtype == FALNET_BF16) {
         if (planar) launch_conv<bf16_t, true>(p, bn, grid, st);
         else launch_conv<bf16_t, false>(p, bn, grid, st);
     } else {
         if (planar) launch_conv<float, true>(p, bn, grid, st);
         else launch_conv<float, false>(p, bn, grid, st);
+    }
+    if (ksplit > 1) {
+        const int64_t total = M * (p.Cout / 8);
+        const unsigned eg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        if (p.dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(eg), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(eg), dim3(256), 0, st, p);
     }
     FALNET_RETURN_LAUNCH();
 }
@@ -1207,15 +1308,15 @@ extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, 
 extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db, int accumulate, int dtype,
                                 void* stream) {
     FALNET_CHECK_ARG(g && db && npix > 0 && cout > 0 && cout <= gC, "bias_grad: bad argument");
-    FALNET_CHECK_ARG(gC % 32 == 0 && (gC >= 256 ? gC % 256 == 0 : 256 % gC == 0), "bias_grad: unsupported channel count %d", gC);
+    FALNET_CHECK_ARG(gC % 32 == 0 && gC <= 2048, "bias_grad: unsupported channel count %d", gC);
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * cout, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    const int rows = gC < 256 ? 256 / gC : 1;
-    int64_t gx = (npix + rows * 64 - 1) / (rows * 64);
-    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
-    const dim3 grid((unsigned)gx, (unsigned)((gC + 255) / 256));
+    const int segs = gC / 8, spb = segs < 256 ? segs : 256, rows = 256 / spb;
+    int64_t gx = (npix + rows * 16 - 1) / (rows * 16);
+    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    const dim3 grid((unsigned)gx, 1);
     if (dtype == FALNET_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, npix, gC, cout, db);
     else

@@ -170,10 +170,14 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.actout_kind = actout_kind
     d.dtype = L.dtype_code(dtype)
     d.variant = 0
+    d.ksplit = 1
+    ws = _splitk_workspace(out.device) if out.is_cuda and out_layout == L.OUT_NHWC else None
+    d.splitk_ws = 0 if ws is None else ws.data_ptr()
+    d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
     ref = C.byref(d)
-    keep = (d, srcs, weight, out, bias, addend, actout)
-    if AUTOTUNE and len(taps) == 9 and stride_in == 1 and out_layout == L.OUT_NHWC and out.is_cuda:
-        d.variant = _autotune_conv(lib, d, ref)
+    keep = (d, srcs, weight, out, bias, addend, actout, ws)
+    if AUTOTUNE and out_layout == L.OUT_NHWC and out.is_cuda:
+        d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
@@ -182,11 +186,30 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     return call
 
 
-def _autotune_conv(lib, d, ref, reps=3):
-    best, best_t = 0, None
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, nbytes=32 << 20):
+    """Per-device f32 scratch shared by all split-K conv launches (they are stream-ordered)."""
+    key = (device.type, device.index)
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    return _SPLITK_WS[key]
+
+
+def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
+    """Fastest (variant, ksplit) for this launch.  Candidates: gather (with split-K when the launch would
+    otherwise occupy only a fraction of the 256 CUs), and the halo-patch variants where applicable."""
     st = L.stream_ptr()
-    for v in (1, 2, 3, 4):
-        d.variant = v
+    cands = [(1, 1)]
+    bn = 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
+    wgs = ((M + 127) // 128) * ((Cout + bn - 1) // bn)
+    if wgs < 256 and M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
+        cands += [(1, k) for k in (2, 4, 8, 16) if wgs * k <= 2048]
+    cands += [(2, 1), (3, 1), (4, 1)]
+    best, best_t = (1, 1), None
+    for v, k in cands:
+        d.variant, d.ksplit = v, k
         if lib.falnet_conv2d(ref, st) != 0:  # -2: variant not applicable to this launch
             continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,7 +220,7 @@ def _autotune_conv(lib, d, ref, reps=3):
         e1.synchronize()
         t = e0.elapsed_time(e1)
         if best_t is None or t < best_t:
-            best, best_t = v, t
+            best, best_t = (v, k), t
     return best
 
 

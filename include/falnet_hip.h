@@ -87,6 +87,10 @@ typedef struct {
     const void* actout;        /* NHWC like out: multiply by d act / d pre computed from the activation output */
     int32_t actout_kind;       /* FALNET_ACT_ELU / RELU / NONE */
     int32_t dtype;
+    int32_t ksplit;            /* gather kernel only: > 1 splits the K loop over blockIdx.z (f32 atomics into
+                                  splitk_ws [B*TH*TW][w_rows], then an epilogue launch); for small-M layers */
+    float* splitk_ws;
+    int64_t splitk_ws_bytes;
     int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
                                   4 halo-patch single-stage; -2 is returned when the variant does not apply */
 } falnet_conv_t;
