@@ -471,7 +471,10 @@ __device__ __forceinline__ void mma_rows(const char* const (&arow)[MT], const ch
 #define PT_NPIX ((PT_TH + 2) * PT_PW)
 
 template <typename T, int BN, int KCB, int TPS, bool ADB>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falnet_conv_t p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
+    // Taps are walked in spatial order t = (dy+1)*3 + (dx+1) with COMPILE-TIME offsets (the 9-tap loops are fully
+    // unrolled, so every LDS address below is lane base + immediate); the packed-weight tap of spatial tap t is t
+    // for a forward launch and 8-t for a stride-1 dgrad (flip) -- checked by falnet_conv2d.
     constexpr int PITCH = KCB + 16;
     constexpr int SEGS = KCB / 16;
     constexpr int KCV = KCB / (int)sizeof(T);
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
         }
     };
     auto w_tile_load = [&](int tap, int kofs, uint4 (&regs)[B_SLOTS]) {
-        const T* base = reinterpret_cast<const T*>(p.weight) + (int64_t)p.tap_w[tap] * p.cin_total + kofs;
+        const T* base = reinterpret_cast<const T*>(p.weight) + (flip ? 8 - tap : tap) * p.cin_total + kofs;
 #pragma unroll
         for (int u = 0; u < B_SLOTS; ++u) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -595,14 +598,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
-    const int a_lane = (wm * MT + 1) * PT_PW + (r + 1);  // patch pixel of (first row of this wave, lane column), tap (0,0)
+    const int a_lane = ((wm * MT) * PT_PW + r) * PITCH;  // patch pixel of (first row of this wave, lane column) at tap (-1,-1)
     const int b_lane = (wn * WTN + r) * PITCH;
-    auto compute_tap = [&](const char* A, const char* Btile, int t) {
-        const int doff = (p.tap_dy[t] * PT_PW + p.tap_dx[t]) * PITCH;  // wave-uniform
+    auto compute_tap = [&](const char* A, const char* Btile, int t /* compile-time after unrolling */) {
+        const int doff = ((t / 3) * PT_PW + (t % 3)) * PITCH;
         const char* arow[MT];
         const char* brow[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) arow[mt] = A + (a_lane + mt * PT_PW) * PITCH + doff;
+        for (int mt = 0; mt < MT; ++mt) arow[mt] = A + a_lane + (mt * PT_PW * PITCH + doff);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) brow[nt] = Btile + b_lane + nt * 32 * PITCH;
         mma_rows<T, KCB, MT, NT, false>(arow, brow, h, acc);
@@ -613,9 +616,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     auto advance = [&](int& s, int& c0, int& kofs) {
         c0 += KCV;
         kofs += KCV;
-        if (c0 >= p.src[s].C) {
+        if (s < 2 && c0 >= p.src[s].C) {
             c0 = 0;
-            ++s;
+            s = s + 1 < p.nsrc ? s + 1 : s;
         }
     };
     auto load_whole_patch = [&](char* A, int s, int c0) {
@@ -652,32 +655,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
         __syncthreads();
         int sn = s_, c0n = c0_, kofsn = kofs_;  // next chunk
         advance(sn, c0n, kofsn);
-        const int niter = nchunks * 9;
-        int c = 0, g = 0;
-        for (int it = 0; it < niter; ++it) {
-            const bool more = it + 1 < niter;
+        for (int c = 0; c < nchunks; ++c) {
             const bool next_chunk = ADB && (c + 1 < nchunks);
-            uint4 breg[B_SLOTS], areg0[A_SLOTS], areg1[A_SLOTS];
-            if (more) w_tile_load(g == 8 ? 0 : g + 1, g == 8 ? kofsn : kofs_, breg);
-            if (next_chunk) {  // 10 patch rows over 9 taps: tap g brings row g, tap 8 also row 9
-                patch_row_load(g, sn, c0n, areg0);
-                if (g == 8) patch_row_load(9, sn, c0n, areg1);
+            const char* Acur = Abuf(c & 1);
+            char* Anext = Abuf((c + 1) & 1);
+#pragma unroll
+            for (int g = 0; g < 9; ++g) {
+                const bool more = g < 8 || c + 1 < nchunks;
+                uint4 breg[B_SLOTS], areg0[A_SLOTS], areg1[A_SLOTS];
+                if (more) w_tile_load(g == 8 ? 0 : g + 1, g == 8 ? kofsn : kofs_, breg);
+                if (next_chunk) {  // 10 patch rows over 9 taps: tap g brings row g, tap 8 also row 9
+                    patch_row_load(g, sn, c0n, areg0);
+                    if (g == 8) patch_row_load(9, sn, c0n, areg1);
+                }
+                compute_tap(Acur, Bbuf((c + g) & 1), g);
+                if (more) w_tile_store(Bbuf((c + g + 1) & 1), breg);
+                if (next_chunk) {
+                    patch_row_store(Anext, g, areg0);
+                    if (g == 8) patch_row_store(Anext, 9, areg1);
+                }
+                __syncthreads();
             }
-            compute_tap(Abuf(c & 1), Bbuf(it & 1), g);
-            if (more) w_tile_store(Bbuf((it + 1) & 1), breg);
-            if (next_chunk) {
-                patch_row_store(Abuf((c + 1) & 1), g, areg0);
-                if (g == 8) patch_row_store(Abuf((c + 1) & 1), 9, areg1);
-            }
-            __syncthreads();
-            if (++g == 9) {
-                g = 0;
-                ++c;
-                s_ = sn;
-                c0_ = c0n;
-                kofs_ = kofsn;
-                advance(sn, c0n, kofsn);
-            }
+            s_ = sn;
+            c0_ = c0n;
+            kofs_ = kofsn;
+            advance(sn, c0n, kofsn);
         }
     }
 
@@ -840,20 +842,21 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_
 #define WP_PW (WP_TW + 2)
 #define WP_NPIX ((WP_TH + 2) * WP_PW)
 
+#define WP_THREADS 192  // three waves: wave w owns the tap row dy = w-1 (taps 3w..3w+2)
+
 template <typename T>
-__global__ __launch_bounds__(CONV_THREADS) void wgrad3x3_patch_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
-                                                                      int patches_per_split) {
+__global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+                                                                    int patches_per_split) {
     constexpr int EPS = 16 / (int)sizeof(T);
     constexpr int ROWB_ = 32 * (int)sizeof(T);      // bytes of 32 channels
     constexpr int SEGS = ROWB_ / 16;                // 4 (bf16) / 8 (f32)
-    constexpr int PITCH = ROWB_ + 16;
+    // no row padding: a ds_read_b64_tr_b16 32-lane half reads 4 rows x 64 B = exactly the 64 banks once
+    constexpr int PITCH = ROWB_;
     constexpr int G_BYTES = WP_TH * WP_TW * PITCH, I_BYTES = WP_NPIX * PITCH;
-    constexpr int G_SLOTS = (WP_TH * WP_TW * SEGS + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int IROWL = WP_PW * SEGS;             // 16-B loads per halo row
-    constexpr int I_SLOTS = ((WP_TH + 2) * IROWL + CONV_THREADS - 1) / CONV_THREADS;
-    constexpr int STAGE_BYTES = 2 * (G_BYTES + I_BYTES);
-    constexpr int RED_BYTES = 9 * 16 * 64 * 4;      // one wave's accumulators
-    __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+    constexpr int G_LOADS = WP_TH * WP_TW * SEGS, I_LOADS = WP_NPIX * SEGS;
+    constexpr int G_SLOTS = (G_LOADS + WP_THREADS - 1) / WP_THREADS;
+    constexpr int I_SLOTS = (I_LOADS + WP_THREADS - 1) / WP_THREADS;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (G_BYTES + I_BYTES)];
     auto Gbuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES); };
     auto Ibuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES) + G_BYTES; };
 
@@ -867,26 +870,13 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad3x3_patch_kernel(const faln
     const int npatch = p.B * tiles_x * tiles_y;
     const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
 
-    // loop-invariant slot descriptors
-    int g_lds[G_SLOTS], g_col[G_SLOTS], g_row[G_SLOTS], g_seg[G_SLOTS];
-#pragma unroll
-    for (int u = 0; u < G_SLOTS; ++u) {
-        const int idx = tid + u * CONV_THREADS;
-        const int pix = idx / SEGS;
-        g_seg[u] = idx % SEGS;
-        g_row[u] = pix / WP_TW;
-        g_col[u] = pix % WP_TW;
-        g_lds[u] = idx < WP_TH * WP_TW * SEGS ? pix * PITCH + g_seg[u] * 16 : -1;
-    }
-    int i_lds[I_SLOTS], i_row[I_SLOTS], i_col[I_SLOTS], i_seg[I_SLOTS];
+    // halo slots: (row, col) of the 6x34 patch per slot (division by 34 hoisted out of the patch loop)
+    short i_row[I_SLOTS], i_col[I_SLOTS];
 #pragma unroll
     for (int u = 0; u < I_SLOTS; ++u) {
-        const int idx = tid + u * CONV_THREADS;
-        const int pix = idx / SEGS;
-        i_seg[u] = idx % SEGS;
-        i_row[u] = pix / WP_PW;
-        i_col[u] = pix % WP_PW;
-        i_lds[u] = idx < WP_NPIX * SEGS ? pix * PITCH + i_seg[u] * 16 : -1;
+        const int pix = (tid + u * WP_THREADS) / SEGS;
+        i_row[u] = (short)(pix / WP_PW);
+        i_col[u] = (short)(pix % WP_PW);
     }
 
     uint4 greg[G_SLOTS], ireg[I_SLOTS];
@@ -897,41 +887,50 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad3x3_patch_kernel(const faln
         const int tiy = q % tiles_y;
         const int b = q / tiles_y;
         const int y0 = tiy * WP_TH, x0 = tix * WP_TW;
+        const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC + co0;
 #pragma unroll
         for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            const int seg = idx % SEGS, pix = idx / SEGS;
+            const int y = y0 + pix / WP_TW, x = x0 + pix % WP_TW;  // WP_TW = 32: shifts
             uint4 v = make_uint4(0, 0, 0, 0);
-            const int y = y0 + g_row[u], x = x0 + g_col[u];
-            if (g_lds[u] >= 0 && y < p.TH && x < p.TW && co0 + g_seg[u] * EPS < p.gC)
-                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)b * p.TH + y) * p.TW + x) * p.gC + co0 + g_seg[u] * EPS);
+            if (idx < G_LOADS && y < p.TH && x < p.TW && co0 + seg * EPS < p.gC)
+                v = *reinterpret_cast<const uint4*>(gbase + ((int64_t)y * p.TW + x) * p.gC + seg * EPS);
             greg[u] = v;
         }
+        const T* ibase = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + cloc;
 #pragma unroll
         for (int u = 0; u < I_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            const int seg = idx % SEGS;
             uint4 v = make_uint4(0, 0, 0, 0);
             int vy = y0 - 1 + i_row[u], vx = x0 - 1 + i_col[u];
-            if (i_lds[u] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) {
+            if (idx < I_LOADS && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) {
                 if (ups) {
                     vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
                     vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
                 }
-                v = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + (int64_t)vy * S.sy + (int64_t)vx * S.sx +
-                                                    cloc + i_seg[u] * EPS);
+                v = *reinterpret_cast<const uint4*>(ibase + (int64_t)vy * S.sy + (int64_t)vx * S.sx + seg * EPS);
             }
             ireg[u] = v;
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < G_SLOTS; ++u)
-            if (g_lds[u] >= 0) *reinterpret_cast<uint4*>(Gbuf(buf) + g_lds[u]) = greg[u];
+        for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + idx * 16) = greg[u];   // pixel-major, unpadded: idx*16 B
+        }
 #pragma unroll
-        for (int u = 0; u < I_SLOTS; ++u)
-            if (i_lds[u] >= 0) *reinterpret_cast<uint4*>(Ibuf(buf) + i_lds[u]) = ireg[u];
+        for (int u = 0; u < I_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            if (idx < I_LOADS) *reinterpret_cast<uint4*>(Ibuf(buf) + idx * 16) = ireg[u];
+        }
     };
 
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
@@ -943,74 +942,58 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad3x3_patch_kernel(const faln
     for (int patch = pbeg; patch < pend; ++patch) {
         const int cur = (patch - pbeg) & 1;
         if (patch + 1 < pend) gload(patch + 1);
-        const char* G = Gbuf(cur) + wave * WP_TW * PITCH;              // this wave's image row of gout
-        const char* I = Ibuf(cur);
+        const char* G = Gbuf(cur);
+        const char* I = Ibuf(cur) + wave * (WP_PW * PITCH);   // tap row dy = wave-1: halo rows shifted by `wave`
         if constexpr (sizeof(T) == 2) {
             const int i16 = lane & 15, g16 = lane >> 4;
             const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
             typedef s16x4 __attribute__((address_space(3))) * lds_v4;
-            const int col = (cb * 16 + pc * 4) * 2;
+            const int lane_off = (kh * 8 + q) * PITCH + (cb * 16 + pc * 4) * 2;
+            const char* gl = G + lane_off;
+            const char* il = I + lane_off;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int krow = ks * 16 + kh * 8 + q;
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + krow * PITCH + col));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(G + (krow + 4) * PITCH + col));
+            for (int ks = 0; ks < 8; ++ks) {  // K = 128 positions: image row ks>>1 of the patch, 16-position half ks&1
+                const int goff = ks * 16 * PITCH;
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + goff));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + goff + 4 * PITCH));
                 const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int prow = (wave + 1 + p.tap_dy[t]) * WP_PW + 1 + p.tap_dx[t] + krow;
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + prow * PITCH + col));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(I + (prow + 4) * PITCH + col));
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int ioff = ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
                     const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[dx], 0, 0, 0);
                 }
             }
         } else {
             const int r = lane & 31, h = lane >> 5;
-#pragma unroll 4
-            for (int ks = 0; ks < 16; ++ks) {
-                const float a = *reinterpret_cast<const float*>(G + (ks * 2 + h) * PITCH + r * 4);
+#pragma unroll 8
+            for (int ks = 0; ks < 64; ++ks) {  // 2 positions per MFMA
+                const int pos = ks * 2 + h;     // 0..127 inside the patch
+                const float a = *reinterpret_cast<const float*>(G + pos * PITCH + r * 4);
+                const int ipix = (pos >> 5) * WP_PW + (pos & 31);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int prow = (wave + 1 + p.tap_dy[t]) * WP_PW + 1 + p.tap_dx[t] + ks * 2 + h;
-                    const float bb = *reinterpret_cast<const float*>(I + prow * PITCH + r * 4);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float bb = *reinterpret_cast<const float*>(I + (ipix + dx) * PITCH + r * 4);
+                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dx], 0, 0, 0);
                 }
             }
         }
         if (patch + 1 < pend) lstore(cur ^ 1);
         __syncthreads();
     }
-    // sum the four waves' accumulators through LDS (staging buffers are dead now), wave 0 writes the slab
-    float* red = reinterpret_cast<float*>(lds);
-    for (int w = 1; w < 4; ++w) {
-        if (wave == w) {
+    // every wave owns its three taps: no cross-wave reduction
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + r;
+    if (ci < p.cin_total) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+        for (int dx = 0; dx < 3; ++dx) {
+            float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + dx) * w_rows) * p.cin_total;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) red[(t * 16 + j) * 64 + lane] = acc[t][j];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[t][j] += red[(t * 16 + j) * 64 + lane];
-        }
-        __syncthreads();
-    }
-    if (wave == 0) {
-        const int r = lane & 31, h = lane >> 5;
-        const int ci = ci0 + r;
-        if (ci < p.cin_total) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float* dst = p.partial + (((int64_t)split * 9 + t) * w_rows) * p.cin_total;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int co = co0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                    if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[t][j];
-                }
+            for (int j = 0; j < 16; ++j) {
+                const int co = co0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dx][j];
             }
         }
     }
@@ -1164,7 +1147,19 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     // ---- kernel variant: 0 heuristic, 1 gather, 2 patch/128-B chunks, 3 patch/64-B chunks, 4 patch mode S ----
     bool dense3x3 = !planar && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
                     p.TH == p.OH && p.TW == p.OW && p.TH == p.IH && p.TW == p.IW && p.TW >= 16;
-    for (int t = 0; t < p.ntaps && dense3x3; ++t) dense3x3 = p.tap_dy[t] >= -1 && p.tap_dy[t] <= 1 && p.tap_dx[t] >= -1 && p.tap_dx[t] <= 1;
+    // the patch kernels walk taps in spatial order with weight tap t (forward) or 8-t (stride-1 dgrad)
+    int flip = -1;
+    if (dense3x3 && p.w_taps == 9) {
+        bool fwd = true, bwd = true;
+        for (int t = 0; t < 9; ++t) {
+            const int sp = (p.tap_dy[t] + 1) * 3 + (p.tap_dx[t] + 1);
+            if (p.tap_dy[t] < -1 || p.tap_dy[t] > 1 || p.tap_dx[t] < -1 || p.tap_dx[t] > 1) fwd = bwd = false;
+            fwd = fwd && p.tap_w[t] == sp;
+            bwd = bwd && p.tap_w[t] == 8 - sp;
+        }
+        flip = fwd ? 0 : (bwd ? 1 : -1);
+    }
+    dense3x3 = dense3x3 && flip >= 0;
     const int esz = p.dtype == FALNET_BF16 ? 2 : 4;
     bool c128 = true;  // every source is a whole number of 128-B channel chunks
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
@@ -1189,7 +1184,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         const bool multi = ctot / (128 / esz) > 1;
 #define LAUNCH_PATCH(T, BN, KCB, TPS, ADB)                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_patch_kernel<T, BN, KCB, TPS, ADB>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)), \
-                       dim3(CONV_THREADS), 0, st, p, tiles_x, tiles_y)
+                       dim3(CONV_THREADS), 0, st, p, tiles_x, tiles_y, flip)
 #define DISPATCH_PATCH(T)                                                                        \
     do {                                                                                         \
         if (variant == 2) {                                                                      \
@@ -1266,16 +1261,16 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     const int w_rows = round32(p.gC);
     // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
     bool dense = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
-    for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] >= -1 && p.tap_dy[t] <= 1 && p.tap_dx[t] >= -1 && p.tap_dx[t] <= 1;
+    for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;  // canonical forward order
     if (dense) {
         const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
         const int npatch = p.B * tiles_x * tiles_y;
         const int pps = (npatch + p.nsplit - 1) / p.nsplit;
         const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
         if (p.dtype == FALNET_BF16)
-            hipLaunchKernelGGL(wgrad3x3_patch_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            hipLaunchKernelGGL(wgrad3x3_patch_kernel<bf16_t>, grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
         else
-            hipLaunchKernelGGL(wgrad3x3_patch_kernel<float>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            hipLaunchKernelGGL(wgrad3x3_patch_kernel<float>, grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
         FALNET_RETURN_LAUNCH();
     }
     const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);

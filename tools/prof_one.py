@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Run ONE conv / wgrad launch configuration repeatedly (target for rocprofv3 --pmc).  usage:
+   prof_one.py conv <groups e.g. 256> <cout> <H> <W> <variant> | wgrad <groups> <cout> <H> <W>"""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from fal_net_amd import _lib as L, ops
+ops.AUTOTUNE = False
+DEV, dtype, B = "cuda", torch.bfloat16, 8
+kind = sys.argv[1]
+groups = [int(x) for x in sys.argv[2].split("+")]
+cout, H, W = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+cin = sum(groups)
+w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=DEV) * 0.05)
+pc = ops.PackedConv("t", w, None, groups, 1)
+pc.alloc(dtype, torch.device(DEV))
+pc.pack_call()()
+srcs_t = [torch.randn(B, H, W, ops.pad_c(g), device=DEV).to(dtype) for g in groups]
+if kind == "conv":
+    out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
+    call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
+                         H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU)
+    call.desc.variant = int(sys.argv[6])
+    run = call
+else:
+    gout = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype)
+    ws = torch.empty(24 << 20, device=DEV)
+    gw = torch.empty_like(w)
+    c = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W,
+                        pc, gw, None, ws)
+    run = lambda: c(0)
+for _ in range(10):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    run()
+e1.record()
+torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 10
+print(f"{kind} {groups}->{cout} @{H}x{W}: {t*1e3:.1f} us, {2.0*B*H*W*cout*cin*9/t/1e9:.1f} TF")
