@@ -621,23 +621,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
             s = s + 1 < p.nsrc ? s + 1 : s;
         }
     };
+    // all (8+2) rows are requested before the first one is stored: ONE memory round trip, not ten
     auto load_whole_patch = [&](char* A, int s, int c0) {
-        for (int pr = 0; pr < PT_TH + 2; ++pr) {
-            uint4 regs[A_SLOTS];
-            patch_row_load(pr, s, c0, regs);
-            patch_row_store(A, pr, regs);
-        }
+        uint4 regs[PT_TH + 2][A_SLOTS];
+#pragma unroll
+        for (int pr = 0; pr < PT_TH + 2; ++pr) patch_row_load(pr, s, c0, regs[pr]);
+#pragma unroll
+        for (int pr = 0; pr < PT_TH + 2; ++pr) patch_row_store(A, pr, regs[pr]);
     };
 
     if constexpr (!PIPE) {
         for (int c = 0; c < nchunks; ++c) {
             if (c > 0) __syncthreads();
-            load_whole_patch(Abuf(0), s_, c0_);
+            {
+                uint4 wregs[9][B_SLOTS];
 #pragma unroll
-            for (int tt = 0; tt < 9; ++tt) {
-                uint4 regs[B_SLOTS];
-                w_tile_load(tt, kofs_, regs);
-                w_tile_store(Bbuf(0) + tt * BN * PITCH, regs);
+                for (int tt = 0; tt < 9; ++tt) w_tile_load(tt, kofs_, wregs[tt]);
+                load_whole_patch(Abuf(0), s_, c0_);
+#pragma unroll
+                for (int tt = 0; tt < 9; ++tt) w_tile_store(Bbuf(0) + tt * BN * PITCH, wregs[tt]);
             }
             __syncthreads();
 #pragma unroll
@@ -645,11 +647,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
             advance(s_, c0_, kofs_);
         }
     } else {
-        // prologue: patch of chunk 0 and the weight tile of (chunk 0, tap 0)
-        load_whole_patch(Abuf(0), s_, c0_);
+        // prologue: patch of chunk 0 and the weight tile of (chunk 0, tap 0), all loads in flight together
         {
             uint4 regs[B_SLOTS];
             w_tile_load(0, kofs_, regs);
+            load_whole_patch(Abuf(0), s_, c0_);
             w_tile_store(Bbuf(0), regs);
         }
         __syncthreads();
@@ -879,8 +881,8 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
         i_col[u] = (short)(pix % WP_PW);
     }
 
-    uint4 greg[G_SLOTS], ireg[I_SLOTS];
-    auto gload = [&](int patch) {
+    struct Regs { uint4 g[G_SLOTS]; uint4 i[I_SLOTS]; };
+    auto gload = [&](int patch, Regs& R) {
         int q = patch;
         const int tix = q % tiles_x;
         q /= tiles_x;
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
             uint4 v = make_uint4(0, 0, 0, 0);
             if (idx < G_LOADS && y < p.TH && x < p.TW && co0 + seg * EPS < p.gC)
                 v = *reinterpret_cast<const uint4*>(gbase + ((int64_t)y * p.TW + x) * p.gC + seg * EPS);
-            greg[u] = v;
+            R.g[u] = v;
         }
         const T* ibase = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + cloc;
 #pragma unroll
@@ -912,19 +914,19 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
                 }
                 v = *reinterpret_cast<const uint4*>(ibase + (int64_t)vy * S.sy + (int64_t)vx * S.sx + seg * EPS);
             }
-            ireg[u] = v;
+            R.i[u] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const Regs& R) {
 #pragma unroll
         for (int u = 0; u < G_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + idx * 16) = greg[u];   // pixel-major, unpadded: idx*16 B
+            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + idx * 16) = R.g[u];   // pixel-major, unpadded: idx*16 B
         }
 #pragma unroll
         for (int u = 0; u < I_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            if (idx < I_LOADS) *reinterpret_cast<uint4*>(Ibuf(buf) + idx * 16) = ireg[u];
+            if (idx < I_LOADS) *reinterpret_cast<uint4*>(Ibuf(buf) + idx * 16) = R.i[u];
         }
     };
 
@@ -934,14 +936,7 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-    if (pbeg < pend) {
-        gload(pbeg);
-        lstore(0);
-    }
-    __syncthreads();
-    for (int patch = pbeg; patch < pend; ++patch) {
-        const int cur = (patch - pbeg) & 1;
-        if (patch + 1 < pend) gload(patch + 1);
+    auto compute = [&](int cur) {
         const char* G = Gbuf(cur);
         const char* I = Ibuf(cur) + wave * (WP_PW * PITCH);   // tap row dy = wave-1: halo rows shifted by `wave`
         if constexpr (sizeof(T) == 2) {
@@ -980,7 +975,20 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
                 }
             }
         }
-        if (patch + 1 < pend) lstore(cur ^ 1);
+    };
+
+    // distance-1 prefetch (a second register set for distance 2 costs a wave of occupancy and measured slower)
+    Regs R0;
+    if (pbeg < pend) {
+        gload(pbeg, R0);
+        lstore(0, R0);
+    }
+    __syncthreads();
+    for (int patch = pbeg; patch < pend; ++patch) {
+        const int cur = (patch - pbeg) & 1;
+        if (patch + 1 < pend) gload(patch + 1, R0);
+        compute(cur);
+        if (patch + 1 < pend) lstore(cur ^ 1, R0);
         __syncthreads();
     }
     // every wave owns its three taps: no cross-wave reduction
