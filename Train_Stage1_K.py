@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Stage-1 training entry point (reference: Train_Stage1_K.py) on the MI355X implementation.
+
+Same flag names and defaults as the reference (Train_Stage1_K.py:30-70), with types added (the reference's
+untyped flags only work at their defaults).  Differences, all outside the hot path:
+  * `--synthetic` (default when no dataset loader is available): seeded random stereo pairs of the crop size,
+    so the script runs with no KITTI files -- the data pipeline (Datasets/, data_transforms.py) is out of scope
+    for this round;
+  * data parallelism is one process per GPU (`torchrun --nproc-per-node N Train_Stage1_K.py ...`) with ONE RCCL
+    all-reduce of the flat gradient buffer per step, instead of nn.DataParallel (Train_Stage1_K.py:172);
+  * logging is stdout / JSON lines; losses are read back every `--print-freq` steps only (the reference syncs twice
+    per step, :249,259).
+"""
+import argparse
+import datetime
+import json
+import os
+import time
+
+parser = argparse.ArgumentParser(description='FAL_net Stage 1 on MI355X', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+parser.add_argument('-d', '--data', metavar='DIR', default=None, help='path to dataset (unused with --synthetic)')
+parser.add_argument('-n0', '--dataName0', default='Kitti')
+parser.add_argument('-train_split', '--train_split', default='eigen_train_split')
+parser.add_argument('-vdn', '--vdataName', default='Kitti2015')
+parser.add_argument('-relbase_test', '--rel_baset', type=float, default=1)
+parser.add_argument('-maxd', '--max_disp', type=float, default=300)
+parser.add_argument('-mind', '--min_disp', type=float, default=2)
+parser.add_argument('-gpu_no', '--gpu_no', default='0')
+parser.add_argument('-mm', '--m_model', default='FAL_netB', choices=['FAL_netB'])
+parser.add_argument('-no_levels', '--no_levels', type=int, default=49)
+parser.add_argument('-perc', '--a_p', type=float, default=0.01)
+parser.add_argument('-smooth', '--a_sm', type=float, default=0.2 * 2 / 512)
+parser.add_argument('-w', '--workers', type=int, default=4)
+parser.add_argument('-b', '--batch_size', type=int, default=8)
+parser.add_argument('-ch', '--crop_height', type=int, default=192)
+parser.add_argument('-cw', '--crop_width', type=int, default=640)
+parser.add_argument('-tbs', '--tbatch_size', type=int, default=1)
+parser.add_argument('-op', '--optimizer', default='adam')
+parser.add_argument('--lr', type=float, default=0.0001)
+parser.add_argument('--beta', type=float, default=0.999)
+parser.add_argument('--momentum', type=float, default=0.5)
+parser.add_argument('--milestones', type=int, nargs='*', default=[30, 40])
+parser.add_argument('--weight-decay', '--wd', type=float, default=0.0)
+parser.add_argument('--bias-decay', type=float, default=0.0)
+parser.add_argument('--epochs', type=int, default=50)
+parser.add_argument('--epoch_size', type=int, default=0)
+parser.add_argument('--sparse', default=True, action='store_true')
+parser.add_argument('--print-freq', '-p', type=int, default=100)
+parser.add_argument('--start-epoch', type=int, default=0)
+parser.add_argument('--pretrained', default=None, help='checkpoint.pth.tar in the reference format')
+# --- additions ---
+parser.add_argument('--synthetic', action='store_true', help='seeded random pairs instead of a dataset')
+parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype (f32 = exact-f32 MFMA parity path)')
+parser.add_argument('--save-path', default=None)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from fal_net_amd import loss_functions as LF
+    from fal_net_amd import myUtils as utils
+    from fal_net_amd import synthetic, train
+    import models
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank, local_rank = int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    if args.weight_decay or args.bias_decay:
+        raise SystemExit('weight decay is 0 in the reference defaults; the fused flat Adam implements wd=0 only')
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    LF.set_compute_dtype(dtype)
+
+    save_path = args.save_path or os.path.join(args.dataName0 + '_stage1', datetime.datetime.now().strftime('%m-%d-%H_%M'),
+                                               '{},e{}es{},b{},lr{}'.format(args.m_model, args.epochs, args.epoch_size or '', args.batch_size, args.lr))
+    if rank == 0:
+        os.makedirs(save_path, exist_ok=True)
+        with open(os.path.join(save_path, 'settings.txt'), 'w') as f:
+            f.write(''.join('%15s: %s\n' % (k, v) for k, v in vars(args).items()))
+
+    network_data = torch.load(args.pretrained, map_location='cpu') if args.pretrained else None
+    m_model = models.__dict__[args.m_model](network_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev)
+    if rank == 0:
+        print("=> Number of parameters m-model '{}'".format(utils.get_n_params(m_model)))
+    opt = train.FlatAdam(m_model, lr=args.lr, betas=(args.momentum, args.beta))
+
+    def lr_at(epoch):  # MultiStepLR(milestones, gamma=0.5), fast-forwarded like Train_Stage1_K.py:181-184
+        return args.lr * (0.5 ** sum(1 for m in args.milestones if epoch >= m))
+
+    if not args.synthetic:
+        raise SystemExit('only --synthetic input is wired in this build: the KITTI loaders/augmentations (Datasets/, '
+                         'data_transforms.py) are outside the hot path (SURVEY.md 8f-3).')
+    steps_per_epoch = args.epoch_size or 100
+    best = -1
+    for epoch in range(args.start_epoch, args.epochs):
+        opt.param_groups[0]['lr'] = lr_at(epoch)
+        m_model.train()
+        losses, rec_losses = utils.AverageMeter(), utils.AverageMeter()
+        end = time.time()
+        for i in range(steps_per_epoch):
+            left, right, mn, mx = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width,
+                                                           seed=1234 + rank + 977 * (epoch * steps_per_epoch + i), max_disp=args.max_disp)
+            out = train.stage1_step(m_model, opt, left.to(dev), right.to(dev), mx.to(dev), a_p=args.a_p, a_sm=args.a_sm,
+                                    min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
+            if i % args.print_freq == 0:
+                losses.update(float(out['loss']), args.batch_size)
+                rec_losses.update(float(out['rec']), args.batch_size)
+                if rank == 0:
+                    print(json.dumps({'epoch': epoch, 'iter': i, 'of': steps_per_epoch, 'loss': losses.val, 'rec_loss': rec_losses.val,
+                                      'pairs_per_s': world * args.batch_size * (i + 1) / (time.time() - end)}), flush=True)
+        if rank == 0:
+            utils.save_checkpoint({'epoch': epoch + 1, 'm_model': args.m_model, 'state_dict': m_model.state_dict(), 'best_rmse': best},
+                                  False, save_path)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    args = parser.parse_args()
+    main()
