@@ -45,6 +45,17 @@ class Wgrad(C.Structure):
                 ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("grad", C.c_void_p), ("nsplit", C.c_int32), ("ntaps", C.c_int32),
+                ("w_rows", C.c_int32), ("cin_total", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("c0_real", C.c_int32), ("c0_pad", C.c_int32), ("groups", C.c_int32), ("block_begin", C.c_int32)]
+
+
+class BiasGradDesc(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("db", C.c_void_p), ("npix", C.c_int64), ("gC", C.c_int32), ("cout", C.c_int32),
+                ("blocks", C.c_int32), ("block_begin", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/falnet_hip.h one to one
 SIGNATURES = {
@@ -57,6 +68,8 @@ SIGNATURES = {
     "falnet_wgrad": [C.POINTER(Wgrad), _P],
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
+    "falnet_wgrad_reduce_batched": [_P, _I, _I, _P],
+    "falnet_bias_grad_batched": [_P, _I, _I, _I, _P],
     "falnet_pack_weights": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "falnet_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

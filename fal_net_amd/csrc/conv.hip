@@ -1081,6 +1081,104 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g,
     }
 }
 
+// ---- batched forms: ONE launch reduces the split-K slabs of every layer / sums every bias gradient ----------
+// (a step has ~34 weight tensors and 13 biases; per-layer launches are launch-latency bound)
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_reduce_t* __restrict__ descs, int n) {
+    __shared__ float tile[64 * 9];
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    const falnet_reduce_t d = descs[li];
+    int rel = blockIdx.x - d.block_begin;
+    const int chunks = (d.cin_total + 63) / 64;
+    const int grp = rel % d.groups;
+    rel /= d.groups;
+    const int cp0 = (rel % chunks) * 64, co = rel / chunks;
+    const int s0 = (int)((int64_t)d.nsplit * grp / d.groups), s1 = (int)((int64_t)d.nsplit * (grp + 1) / d.groups);
+    const int64_t slab = (int64_t)d.ntaps * d.w_rows * d.cin_total;
+    for (int e = threadIdx.x; e < d.ntaps * 64; e += blockDim.x) {
+        const int t = e / 64, cl = e % 64;
+        float s = 0.f;
+        if (cp0 + cl < d.cin_total) {
+            const float* src = d.partial + ((int64_t)t * d.w_rows + co) * d.cin_total + cp0 + cl;
+            for (int k = s0; k < s1; ++k) s += src[k * slab];
+        }
+        tile[cl * d.ntaps + t] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < d.ntaps * 64; e += blockDim.x) {
+        const int cl = e / d.ntaps, t = e % d.ntaps;
+        const int cp = cp0 + cl;
+        int ci = -1;
+        if (cp < d.c0_pad) {
+            if (cp < d.c0_real) ci = cp;
+        } else if (d.c0_real + (cp - d.c0_pad) < d.cin) {
+            ci = d.c0_real + (cp - d.c0_pad);
+        }
+        if (ci >= 0) atomicAdd(d.grad + ((int64_t)co * d.cin + ci) * d.ntaps + t, tile[e]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_biasgrad_t* __restrict__ descs, int n) {
+    __shared__ float red[256 * 8];
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    const falnet_biasgrad_t d = descs[li];
+    const int bx = blockIdx.x - d.block_begin, nbx = d.blocks;
+    const T* g = reinterpret_cast<const T*>(d.g);
+    const int segs = d.gC / 8;
+    const int spb = segs < 256 ? segs : 256;
+    const int rows = 256 / spb;
+    const int sl = threadIdx.x % spb, rr = threadIdx.x / spb;
+    for (int seg = sl; seg < segs; seg += spb) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t pix = (int64_t)bx * rows + rr;
+        const int64_t stride = (int64_t)nbx * rows;
+        for (; pix + 3 * stride < d.npix; pix += 4 * stride) {  // four independent 16-B loads in flight
+            Vec8<T> v0, v1, v2, v3;
+            v0.load(g + pix * d.gC + seg * 8);
+            v1.load(g + (pix + stride) * d.gC + seg * 8);
+            v2.load(g + (pix + 2 * stride) * d.gC + seg * 8);
+            v3.load(g + (pix + 3 * stride) * d.gC + seg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += (v0.get(i) + v1.get(i)) + (v2.get(i) + v3.get(i));
+        }
+        for (; pix < d.npix; pix += stride) {
+            Vec8<T> v;
+            v.load(g + pix * d.gC + seg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v.get(i);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = acc[i];
+        __syncthreads();
+        if (rr == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = 0.f;
+                for (int k = 0; k < rows; ++k) t += red[(k * spb + sl) * 8 + i];
+                if (seg * 8 + i < d.cout) atomicAdd(d.db + seg * 8 + i, t);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream) {
+    FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
+    FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "bias_grad_batched: bad argument");
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(bias_grad_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    else
+        hipLaunchKernelGGL(bias_grad_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    FALNET_RETURN_LAUNCH();
+}
+
 // OIHW f32 -> packed operands (see falnet_hip.h)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int taps,

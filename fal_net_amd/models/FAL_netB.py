@@ -107,8 +107,6 @@ _DEC = {6: ("deconv6", 256, "iconv6", 256), 5: ("deconv5", 128, "iconv5", 256), 
 class FalnetPlan:
     """Static launch plan of FAL_net.forward / backward for one (B, H, W, dtype, device)."""
 
-    WS_BYTES = 96 << 20  # wgrad split-K slab workspace
-
     def __init__(self, model, B, H, W, dtype, device):
         self.model, self.B, self.H, self.W, self.dtype, self.device = model, B, H, W, dtype, device
         self.N = model.no_levels
@@ -169,23 +167,25 @@ class FalnetPlan:
         OH, OW = gout.shape[1], gout.shape[2]
         gw = self.model._grad_view(pc.weight)
         gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
-        call = ops.wgrad_calls(self.dtype, srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)],
-                               pc.stride, self.B, OH, OW, pc, gw, gb, self.buf["ws"], name="wgrad " + name,
-                               flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps)
-        # weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill
-        # the CUs that the small (latency-bound) dgrad launches leave idle.  Ordering: the side stream waits for
-        # the producer of `gout` (event on the main stream); run_backward joins the side stream at the end.
+        call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
+                               pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps)
+        self._side_call(call)
+
+    def _side_call(self, call):
+        """Weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill the
+        CUs that the small (latency-bound) dgrad launches leave idle.  Ordering: the side stream waits for the producer
+        of the launch's inputs (event on the main stream); run_backward joins the side stream at the end."""
         ev = torch.cuda.Event()
 
         def run(c=call, ev=ev):
             side = self._side_stream
             if side is None:
-                c(self._accumulate)
+                c()
                 return
             ev.record()
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                c(self._accumulate)
+                c()
         self.bwd_body.append(run)
 
     # ---- plan construction ----
@@ -197,7 +197,7 @@ class FalnetPlan:
         for pc in pcs.values():
             pc.alloc(dt, dev)
             self.pack.append(pc.pack_call())
-        self._f32("ws", self.WS_BYTES // 4)
+        self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)
         left = self._f32("left", B, 3, H, W)
@@ -321,6 +321,10 @@ class FalnetPlan:
             self._wgrad(pcc, srcs, ih, iw, g_a, name=cname)
             if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                 self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
+        # one batched slab reduce + one batched bias-gradient launch for all layers, after the last wgrad
+        reduce_all, bias_all = self.wbatch.finalize()
+        self._side_call(reduce_all)
+        self._side_call(bias_all)
 
     # ---- execution ----
     def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
@@ -350,6 +354,8 @@ class FalnetPlan:
         if g_pan is not None:
             b["g_pan"].copy_(g_pan)
         self._accumulate = self.model._begin_grad_accumulation()
+        if not self._accumulate:
+            self.model._flat_grad.zero_()  # the batched reduce / bias kernels ADD into the flat gradient buffer
         main = torch.cuda.current_stream()
         if self.use_side_stream and ops.TIMER is None:
             if self._side is None:

@@ -282,6 +282,99 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     return call
 
 
+class WgradBatch:
+    """All weight / bias gradients of one backward pass: per-layer split-K wgrad launches (each with its OWN slab
+    region, so they can run back to back) followed by ONE batched slab reduce and ONE batched bias-gradient launch
+    that add into the (pre-zeroed or accumulating) flat gradient buffer."""
+
+    SLAB_CAP = 32 << 20  # bytes of partial slabs per layer
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.items, self.bias = [], []
+        self.ws = None
+
+    def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0):
+        lib = L.lib()
+        d = L.Wgrad()
+        d.nsrc = len(srcs)
+        for i, s in enumerate(srcs):
+            d.src[i] = s
+        d.IH, d.IW = IH, IW
+        gC = gout.shape[-1]
+        d.gout, d.gC = gout.data_ptr(), gC
+        _fill_taps(d, taps)
+        d.isy = d.isx = stride_in
+        d.B, d.TH, d.TW = B, TH, TW
+        d.cin_total = pc.cin_pad
+        M = B * TH * TW
+        slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
+        dense = len(taps) == 9 and stride_in == 1 and TW >= 16
+        if dense:
+            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32)
+            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+            nsplit = max(1, min((768 + tiles - 1) // tiles, npatch))
+        else:
+            tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
+            nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
+        nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
+        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), 0
+        ref = C.byref(d)
+        keep = (d, srcs, gout, grad_w, grad_b)
+        dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
+
+        def launch(_keep=keep):
+            L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
+        c0_real, c0_pad = pc.group_channels()
+        self.items.append(dict(d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
+                               cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
+        if grad_b is not None:
+            self.bias.append(dict(g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
+        return _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, launch)
+
+    def finalize(self):
+        """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables."""
+        lib = L.lib()
+        total = sum((it["bytes"] + 255) // 256 * 256 for it in self.items)
+        self.ws = torch.empty(max(total, 256) // 4, dtype=torch.float32, device=self.device)
+        red = (L.ReduceDesc * len(self.items))()
+        off, blk = 0, 0
+        for i, it in enumerate(self.items):
+            it["d"].partial = self.ws.data_ptr() + off
+            blocks = it["cout"] * ((it["cin_total"] + 63) // 64)
+            groups = 1
+            if it["nsplit"] >= 16 and blocks < 1024:
+                groups = (1024 + blocks - 1) // blocks
+            groups = max(1, min(groups, it["nsplit"] // 8))
+            r = red[i]
+            r.partial, r.grad = self.ws.data_ptr() + off, it["grad"].data_ptr()
+            r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
+            r.cout, r.cin, r.c0_real, r.c0_pad, r.groups, r.block_begin = it["cout"], it["cin"], it["c0_real"], it["c0_pad"], groups, blk
+            blk += blocks * groups
+            off += (it["bytes"] + 255) // 256 * 256
+        self.red_dev = torch.frombuffer(bytearray(bytes(red)), dtype=torch.uint8).to(self.device)
+        n_red, red_blocks = len(self.items), blk
+        bias = (L.BiasGradDesc * max(len(self.bias), 1))()
+        blk = 0
+        for i, it in enumerate(self.bias):
+            segs = it["gC"] // 8
+            rows = 256 // min(segs, 256)
+            blocks = int(max(1, min(256, (it["npix"] + rows * 64 - 1) // (rows * 64))))
+            b = bias[i]
+            b.g, b.db, b.npix, b.gC, b.cout, b.blocks, b.block_begin = it["g"].data_ptr(), it["db"].data_ptr(), it["npix"], it["gC"], it["cout"], blocks, blk
+            blk += blocks
+        self.bias_dev = torch.frombuffer(bytearray(bytes(bias)), dtype=torch.uint8).to(self.device)
+        n_bias, bias_blocks, code = len(self.bias), blk, L.dtype_code(self.dtype)
+
+        def reduce_all():
+            L.check(lib.falnet_wgrad_reduce_batched(L.ptr(self.red_dev), n_red, red_blocks, L.stream_ptr()), "wgrad_reduce_batched")
+
+        def bias_all():
+            if n_bias:
+                L.check(lib.falnet_bias_grad_batched(L.ptr(self.bias_dev), n_bias, bias_blocks, code, L.stream_ptr()), "bias_grad_batched")
+        return _timed("wgrad_reduce_batched", 0, 0, reduce_all), _timed("bias_grad_batched", 0, 0, bias_all)
+
+
 def simple_call(fn_name, *args, name=None, nbytes=0):
     lib = L.lib()
     fn = getattr(lib, fn_name)

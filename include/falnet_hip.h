@@ -131,6 +131,21 @@ int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pa
 int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db,
                      int accumulate, int dtype, void* stream);
 
+/* Batched forms: device-resident descriptor tables, ONE launch for all layers of a step.  Both ADD into the
+ * gradient buffers (f32 atomics): the caller zeroes the flat gradient buffer once per step (or keeps it to accumulate).
+ * block_begin = first blockIdx.x of the entry; reduce entry uses cout * ceil(cin_total/64) * groups blocks
+ * (block -> (co, 64-channel chunk, slab group)), bias entry uses `blocks` blocks. */
+typedef struct {
+    const float* partial; float* grad;
+    int32_t nsplit, ntaps, w_rows, cin_total, cout, cin, c0_real, c0_pad, groups, block_begin;
+} falnet_reduce_t;
+typedef struct {
+    const void* g; float* db; int64_t npix;
+    int32_t gC, cout, blocks, block_begin;
+} falnet_biasgrad_t;
+int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream);
+int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
+
 /*
  * OIHW f32 master weights -> packed compute-dtype operands.
  *   fwd  : wf[co][tap][ci]  (CoutPad x taps x CinPad), channel groups padded per source:
