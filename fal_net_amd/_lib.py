@@ -51,6 +51,12 @@ class ReduceDesc(C.Structure):
                 ("c0_real", C.c_int32), ("c0_pad", C.c_int32), ("groups", C.c_int32), ("block_begin", C.c_int32)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("taps", C.c_int32), ("c0_real", C.c_int32), ("c0_pad", C.c_int32), ("cin_pad", C.c_int32),
+                ("cout_pad", C.c_int32), ("block_begin", C.c_int32)]
+
+
 class BiasGradDesc(C.Structure):
     _fields_ = [("g", C.c_void_p), ("db", C.c_void_p), ("npix", C.c_int64), ("gC", C.c_int32), ("cout", C.c_int32),
                 ("blocks", C.c_int32), ("block_begin", C.c_int32)]
@@ -68,6 +74,7 @@ SIGNATURES = {
     "falnet_wgrad": [C.POINTER(Wgrad), _P],
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
+    "falnet_pack_weights_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_batched": [_P, _I, _I, _P],
     "falnet_bias_grad_batched": [_P, _I, _I, _I, _P],
     "falnet_pack_weights": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],

@@ -1164,6 +1164,37 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_pack_t* __restrict__ descs, int n) {
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    const falnet_pack_t d = descs[li];
+    const int64_t total = (int64_t)d.cout_pad * d.taps * d.cin_pad;
+    const int64_t i = (int64_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cp = (int)(i % d.cin_pad), t = (int)((i / d.cin_pad) % d.taps), co = (int)(i / ((int64_t)d.cin_pad * d.taps));
+    int ci = -1;
+    if (cp < d.c0_pad) {
+        if (cp < d.c0_real) ci = cp;
+    } else if (d.c0_real + (cp - d.c0_pad) < d.cin) {
+        ci = d.c0_real + (cp - d.c0_pad);
+    }
+    const float v = (co < d.cout && ci >= 0) ? d.w[((int64_t)co * d.cin + ci) * d.taps + t] : 0.f;
+    T* wf = reinterpret_cast<T*>(d.wf);
+    T* wd = reinterpret_cast<T*>(d.wd);
+    if (wf) wf[i] = from_f32<T>(v);
+    if (wd) wd[((int64_t)cp * d.taps + t) * d.cout_pad + co] = from_f32<T>(v);
+}
+
+extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
+    FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "pack_weights_batched: bad argument");
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    else
+        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    FALNET_RETURN_LAUNCH();
+}
+
 extern "C" int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream) {
     FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
     hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);

@@ -196,7 +196,7 @@ class FalnetPlan:
         pcs = m._packed
         for pc in pcs.values():
             pc.alloc(dt, dev)
-            self.pack.append(pc.pack_call())
+        self.pack.append(ops.pack_all_call(list(pcs.values()), dt, dev))
         self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)

@@ -113,6 +113,26 @@ class PackedConv:
         return c0_real, c0_pad
 
 
+def pack_all_call(pcs, dtype, device):
+    """ONE launch that re-packs every layer's f32 OIHW master weight into its wf / wd operands."""
+    lib = L.lib()
+    descs = (L.PackDesc * len(pcs))()
+    blk = 0
+    for i, pc in enumerate(pcs):
+        c0_real, c0_pad = pc.group_channels()
+        d = descs[i]
+        d.w, d.wf, d.wd = pc.weight.data_ptr(), pc.wf.data_ptr(), pc.wd.data_ptr()
+        d.cout, d.cin, d.taps, d.c0_real, d.c0_pad, d.cin_pad, d.cout_pad, d.block_begin = (
+            pc.cout, pc.cin, pc.taps, c0_real, c0_pad, pc.cin_pad, pc.cout_pad, blk)
+        blk += (pc.cout_pad * pc.taps * pc.cin_pad + 255) // 256
+    dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+    n, total, code = len(pcs), blk, L.dtype_code(dtype)
+
+    def launch(_keep=(dev, pcs)):
+        L.check(lib.falnet_pack_weights_batched(L.ptr(dev), n, total, code, L.stream_ptr()), "pack_weights_batched")
+    return _timed("pack_weights_batched", 0, 0, launch)
+
+
 def fwd_taps(ksize):
     if ksize == 1:
         return [(0, 0, 0)]

@@ -50,14 +50,42 @@ def allreduce_gradients(model):
     return 1.0
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(device):
+    key = (device.type, device.index)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _AUX_STREAMS[key]
+
+
+def vgg_label_async(label):
+    """VGG features of a label image on an auxiliary HIP stream: independent of the network forward, so it runs
+    concurrently with it and fills the CUs the small backbone layers leave idle.  Returns (features, join)."""
+    main = torch.cuda.current_stream()
+    aux = _aux_stream(label.device)
+    aux.wait_stream(main)
+    with torch.cuda.stream(aux):
+        feats = vgg(label)
+
+    def join():
+        main.wait_stream(aux)
+        for t in feats:
+            t.record_stream(main)
+        return feats
+    return join
+
+
 def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0, max_disp_arg=300.0):
     """One iteration of Train_Stage1_K.py:233-262 (forward, VGG, losses, backward, all-reduce, Adam).
     Returns device scalars (no host sync)."""
     opt.zero_grad()
     W = left.shape[3]
     min_disp = max_disp * min_disp_arg / max_disp_arg  # :237
+    join_vgg = vgg_label_async(right) if a_p > 0 else None  # :241-244, overlapped with the model forward
     rpan, ldisp = model(left, min_disp, max_disp, ret_disp=True, ret_pan=True, ret_subocc=False)  # :238
-    vgg_right = vgg(right) if a_p > 0 else None  # :241-244
+    vgg_right = join_vgg() if join_vgg else None
     rec_loss = rec_loss_fnc(1, rpan, right, vgg_right, a_p)  # :248
     sm_loss = 0
     if a_sm > 0:

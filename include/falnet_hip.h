@@ -143,6 +143,11 @@ typedef struct {
     const void* g; float* db; int64_t npix;
     int32_t gC, cout, blocks, block_begin;
 } falnet_biasgrad_t;
+typedef struct {
+    const float* w; void* wf; void* wd;
+    int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses ceil(cout_pad*taps*cin_pad/256) blocks */
+} falnet_pack_t;
+int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream);
 int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 
