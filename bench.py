@@ -31,17 +31,17 @@ class EventTimer:
     def __init__(self):
         self.records = []
 
-    def run(self, tag, flops, nbytes, launch):
+    def run(self, tag, flops, nbytes, launch, name=""):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        self.records.append((tag, flops, nbytes, e0, e1))
+        self.records.append((tag, flops, nbytes, e0, e1, name))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for tag, flops, nbytes, e0, e1 in self.records:
+        for tag, flops, nbytes, e0, e1, _ in self.records:
             a = agg.setdefault(tag, {"ms": 0.0, "flops": 0, "bytes": 0, "launches": 0})
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.0: off by default)")
+    ap.add_argument("--launch-table", default=None, help="write the per-launch time table of the instrumented pass here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,8 +111,19 @@ def main():
     left, right, mn, mx = synthetic.synthetic_pair(args.batch, args.height, args.width, seed=1234 + rank)
     left, right, mx = left.to(dev), right.to(dev), mx.to(dev)  # inputs resident in HBM before the timed region
 
-    def step():
+    def eager_step():
         return train.stage1_step(model, opt, left, right, mx)
+
+    step, graphed = eager_step, False
+    if args.graph:
+        try:
+            step = train.GraphedStage1Step(model, opt, left, right, mx)
+            graphed = True
+        except Exception as e:  # capture is an optimisation, not a requirement: report and run eagerly
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager_step
 
     for _ in range(args.warmup):
         out = step()
@@ -138,7 +152,8 @@ def main():
         "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
         "config": {"workload": f"Stage-1 training step (BASELINE configs[1]), batch {args.batch}/GPU, "
                                f"{args.height}x{args.width}, N={args.levels}, seeded weights, seeded VGG19",
-                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss},
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss,
+                   "launch": "hipGraph replay" if graphed else "eager"},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -146,9 +161,19 @@ def main():
         timer = EventTimer()
         ops.TIMER = timer
         for _ in range(3):
-            step()
+            eager_step()
         agg = timer.summary()
         ops.TIMER = None
+        if args.launch_table:
+            per = {}
+            for tag, flops, nbytes, e0, e1, name in timer.records:
+                a = per.setdefault(name, [0.0, 0, flops, tag])
+                a[0] += e0.elapsed_time(e1)
+                a[1] += 1
+            with open(args.launch_table, "w") as f:
+                for name, (ms, cnt, flops, tag) in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                    us = ms * 1e3 / cnt
+                    f.write(f"{us:8.1f} us  {flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  {name:44s} {tag}\n")
         total_ms = sum(a["ms"] for a in agg.values()) / 3
         dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
         d = agg[dom_tag]

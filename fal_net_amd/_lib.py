@@ -95,6 +95,7 @@ SIGNATURES = {
     "falnet_smooth_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P],
     "falnet_mask_mix": [_P, _P, _P, _P, _I, _I, _L, _P],
     "falnet_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
+    "falnet_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
     "falnet_hflip": [_P, _P, _L, _I, _P],
     "falnet_rowmax": [_P, _P, _I, _L, _P],
 }

@@ -1164,26 +1164,35 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
     }
 }
 
+// One block = one 32(cout) x 32(packed cin) tile of one layer, all taps, staged through LDS: the OIHW reads are
+// runs of taps*32 contiguous floats, the wf rows ([co][tap][32 cin]) and wd rows ([cin][tap][32 cout]) are written as
+// 32 contiguous elements.  (The element-per-thread version gathered with stride `taps` and scattered 2-byte writes.)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_pack_t* __restrict__ descs, int n) {
+    __shared__ float tile[32][32 * 9 + 1];
     int li = 0;
     while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
     const falnet_pack_t d = descs[li];
-    const int64_t total = (int64_t)d.cout_pad * d.taps * d.cin_pad;
-    const int64_t i = (int64_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int cp = (int)(i % d.cin_pad), t = (int)((i / d.cin_pad) % d.taps), co = (int)(i / ((int64_t)d.cin_pad * d.taps));
-    int ci = -1;
-    if (cp < d.c0_pad) {
-        if (cp < d.c0_real) ci = cp;
-    } else if (d.c0_real + (cp - d.c0_pad) < d.cin) {
-        ci = d.c0_real + (cp - d.c0_pad);
+    const int rel = blockIdx.x - d.block_begin;
+    const int ctiles = d.cin_pad / 32;
+    const int co0 = (rel / ctiles) * 32, cp0 = (rel % ctiles) * 32;
+    const int taps = d.taps, rowlen = 32 * taps;
+    // packed columns cp0..cp0+31 map to a contiguous run of real channels (group boundaries are multiples of 32)
+    const int ci0 = cp0 < d.c0_pad ? cp0 : d.c0_real + (cp0 - d.c0_pad);
+    const int ci_end = cp0 < d.c0_pad ? d.c0_real : d.cin;   // exclusive bound of valid real channels for this tile
+    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
+        const int r = e / rowlen, k = e % rowlen;            // r: cout row of the tile, k = cil*taps + t
+        const int co = co0 + r, ci = ci0 + k / taps;
+        tile[r][k] = (co < d.cout && ci < ci_end) ? d.w[((int64_t)co * d.cin + ci0) * taps + k] : 0.f;
     }
-    const float v = (co < d.cout && ci >= 0) ? d.w[((int64_t)co * d.cin + ci) * d.taps + t] : 0.f;
+    __syncthreads();
     T* wf = reinterpret_cast<T*>(d.wf);
     T* wd = reinterpret_cast<T*>(d.wd);
-    if (wf) wf[i] = from_f32<T>(v);
-    if (wd) wd[((int64_t)cp * d.taps + t) * d.cout_pad + co] = from_f32<T>(v);
+    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
+        const int c = e % 32, t = (e / 32) % taps, r = e / (32 * taps);
+        if (wf) wf[((int64_t)(co0 + r) * taps + t) * d.cin_pad + cp0 + c] = from_f32<T>(tile[r][c * taps + t]);       // r = cout row, c = cin
+        if (wd) wd[((int64_t)(cp0 + r) * taps + t) * d.cout_pad + co0 + c] = from_f32<T>(tile[c][r * taps + t]);      // r = cin row, c = cout
+    }
 }
 
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {

@@ -195,6 +195,38 @@ __global__ __launch_bounds__(RED_THREADS) void adam_kernel(float* __restrict__ p
     }
 }
 
+// Adam with its hyper-state on the device: state = {lr, t}.  A captured hipGraph replays the same launch
+// arguments, so the step count (bias corrections) must advance in device memory, not in a kernel argument.
+__global__ __launch_bounds__(RED_THREADS) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                               float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                               const float* __restrict__ state, float b1, float b2, float eps,
+                                                               float grad_scale) {
+    const float lr = state[0];
+    const float t = state[1] + 1.0f;
+    const float step_size = lr / (1.0f - powf(b1, t));
+    const float rsqrt_bc2 = rsqrtf(1.0f - powf(b2, t));
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* P = &pp.x;
+        float* G = &gg.x;
+        float* M = &mm.x;
+        float* V = &vv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = G[j] * grad_scale;
+            M[j] = b1 * M[j] + (1.f - b1) * gr;
+            V[j] = b2 * V[j] + (1.f - b2) * gr * gr;
+            P[j] -= step_size * M[j] / (sqrtf(V[j]) * rsqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+__global__ void adam_tick_kernel(float* state) { state[1] += 1.0f; }
+
 // ------------------------------------------------------------------ flip / per-sample max (Train_Stage2_K.py:248-253,319)
 __global__ __launch_bounds__(RED_THREADS) void hflip_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                             int64_t total, int W) {
@@ -303,6 +335,15 @@ extern "C" int falnet_adam_step(float* p, const float* g, float* m, float* v, in
     const float step_size = (float)(lr / bc1), rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adam_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, step_size, b1,
                        b2, eps, rsqrt_bc2, grad_scale);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
+                                    float eps, float grad_scale, void* stream) {
+    FALNET_CHECK_ARG(p && g && m && v && state && n > 0 && (n & 3) == 0, "adam_step_dev: bad argument (n must be a multiple of 4)");
+    FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_dev: buffers must be 16-B aligned");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps, grad_scale);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
     FALNET_RETURN_LAUNCH();
 }
 

@@ -22,14 +22,14 @@ TIMER = None
 AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 
 
-def _timed(tag, flops, nbytes, launch):
+def _timed(tag, flops, nbytes, launch, name=""):
     def call(*a):
         t = TIMER
         if t is None:
             launch(*a)
         else:
-            t.run(tag, flops, nbytes, lambda: launch(*a))
-    call.tag, call.flops, call.nbytes = tag, flops, nbytes
+            t.run(tag, flops, nbytes, lambda: launch(*a), name)
+    call.tag, call.flops, call.nbytes, call.name = tag, flops, nbytes, name
     return call
 
 
@@ -124,13 +124,13 @@ def pack_all_call(pcs, dtype, device):
         d.w, d.wf, d.wd = pc.weight.data_ptr(), pc.wf.data_ptr(), pc.wd.data_ptr()
         d.cout, d.cin, d.taps, d.c0_real, d.c0_pad, d.cin_pad, d.cout_pad, d.block_begin = (
             pc.cout, pc.cin, pc.taps, c0_real, c0_pad, pc.cin_pad, pc.cout_pad, blk)
-        blk += (pc.cout_pad * pc.taps * pc.cin_pad + 255) // 256
+        blk += (pc.cout_pad // 32) * (pc.cin_pad // 32)
     dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
     n, total, code = len(pcs), blk, L.dtype_code(dtype)
 
     def launch(_keep=(dev, pcs)):
         L.check(lib.falnet_pack_weights_batched(L.ptr(dev), n, total, code, L.stream_ptr()), "pack_weights_batched")
-    return _timed("pack_weights_batched", 0, 0, launch)
+    return _timed("pack_weights_batched", 0, 0, launch, "pack_weights_batched")
 
 
 def fwd_taps(ksize):
@@ -201,7 +201,8 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
-    call = _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32, d.variant), flops, 0, launch)
+    call = _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32, d.variant), flops, 0, launch,
+                  f"{name} v{d.variant} k{d.ksplit}")
     call.desc, call.ref = d, ref
     return call
 
@@ -350,7 +351,7 @@ class WgradBatch:
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
         if grad_b is not None:
             self.bias.append(dict(g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
-        return _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, launch)
+        return _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, launch, name)
 
     def finalize(self):
         """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables."""
@@ -392,7 +393,8 @@ class WgradBatch:
         def bias_all():
             if n_bias:
                 L.check(lib.falnet_bias_grad_batched(L.ptr(self.bias_dev), n_bias, bias_blocks, code, L.stream_ptr()), "bias_grad_batched")
-        return _timed("wgrad_reduce_batched", 0, 0, reduce_all), _timed("bias_grad_batched", 0, 0, bias_all)
+        return (_timed("wgrad_reduce_batched", 0, 0, reduce_all, "wgrad_reduce_batched"),
+                _timed("bias_grad_batched", 0, 0, bias_all, "bias_grad_batched"))
 
 
 def simple_call(fn_name, *args, name=None, nbytes=0):
@@ -401,4 +403,4 @@ def simple_call(fn_name, *args, name=None, nbytes=0):
 
     def launch():
         L.check(fn(*args, L.stream_ptr()), name or fn_name)
-    return _timed(fn_name, 0, nbytes, launch)
+    return _timed(fn_name, 0, nbytes, launch, name or fn_name)

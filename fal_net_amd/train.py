@@ -32,13 +32,18 @@ class FlatAdam:
         flat, grad = self.model.flat_parameters(), self.model.flat_gradients()
         if flat is None:
             raise RuntimeError("FlatAdam.step before any forward/backward of the model")
-        if self.m is None or self.m.data_ptr() == 0 or self.m.numel() != flat.numel() or self.m.device != flat.device:
+        if self.m is None or self.m.numel() != flat.numel() or self.m.device != flat.device:
             self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+            # hyper-state {lr, t} lives on the device so that a captured hipGraph advances the step count
+            self.state = torch.tensor([float(self.param_groups[0]["lr"]), float(self.t)], device=flat.device)
+            self._lr_dev = float(self.param_groups[0]["lr"])
+        if self._lr_dev != float(self.param_groups[0]["lr"]):
+            self._lr_dev = float(self.param_groups[0]["lr"])
+            self.state[0] = self._lr_dev
         self.t += 1
         b1, b2 = self.betas
-        L.check(L.lib().falnet_adam_step(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(),
-                                         float(self.param_groups[0]["lr"]), b1, b2, self.eps, self.t, float(grad_scale),
-                                         L.stream_ptr()), "adam_step")
+        L.check(L.lib().falnet_adam_step_dev(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
+                                             b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
 
 
 def allreduce_gradients(model):
@@ -71,13 +76,15 @@ def vgg_label_async(label):
 
     def join():
         main.wait_stream(aux)
-        for t in feats:
-            t.record_stream(main)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in feats:
+                t.record_stream(main)
         return feats
     return join
 
 
-def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0, max_disp_arg=300.0):
+def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0, max_disp_arg=300.0,
+                optimize=True):
     """One iteration of Train_Stage1_K.py:233-262 (forward, VGG, losses, backward, all-reduce, Adam).
     Returns device scalars (no host sync)."""
     opt.zero_grad()
@@ -93,10 +100,42 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
         sm_loss = smoothness(left[:, :, :, c:], ldisp[:, :, :, c:], gamma=2)  # :255
     loss = rec_loss + a_sm * sm_loss  # :258
     loss.backward()
-    scale = allreduce_gradients(model)
-    opt.step(scale)
-    return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
-            "rpan": rpan, "ldisp": ldisp}
+    out = {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
+           "rpan": rpan, "ldisp": ldisp}
+    if optimize:
+        opt.step(allreduce_gradients(model))
+    return out
+
+
+class GraphedStage1Step:
+    """The Stage-1 step captured ONCE into a hipGraph and replayed: the ~300 launches of a step become one graph
+    launch (no per-launch host cost, dependent-kernel gaps shrink to the hardware boundary).  Possible because the
+    plan is static (fixed buffers, fixed descriptors) and Adam's step count lives on the device.  The inputs are the
+    tensors given here (copy new batches into them).  With world_size > 1 the graph ends after backward; the single
+    RCCL all-reduce and the Adam launch stay eager (collectives are not captured)."""
+
+    def __init__(self, model, opt, left, right, max_disp, warmup=3, **kw):
+        self.model, self.opt, self.kw = model, opt, kw
+        self.left, self.right, self.max_disp = left, right, max_disp
+        self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        s = torch.cuda.Stream(device=left.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up off the default stream: builds plans, autotunes, allocates optimiser state
+            for _ in range(warmup):
+                stage1_step(model, opt, left, right, max_disp, **kw)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = stage1_step(model, opt, left, right, max_disp, optimize=not self.multi, **kw)
+
+    def __call__(self):
+        self.graph.replay()
+        if self.multi:
+            self.opt.step(allreduce_gradients(self.model))
+        else:
+            self.opt.t += 1  # host mirror of the device step count
+        return self.out
 
 
 def hflip(x):

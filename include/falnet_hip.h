@@ -145,7 +145,7 @@ typedef struct {
 } falnet_biasgrad_t;
 typedef struct {
     const float* w; void* wf; void* wd;
-    int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses ceil(cout_pad*taps*cin_pad/256) blocks */
+    int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps <= 9 */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream);
@@ -227,6 +227,11 @@ int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, 
  * step_size = lr / (1 - b1^t), bias2 = sqrt(1 - b2^t) computed by the caller. */
 int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                      float eps, int step, float grad_scale, void* stream);
+
+/* Same update with the hyper-state on the device: state = {lr, t} (f32).  The kernel uses t+1 and a one-thread
+ * launch then advances t, so a captured hipGraph replays correctly.  n must be a multiple of 4. */
+int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
+                         float eps, float grad_scale, void* stream);
 
 /* horizontal flip of planar f32 [n_rows][W] (Train_Stage2_K.py:248-253 flip grid) */
 int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stream);
