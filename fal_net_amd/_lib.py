@@ -15,7 +15,8 @@ ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 OUT_NHWC, OUT_PLANAR_F32 = 0, 1
 CPAD = 32  # channel padding granule of NHWC tensors / packed weights (falnet_channel_pad)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfalnet_hip.so")
+# FALNET_LIB: alternative build of the same C-ABI (kernel A/B experiments); default = the in-tree library
+_LIB_PATH = os.environ.get("FALNET_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfalnet_hip.so")
 
 
 class Src(C.Structure):

@@ -13,6 +13,7 @@
 //         (half h owns k in [8h, 8h+8)) so that each lane's operands are two ds_read_b128.
 // Wave tiling: 4 waves, 128 positions x {32,64,128} channels per workgroup.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -79,17 +80,36 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
     constexpr int PITCHF = NT * 32 + 4;
     constexpr int CS = NT * 4;          // 8-channel segments per row
     constexpr int RPP = 64 / CS;        // rows per pass
+    constexpr int PASSES = 32 / RPP;
     const int r = lane & 31, h = lane >> 5;
     const T* addend = reinterpret_cast<const T*>(p.addend);
     const T* actout = reinterpret_cast<const T*>(p.actout);
     T* out = reinterpret_cast<T*>(p.out);
     const int cs = lane % CS, rsub = lane / CS;
     const int n = nbase + cs * 8;
+    const bool nok = n < p.Cout;
     float bias[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && n < p.Cout) ? p.bias[n + i] : 0.f;
+    for (int i = 0; i < 8; ++i) bias[i] = (p.bias && nok) ? p.bias[n + i] : 0.f;
+    // residual / activation-output vectors of a whole slab are requested BEFORE that slab is staged (one slab ahead
+    // for bf16), so their memory latency overlaps the LDS staging instead of serialising every 8-channel piece
+    constexpr int NBUF = sizeof(T) == 2 ? 2 : 1;
+    Vec8<T> addv[NBUF][PASSES], actv[NBUF][PASSES];
+    auto prefetch = [&](int mt, int buf) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int64_t o = rowoff(mt, ps * RPP + rsub);
+            if (o >= 0 && nok) {
+                if (addend) addv[buf][ps].load(addend + o + n);
+                if (actout) actv[buf][ps].load(actout + o + n);
+            }
+        }
+    };
+    if (addend || actout) prefetch(0, 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        const int buf = NBUF == 2 ? (mt & 1) : 0;
+        if (NBUF == 2 && mt + 1 < MT && (addend || actout)) prefetch(mt + 1, (mt + 1) & 1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -97,33 +117,31 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
+        for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * RPP + rsub;
             const int64_t o = rowoff(mt, row);
-            if (o >= 0 && n < p.Cout) {
+            if (o >= 0 && nok) {
                 const float4 x0 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8);
                 const float4 x1 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8 + 4);
                 float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                const int64_t off = o + n;
-                Vec8<T> t;
                 if (addend) {
-                    t.load(addend + off);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] += t.get(i);
+                    for (int i = 0; i < 8; ++i) v[i] += addv[buf][ps].get(i);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i] + bias[i], p.act);
                 if (actout) {
-                    t.load(actout + off);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] *= act_grad_from_out(t.get(i), p.actout_kind);
+                    for (int i = 0; i < 8; ++i) v[i] *= act_grad_from_out(actv[buf][ps].get(i), p.actout_kind);
                 }
+                Vec8<T> t;
                 t.set8(v);
-                t.store(out + off);
+                t.store(out + o + n);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (NBUF == 1 && mt + 1 < MT && (addend || actout)) prefetch(mt + 1, 0);
     }
 }
 
@@ -428,40 +446,57 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
 //                   workgroups per CU overlap each other.
 // One 32-position MFMA row tile = one image row of the block, so A-fragment rows are consecutive patch pixels
 // (pitch KCB+16 B: conflict-free ds_read_b128, as in the gather kernel).
-template <typename T, int KCB, int MT, int NT, bool SWAP_>
-__device__ __forceinline__ void mma_rows(const char* const (&arow)[MT], const char* const (&brow)[NT], int h,
-                                         f32x16 (&acc)[MT][NT]) {
-    if constexpr (sizeof(T) == 2) {
+// MFMA over a compile-time sequence of NSTEP (tap, k-segment) steps with the fragment reads of step i+2 issued before
+// the MFMAs of step i (three fragment sets in flight): the ~128-cycle ds_read latency is covered by two steps of
+// MFMAs instead of being exposed in front of every small MFMA group, so one or two waves per SIMD keep the matrix
+// pipe busy.  a_of(step, mt) / b_of(step, nt) return the 16-B fragment address of this lane.
+template <typename T, int MT, int NT, int NSTEP, typename AOf, typename BOf>
+__device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT]) {
+    uint4 fa[3][MT], fb[3][NT];
+    auto load = [&](int step, int slot) {
 #pragma unroll
-        for (int ks = 0; ks < KCB / 32; ++ks) {
-            bf16x8 a[MT], b[NT];
+        for (int mt = 0; mt < MT; ++mt) fa[slot][mt] = *reinterpret_cast<const uint4*>(a_of(step, mt));
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(arow[mt] + (ks * 2 + h) * 16);
+        for (int nt = 0; nt < NT; ++nt) fb[slot][nt] = *reinterpret_cast<const uint4*>(b_of(step, nt));
+    };
+    load(0, 0);
+    if (NSTEP > 1) load(1, 1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(brow[nt] + (ks * 2 + h) * 16);
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + 2 < NSTEP) load(st + 2, (st + 2) % 3);
+#ifndef FALNET_PIN_SCHED
+#define FALNET_PIN_SCHED 0
+#endif
+#if FALNET_PIN_SCHED
+        // optional: pin the issue order (hipcc otherwise sinks the reads back next to their MFMAs); measured -0.8 % on the step
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const int sl = st % 3;
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-        }
-    } else {
-        constexpr int HB = KCB / 2;  // bytes of K owned by one lane half
-#pragma unroll
-        for (int q = 0; q < HB / 16; ++q) {
-            float4 a[MT], b[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(arow[mt] + h * HB + q * 16);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(brow[nt] + h * HB + q * 16);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][mt]),
+                                                                          __builtin_bit_cast(bf16x8, fb[sl][nt]), acc[mt][nt], 0, 0, 0);
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32((&a[mt].x)[e], (&b[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fa[sl][mt].x)[e]),
+                                                                           __uint_as_float((&fb[sl][nt].x)[e]), acc[mt][nt], 0, 0, 0);
         }
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
 }
 
@@ -470,27 +505,32 @@ __device__ __forceinline__ void mma_rows(const char* const (&arow)[MT], const ch
 #define PT_PW (PT_TW + 2)
 #define PT_NPIX ((PT_TH + 2) * PT_PW)
 
-template <typename T, int BN, int KCB, int TPS, bool ADB>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
+template <typename T, int BN, int KCB, int TPS, bool ADB, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
     // Taps are walked in spatial order t = (dy+1)*3 + (dx+1) with COMPILE-TIME offsets (the 9-tap loops are fully
     // unrolled, so every LDS address below is lane base + immediate); the packed-weight tap of spatial tap t is t
     // for a forward launch and 8-t for a stride-1 dgrad (flip) -- checked by falnet_conv2d.
+    // TH x 32 output positions per workgroup (TH = 8: M = 256, 4 waves; TH = 16: M = 512, 8 waves = 2 per SIMD).
+    // The bigger block halves the weight bytes loaded per MAC: these kernels sit on the CU load path (~8-10 B/clk/CU).
+    constexpr int NTHR = NWAVES * 64;
+    constexpr int NPIX = (TH + 2) * PT_PW;
     constexpr int PITCH = KCB + 16;
     constexpr int SEGS = KCB / 16;
     constexpr int KCV = KCB / (int)sizeof(T);
     constexpr int EPS = 16 / (int)sizeof(T);
-    constexpr int WAVES_N = BN >= 128 ? 2 : 1, WAVES_M = 4 / WAVES_N;
-    constexpr int MT = PT_TH / WAVES_M;
+    constexpr int WAVES_N = BN >= 128 ? 2 : 1, WAVES_M = NWAVES / WAVES_N;
+    constexpr int MT = TH / WAVES_M;
     constexpr int WTN = BN / WAVES_N, NT = WTN / 32;
     constexpr bool PIPE = TPS < 9;  // mode P
-    constexpr int A_BYTES = PT_NPIX * PITCH, B_BYTES = TPS * BN * PITCH;
+    constexpr int A_BYTES = NPIX * PITCH, B_BYTES = TPS * BN * PITCH;
     constexpr int ROWL = PT_PW * SEGS;                                   // 16-B loads per patch row
-    constexpr int A_SLOTS = (ROWL + CONV_THREADS - 1) / CONV_THREADS;    // per thread per patch row
+    constexpr int A_SLOTS = (ROWL + NTHR - 1) / NTHR;    // per thread per patch row
     constexpr int BL = BN * SEGS;                                        // 16-B loads per weight tap tile
-    constexpr int B_SLOTS = (BL + CONV_THREADS - 1) / CONV_THREADS;
-    __shared__ __attribute__((aligned(16))) char lds[(ADB ? 2 : 1) * A_BYTES + (PIPE ? 2 : 1) * B_BYTES];
+    constexpr int B_SLOTS = (BL + NTHR - 1) / NTHR;
+    constexpr bool DBS = !PIPE && ADB;  // mode D: single-stage chunks, double-buffered (next chunk prefetched behind the MFMAs)
+    __shared__ __attribute__((aligned(16))) char lds[(ADB ? 2 : 1) * A_BYTES + ((PIPE || DBS) ? 2 : 1) * B_BYTES];
     auto Abuf = [&](int b) -> char* { return lds + (ADB ? b : 0) * A_BYTES; };
-    auto Bbuf = [&](int b) -> char* { return lds + (ADB ? 2 : 1) * A_BYTES + (PIPE ? b : 0) * B_BYTES; };
+    auto Bbuf = [&](int b) -> char* { return lds + (ADB ? 2 : 1) * A_BYTES + ((PIPE || DBS) ? b : 0) * B_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -500,7 +540,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     bid /= tiles_x;
     const int tiy = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int ty0 = tiy * PT_TH, tx0 = tix * PT_TW;
+    const int ty0 = tiy * TH, tx0 = tix * PT_TW;
     const int n0 = blockIdx.y * BN;
 
     int nchunks = 0;
@@ -512,7 +552,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     int a_goff[A_SLOTS][2];        // element offset (px*sx + seg*EPS) per source, -1 = outside the image (zero fill)
 #pragma unroll
     for (int u = 0; u < A_SLOTS; ++u) {
-        const int idx = tid + u * CONV_THREADS;
+        const int idx = tid + u * NTHR;
         a_lds[u] = -1;
         a_goff[u][0] = a_goff[u][1] = -1;
         if (idx < ROWL) {
@@ -537,7 +577,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     int64_t b_goff[B_SLOTS];
 #pragma unroll
     for (int u = 0; u < B_SLOTS; ++u) {
-        const int idx = tid + u * CONV_THREADS;
+        const int idx = tid + u * NTHR;
         b_lds[u] = -1;
         b_goff[u] = 0;
         if (idx < BL) {
@@ -555,7 +595,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     auto patch_row_load = [&](int pr, int s, int c0, uint4 (&regs)[A_SLOTS]) {
         const falnet_src_t& S = p.src[s];
         int vy = ty0 - 1 + pr;
-        const bool rowok = pr < PT_TH + 2 && vy >= 0 && vy < p.IH;
+        const bool rowok = pr < TH + 2 && vy >= 0 && vy < p.IH;
         if (S.H != p.IH) vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
         const T* base = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + (int64_t)vy * S.sy + c0;
 #pragma unroll
@@ -567,7 +607,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
         }
     };
     auto patch_row_store = [&](char* A, int pr, const uint4 (&regs)[A_SLOTS]) {
-        if (pr < PT_TH + 2) {
+        if (pr < TH + 2) {
 #pragma unroll
             for (int u = 0; u < A_SLOTS; ++u)
                 if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(A + pr * (PT_PW * PITCH) + a_lds[u]) = regs[u];
@@ -598,17 +638,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
 
-    const int a_lane = ((wm * MT) * PT_PW + r) * PITCH;  // patch pixel of (first row of this wave, lane column) at tap (-1,-1)
-    const int b_lane = (wn * WTN + r) * PITCH;
-    auto compute_tap = [&](const char* A, const char* Btile, int t /* compile-time after unrolling */) {
-        const int doff = ((t / 3) * PT_PW + (t % 3)) * PITCH;
-        const char* arow[MT];
-        const char* brow[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) arow[mt] = A + a_lane + (mt * PT_PW * PITCH + doff);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) brow[nt] = Btile + b_lane + nt * 32 * PITCH;
-        mma_rows<T, KCB, MT, NT, false>(arow, brow, h, acc);
+    // per-lane fragment bases; every other address component below is a compile-time constant after unrolling
+    //   bf16: k-step ks of a tap reads the 16-B segment (2*ks + h);  f32: lane half h owns bytes [h*KCB/2, (h+1)*KCB/2)
+    constexpr int KSEG = sizeof(T) == 2 ? KCB / 32 : KCB / 32;   // 16-B fragment segments per lane per tap (both dtypes: KCB/32)
+    const int lane_k = sizeof(T) == 2 ? h * 16 : h * (KCB / 2);
+    constexpr int KSTRIDE = sizeof(T) == 2 ? 32 : 16;            // byte distance between consecutive segments of one lane
+    const int a_lane = ((wm * MT) * PT_PW + r) * PITCH + lane_k;  // patch pixel (first row of this wave, lane column) at tap (-1,-1)
+    const int b_lane = (wn * WTN + r) * PITCH + lane_k;
+    // NTAPS consecutive taps starting at compile-time spatial tap t0; weight tiles are laid out [tap][BN][PITCH] from Btile
+    auto compute_taps = [&](const char* A, const char* Btile, auto t0c, auto ntapsc) {
+        constexpr int t0 = decltype(t0c)::value, NTAPS = decltype(ntapsc)::value;
+        const char* ab = A + a_lane;
+        const char* bb = Btile + b_lane;
+        mma_steps<T, MT, NT, NTAPS * KSEG>(
+            [&](int st, int mt) { const int t = t0 + st / KSEG, ks = st % KSEG;
+                                  return ab + (mt * PT_PW * PITCH + ((t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
+            [&](int st, int nt) { const int tt = st / KSEG, ks = st % KSEG;
+                                  return bb + (tt * BN * PITCH + nt * 32 * PITCH + ks * KSTRIDE); },
+            acc);
     };
 
     // K walk over chunks: (source, channel offset, packed-weight offset)
@@ -623,14 +670,49 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     };
     // all (8+2) rows are requested before the first one is stored: ONE memory round trip, not ten
     auto load_whole_patch = [&](char* A, int s, int c0) {
-        uint4 regs[PT_TH + 2][A_SLOTS];
+        uint4 regs[TH + 2][A_SLOTS];
 #pragma unroll
-        for (int pr = 0; pr < PT_TH + 2; ++pr) patch_row_load(pr, s, c0, regs[pr]);
+        for (int pr = 0; pr < TH + 2; ++pr) patch_row_load(pr, s, c0, regs[pr]);
 #pragma unroll
-        for (int pr = 0; pr < PT_TH + 2; ++pr) patch_row_store(A, pr, regs[pr]);
+        for (int pr = 0; pr < TH + 2; ++pr) patch_row_store(A, pr, regs[pr]);
     };
 
-    if constexpr (!PIPE) {
+    if constexpr (DBS) {
+        // mode D: chunk c is computed from LDS buffer c&1 while ALL of chunk c+1 (patch rows + nine weight tiles) is in
+        // flight into registers; one barrier per chunk
+        {
+            uint4 wregs[9][B_SLOTS];
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) w_tile_load(tt, kofs_, wregs[tt]);
+            load_whole_patch(Abuf(0), s_, c0_);
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) w_tile_store(Bbuf(0) + tt * BN * PITCH, wregs[tt]);
+        }
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const bool next_chunk = c + 1 < nchunks;
+            int sn = s_, c0n = c0_, kofsn = kofs_;
+            advance(sn, c0n, kofsn);
+            uint4 wregs[9][B_SLOTS], pregs[TH + 2][A_SLOTS];
+            if (next_chunk) {
+#pragma unroll
+                for (int tt = 0; tt < 9; ++tt) w_tile_load(tt, kofsn, wregs[tt]);
+#pragma unroll
+                for (int pr = 0; pr < TH + 2; ++pr) patch_row_load(pr, sn, c0n, pregs[pr]);
+            }
+            compute_taps(Abuf(c & 1), Bbuf(c & 1), std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+            if (next_chunk) {
+#pragma unroll
+                for (int tt = 0; tt < 9; ++tt) w_tile_store(Bbuf((c + 1) & 1) + tt * BN * PITCH, wregs[tt]);
+#pragma unroll
+                for (int pr = 0; pr < TH + 2; ++pr) patch_row_store(Abuf((c + 1) & 1), pr, pregs[pr]);
+            }
+            __syncthreads();
+            s_ = sn;
+            c0_ = c0n;
+            kofs_ = kofsn;
+        }
+    } else if constexpr (!PIPE) {
         for (int c = 0; c < nchunks; ++c) {
             if (c > 0) __syncthreads();
             {
@@ -642,8 +724,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
                 for (int tt = 0; tt < 9; ++tt) w_tile_store(Bbuf(0) + tt * BN * PITCH, wregs[tt]);
             }
             __syncthreads();
-#pragma unroll
-            for (int tt = 0; tt < 9; ++tt) compute_tap(Abuf(0), Bbuf(0) + tt * BN * PITCH, tt);
+            compute_taps(Abuf(0), Bbuf(0), std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
             advance(s_, c0_, kofs_);
         }
     } else {
@@ -661,23 +742,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
             const bool next_chunk = ADB && (c + 1 < nchunks);
             const char* Acur = Abuf(c & 1);
             char* Anext = Abuf((c + 1) & 1);
-#pragma unroll
-            for (int g = 0; g < 9; ++g) {
+            static_for<0, 9>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
                 const bool more = g < 8 || c + 1 < nchunks;
                 uint4 breg[B_SLOTS], areg0[A_SLOTS], areg1[A_SLOTS];
                 if (more) w_tile_load(g == 8 ? 0 : g + 1, g == 8 ? kofsn : kofs_, breg);
-                if (next_chunk) {  // 10 patch rows over 9 taps: tap g brings row g, tap 8 also row 9
+                constexpr int RPT = (TH + 2 + 8) / 9;  // patch rows prefetched per tap (2: tap g brings rows g and g+9)
+                if (next_chunk) {
                     patch_row_load(g, sn, c0n, areg0);
-                    if (g == 8) patch_row_load(9, sn, c0n, areg1);
+                    if (RPT > 1 && g + 9 < TH + 2) patch_row_load(g + 9, sn, c0n, areg1);
                 }
-                compute_tap(Acur, Bbuf((c + g) & 1), g);
+                compute_taps(Acur, Bbuf((c + g) & 1), std::integral_constant<int, g>{}, std::integral_constant<int, 1>{});
                 if (more) w_tile_store(Bbuf((c + g + 1) & 1), breg);
                 if (next_chunk) {
                     patch_row_store(Anext, g, areg0);
-                    if (g == 8) patch_row_store(Anext, 9, areg1);
+                    if (RPT > 1 && g + 9 < TH + 2) patch_row_store(Anext, g + 9, areg1);
                 }
                 __syncthreads();
-            }
+            });
             s_ = sn;
             c0_ = c0n;
             kofs_ = kofsn;
@@ -689,7 +771,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_patch_kernel(const falne
     __syncthreads();  // every wave is done with the A/B buffers
     {
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
-        static_assert(4 * 32 * (NT * 32 + 4) * 4 <= (ADB ? 2 : 1) * A_BYTES + (PIPE ? 2 : 1) * B_BYTES, "staging must fit in the LDS buffers");
+        static_assert(NWAVES * 32 * (NT * 32 + 4) * 4 <= (ADB ? 2 : 1) * A_BYTES + ((PIPE || DBS) ? 2 : 1) * B_BYTES, "staging must fit in the LDS buffers");
         const int cstride = p.out_cstride;
         epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, [&](int mt, int row) -> int64_t {
             const int y = ty0 + wm * MT + mt, x = tx0 + row;
@@ -1081,12 +1163,27 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g,
     }
 }
 
+// entry lookup for the batched kernels: the block_begin column is fetched by n threads in parallel into LDS (a serial
+// walk of the global table cost ~0.5 us per entry per block)
+template <typename D>
+__device__ __forceinline__ int find_entry(const D* __restrict__ descs, int n, int* sh /* >= 64 ints */) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sh[i] = descs[i].block_begin;
+    __syncthreads();
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= sh[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
 // ---- batched forms: ONE launch reduces the split-K slabs of every layer / sums every bias gradient ----------
 // (a step has ~34 weight tensors and 13 biases; per-layer launches are launch-latency bound)
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_reduce_t* __restrict__ descs, int n) {
     __shared__ float tile[64 * 9];
-    int li = 0;
-    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    __shared__ int entry_begin[64];
+    const int li = find_entry(descs, n, entry_begin);
     const falnet_reduce_t d = descs[li];
     int rel = blockIdx.x - d.block_begin;
     const int chunks = (d.cin_total + 63) / 64;
@@ -1121,8 +1218,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_biasgrad_t* __restrict__ descs, int n) {
     __shared__ float red[256 * 8];
-    int li = 0;
-    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    __shared__ int entry_begin[64];
+    const int li = find_entry(descs, n, entry_begin);
     const falnet_biasgrad_t d = descs[li];
     const int bx = blockIdx.x - d.block_begin, nbx = d.blocks;
     const T* g = reinterpret_cast<const T*>(d.g);
@@ -1170,8 +1267,8 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_pack_t* __restrict__ descs, int n) {
     __shared__ float tile[32][32 * 9 + 1];
-    int li = 0;
-    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].block_begin) ++li;
+    __shared__ int entry_begin[64];
+    const int li = find_entry(descs, n, entry_begin);
     const falnet_pack_t d = descs[li];
     const int rel = blockIdx.x - d.block_begin;
     const int ctiles = d.cin_pad / 32;
@@ -1311,8 +1408,9 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
     int variant = p.variant;
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG(variant >= 0 && variant <= 4, "conv2d: unknown variant %d", variant);
-    if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || (variant == 3 && ctot / (64 / esz) < 2))) {
+    FALNET_CHECK_ARG(variant >= 0 && variant <= 7, "conv2d: unknown variant %d", variant);
+    if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || ((variant == 3 || variant == 5 || variant == 6) && ctot / (64 / esz) < 2) ||
+                         (variant >= 6 && p.OH < 16))) {
         falnet_set_error("conv2d: variant %d not applicable to this launch", variant);
         return -2;
     }
@@ -1325,12 +1423,18 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     if (variant >= 2) {
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + PT_TH - 1) / PT_TH;
         const unsigned gx = (unsigned)(p.B * tiles_x * tiles_y);
+        const int tiles_y16 = (p.OH + 15) / 16;
+        const unsigned gx16 = (unsigned)(p.B * tiles_x * tiles_y16);
         const bool bn128 = p.w_rows % 128 == 0 && p.Cout > 64 && gx >= 256;
+        const bool bn128_16 = p.w_rows % 128 == 0 && p.Cout > 64;
         const bool bn64 = p.w_rows % 64 == 0 && p.Cout > 32;
         const bool multi = ctot / (128 / esz) > 1;
 #define LAUNCH_PATCH(T, BN, KCB, TPS, ADB)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_patch_kernel<T, BN, KCB, TPS, ADB>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)), \
-                       dim3(CONV_THREADS), 0, st, p, tiles_x, tiles_y, flip)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_patch_kernel<T, BN, KCB, TPS, ADB, 8, 4>), dim3(gx, (unsigned)((p.Cout + BN - 1) / BN)), \
+                       dim3(256), 0, st, p, tiles_x, tiles_y, flip)
+#define LAUNCH_PATCH16(T, BN, KCB, TPS, ADB)                                                                                \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_patch_kernel<T, BN, KCB, TPS, ADB, 16, 8>), dim3(gx16, (unsigned)((p.Cout + BN - 1) / BN)), \
+                       dim3(512), 0, st, p, tiles_x, tiles_y16, flip)
 #define DISPATCH_PATCH(T)                                                                        \
     do {                                                                                         \
         if (variant == 2) {                                                                      \
@@ -1347,6 +1451,16 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
             if (bn128) LAUNCH_PATCH(T, 128, 64, 1, true);                                        \
             else if (bn64) LAUNCH_PATCH(T, 64, 64, 1, true);                                     \
             else LAUNCH_PATCH(T, 32, 64, 1, true);                                               \
+        } else if (variant == 5) {                                                               \
+            if (bn64) LAUNCH_PATCH(T, 64, 64, 9, true);                                          \
+            else LAUNCH_PATCH(T, 32, 64, 9, true);                                               \
+        } else if (variant == 6) { /* 16x32 block, 8 waves, 64-B chunks, one tap per barrier */  \
+            if (bn128_16) LAUNCH_PATCH16(T, 128, 64, 1, true);                                   \
+            else if (bn64) LAUNCH_PATCH16(T, 64, 64, 1, true);                                   \
+            else LAUNCH_PATCH16(T, 32, 64, 1, true);                                             \
+        } else if (variant == 7) { /* 16x32 block, 8 waves, single stage */                      \
+            if (bn64) LAUNCH_PATCH16(T, 64, 64, 9, false);                                       \
+            else LAUNCH_PATCH16(T, 32, 64, 9, false);                                            \
         } else {                                                                                 \
             if (bn64) LAUNCH_PATCH(T, 64, 64, 9, false);                                         \
             else LAUNCH_PATCH(T, 32, 64, 9, false);                                              \
@@ -1356,6 +1470,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         else DISPATCH_PATCH(float);
 #undef DISPATCH_PATCH
 #undef LAUNCH_PATCH
+#undef LAUNCH_PATCH16
         FALNET_RETURN_LAUNCH();
     }
     const int bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (p.w_rows % 64 == 0 && p.Cout > 32 ? 64 : 32);

@@ -37,7 +37,7 @@ def conv_kernel_tag(dtype, w_rows, Cout, planar, variant=1):
     """Kernel family falnet_conv2d dispatches to (conv.hip: falnet_conv2d), for the bench's per-family totals."""
     dn = 'bf16' if dtype == torch.bfloat16 else 'f32'
     if variant >= 2:
-        return f"conv3x3_patch_kernel<{dn},{ {2: 'kcb128', 3: 'kcb64', 4: 'single-stage'}[variant]}>"
+        return f"conv3x3_patch_kernel<{dn},{ {2: 'kcb128', 3: 'kcb64', 4: 'single-stage', 5: 'double-stage', 6: 'kcb64,M512', 7: 'single-stage,M512'}[variant]}>"
     bn = 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
     return f"conv_igemm_kernel<{dn},{bn},{'planar' if planar else 'nhwc'}>"
 
@@ -227,7 +227,7 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     wgs = ((M + 127) // 128) * ((Cout + bn - 1) // bn)
     if wgs < 256 and M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
         cands += [(1, k) for k in (2, 4, 8, 16) if wgs * k <= 2048]
-    cands += [(2, 1), (3, 1), (4, 1)]
+    cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1)]
     best, best_t = (1, 1), None
     for v, k in cands:
         d.variant, d.ksplit = v, k

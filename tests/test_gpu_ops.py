@@ -129,6 +129,45 @@ def test_conv_forward(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [PATCH_CASES[0], PATCH_CASES[1], PATCH_CASES[3], PATCH_CASES[4],
+                                  (2, [64], 128, 40, 70, 1, 3, True, L.ACT_ELU, True), (1, [32, 64], 64, 33, 64, 1, 3, False, L.ACT_ELU, False)])
+def test_conv_every_kernel_variant(case, dtype):
+    """Force each kernel variant (gather, halo-patch 128/64-B chunks, single/double stage, 16x32-block forms) on the
+    same launch: all must agree with torch-CPU (the autotuner may pick any of them)."""
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    xs, w, b = _conv_inputs(case, seed=11)
+    addend = torch.randn(B, Cout, H, W, generator=torch.Generator().manual_seed(12)) if res else None
+    ref = _ref_conv(case, xs, w, b, addend)
+    pc = packed(w, b, groups, stride, dtype)
+    srcs_t = [to_nhwc(x, dtype) for x in xs]
+    add_t = to_nhwc(addend, dtype) if res else None
+    bias_t = None
+    if b is not None:
+        bias_t = torch.zeros(pc.cout_pad, device=DEV)
+        bias_t[:Cout] = pc.bias.data
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
+        call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(k), pc.taps, pc.cout_pad,
+                             stride, B, H, W, out, H, W, pc.cout_pad, pc.cout_pad, bias=bias_t, addend=add_t, act=act)
+    finally:
+        ops.AUTOTUNE = old
+    ran = []
+    for variant in range(1, 8):
+        call.desc.variant = variant
+        out.fill_(float("nan"))
+        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+        if rc == -2:
+            continue
+        assert rc == 0, (variant, L.lib().falnet_last_error())
+        got = to_nchw(out, Cout)
+        assert rel(got, ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL), variant
+        ran.append(variant)
+    assert 1 in ran and 4 in ran and (7 in ran or H < 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_planar_output(dtype):
     case = (2, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False)
     xs, w, b = _conv_inputs(case)

@@ -24,7 +24,7 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("iconv4 128+256->256 @32x64", [128, 256], 256, 32, 64, None),
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
 ]
-VARIANTS = [("gather", 1), ("patch128", 2), ("patch64", 3), ("modeS", 4)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7)]
 lib = L.lib()
 for name, groups, cout, H, W, up in LAYERS:
     cin = sum(groups)
@@ -64,8 +64,8 @@ for name, groups, cout, H, W, up in LAYERS:
     line = f"{name:34s}"
     for v, _ in VARIANTS:
         if not times[v]:
-            line += f" | {v}     n/a            "
+            line += f" | {v}    n/a         "
             continue
         t = sorted(times[v])[len(times[v]) // 2]
-        line += f" | {v} {t*1e3:7.1f}us {flops/t/1e9:7.1f}TF"
+        line += f" | {v} {t*1e3:6.1f}us {flops/t/1e9:6.0f}TF"
     print(line, flush=True)
