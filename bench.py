@@ -50,7 +50,24 @@ class EventTimer:
         return agg
 
 
-def cpu_baseline(height, width, levels, sample_batch=1):
+def hbm_traffic_from_profiles(kernel_symbol):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json, made by
+    tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction).
+    None when no profile of this kernel is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))
+    for name, v in table.items():
+        if name[:100] == kernel_symbol[:100]:
+            return {"bytes_per_launch": v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"],
+                    "fetch_bytes_corrected": v["fetch_bytes_per_launch_corrected"], "write_bytes": v["write_bytes_per_launch"],
+                    "source": os.path.basename(files[-1])}
+    return None
+
+
+def cpu_baseline(height, width, levels, sample_batch=8):
     """Reported CPU baseline: the oracle's Stage-1 step (fp32, torch CPU) on a bounded sample.
     Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get *slower* beyond that
     (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
@@ -182,7 +199,8 @@ def main():
         mfma_ms = sum(a["ms"] for a in agg.values() if a["flops"] > 0) / 3
         mfma_fl = sum(a["flops"] for a in agg.values()) / 3
         result["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": hbm_traffic_from_profiles(dom_tag),
             "kernel": dom_tag, "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "kernel_ms_per_step": d["ms"] / 3, "all_kernels_ms_per_step": total_ms,
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,

@@ -201,8 +201,11 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d(ref, L.stream_ptr()), name)
-    call = _timed(conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32, d.variant), flops, 0, launch,
-                  f"{name} v{d.variant} k{d.ksplit}")
+    buf = C.create_string_buffer(160)
+    tag = buf.value.decode() if lib.falnet_conv2d_kernel_name(ref, buf, 160) == 0 and buf.value else \
+        conv_kernel_tag(dtype, w_rows, Cout, out_layout == L.OUT_PLANAR_F32, d.variant)
+    tag = buf.value.decode() or tag
+    call = _timed(tag, flops, 0, launch, f"{name} v{d.variant} k{d.ksplit}")
     call.desc, call.ref = d, ref
     return call
 
@@ -351,7 +354,9 @@ class WgradBatch:
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
         if grad_b is not None:
             self.bias.append(dict(g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
-        return _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, launch, name)
+        tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
+        sym = f"_Z21wgrad3x3_patch_kernelI{tn}Ev14falnet_wgrad_tiiii" if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
+        return _timed(sym, flops, 0, launch, name)
 
     def finalize(self):
         """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables."""

@@ -97,6 +97,8 @@ typedef struct {
                                   -2 is returned when the variant does not apply */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
+/* symbol (as rocprofv3 reports it) of the kernel falnet_conv2d launches for this descriptor */
+int falnet_conv2d_kernel_name(const falnet_conv_t* p, char* buf, int len);
 
 /*
  * Weight gradient (autograd of the conv2d call sites above):
