@@ -195,7 +195,7 @@ __device__ __forceinline__ void mma_tile(const char* __restrict__ As, const char
 
 // ------------------------------------------------------------------------------------------ fwd / dgrad
 template <typename T, int BN, bool SWAP>
-__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_conv_t p) {
+__device__ __forceinline__ void conv_igemm_body(const falnet_conv_t& p, const int zi, const int nz) {
     constexpr int BM = CONV_BM;
     constexpr int WAVES_N = BN >= 64 ? 2 : 1;
     constexpr int WAVES_M = 4 / WAVES_N;
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int64_t M = (int64_t)p.B * p.TH * p.TW;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
+    if (m0 >= M) return;  // uniform per block (multi-descriptor launches are sized for the largest member)
     const int n0 = blockIdx.y * BN;
     const int w_rows = p.w_rows;
 
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
     int niter_all = 0;
     for (int s = 0; s < p.nsrc; ++s) niter_all += p.ntaps * (p.src[s].C / KCV);
     // split-K: blockIdx.z owns K iterations [it0, it1); partial sums go to an f32 workspace with atomics
-    const int it0 = (int)((int64_t)niter_all * blockIdx.z / gridDim.z), it1 = (int)((int64_t)niter_all * (blockIdx.z + 1) / gridDim.z);
+    const int it0 = (int)((int64_t)niter_all * zi / nz), it1 = (int)((int64_t)niter_all * (zi + 1) / nz);
     const int niter = it1 - it0;
 
     // K-walk state: source s, tap t, channel offset c0; srcoff = packed-weight offset of source s
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
 
     // ---- epilogue: v = act(acc + bias + addend) * act'(actout) ----
     const int r = lane & 31, h = lane >> 5;
-    if (gridDim.z > 1) {
+    if (nz > 1) {
         // split-K partial: raw accumulators into ws[m][n] (f32 atomics: 32 lanes = 128 contiguous bytes per row)
         if constexpr (!SWAP) {
             float* ws = p.splitk_ws;
@@ -395,6 +396,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
                 }
         }
     }
+}
+
+template <typename T, int BN, bool SWAP>
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_conv_t p) {
+    conv_igemm_body<T, BN, SWAP>(p, blockIdx.z, gridDim.z);
+}
+
+// Up to four independent launches of the same shape family in ONE grid (blockIdx.z = member): the four output-parity
+// classes of a stride-2 data gradient, which are otherwise four small latency-bound launches.
+struct falnet_conv4_t { falnet_conv_t c[4]; };
+template <typename T, int BN>
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_multi_kernel(const falnet_conv4_t pp) {
+    conv_igemm_body<T, BN, false>(pp.c[blockIdx.z], 0, 1);
 }
 
 // split-K epilogue: ws[m][n] (f32 sums) -> bias / residual / activation / activation-gradient -> NHWC output
@@ -1515,6 +1529,42 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         if (p.dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(eg), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(eg), dim3(256), 0, st, p);
     }
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream) {
+    FALNET_CHECK_ARG(descs && n >= 1 && n <= 4, "conv2d_multi: 1..4 descriptors");
+    falnet_conv4_t pp;
+    int64_t maxM = 0;
+    ConvChoice c0;
+    for (int i = 0; i < n; ++i) {
+        const falnet_conv_t& p = descs[i];
+        FALNET_CHECK_ARG(p.dtype == descs[0].dtype && p.w_rows == descs[0].w_rows && p.Cout == descs[0].Cout && p.out_layout == FALNET_OUT_NHWC &&
+                         p.ksplit <= 1 && p.nsrc >= 1 && p.nsrc <= 2 && p.weight && p.out && p.ntaps >= 1 && p.ntaps <= 9,
+                         "conv2d_multi: members must share dtype / Cout / w_rows and be plain NHWC gather launches");
+        for (int s = 0; s < p.nsrc; ++s)
+            if (int r = check_src(p.src[s], p.dtype == FALNET_BF16 ? 32 : 16, "conv2d_multi")) return r;
+        ConvChoice c;
+        falnet_conv_t q = p;
+        q.variant = 1;
+        if (int r = choose_conv_kernel(q, c)) return r;
+        if (i == 0) c0 = c;
+        const int64_t M = (int64_t)p.B * p.TH * p.TW;
+        maxM = M > maxM ? M : maxM;
+        pp.c[i] = p;
+    }
+    for (int i = n; i < 4; ++i) pp.c[i] = descs[0];
+    const dim3 grid((unsigned)((maxM + CONV_BM - 1) / CONV_BM), (unsigned)((descs[0].Cout + c0.bn - 1) / c0.bn), (unsigned)n);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_MULTI(T)                                                                                              \
+    do {                                                                                                             \
+        if (c0.bn == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 128>), grid, dim3(CONV_THREADS), 0, st, pp); \
+        else if (c0.bn == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 64>), grid, dim3(CONV_THREADS), 0, st, pp); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 32>), grid, dim3(CONV_THREADS), 0, st, pp);  \
+    } while (0)
+    if (descs[0].dtype == FALNET_BF16) LAUNCH_MULTI(bf16_t);
+    else LAUNCH_MULTI(float);
+#undef LAUNCH_MULTI
     FALNET_RETURN_LAUNCH();
 }
 

@@ -168,7 +168,8 @@ def _fill_taps(d, taps):
 
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
-              act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0):
+              act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
+              autotune=True):
     """Build one falnet_conv2d launch; returns a zero-argument callable."""
     lib = L.lib()
     d = L.Conv()
@@ -196,7 +197,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout, ws)
-    if AUTOTUNE and out_layout == L.OUT_NHWC and out.is_cuda:
+    if AUTOTUNE and autotune and out_layout == L.OUT_NHWC and out.is_cuda:
         d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
 
     def launch(_keep=keep):
@@ -219,6 +220,23 @@ def _splitk_workspace(device, nbytes=32 << 20):
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]
+
+
+def conv_multi_call(calls, name="conv multi"):
+    """Fuse up to four conv_call launches (built with autotune off: gather kernel) into one falnet_conv2d_multi."""
+    lib = L.lib()
+    n = len(calls)
+    arr = (L.Conv * n)()
+    for i, c in enumerate(calls):
+        C.memmove(C.byref(arr[i]), C.byref(c.desc), C.sizeof(L.Conv))
+        arr[i].variant, arr[i].ksplit = 1, 1
+    keep = (arr, calls)
+    dn = "DF16b" if arr[0].dtype == L.BF16 else "f"
+    bn = 128 if (arr[0].w_rows % 128 == 0 and arr[0].Cout > 64) else (64 if (arr[0].w_rows % 64 == 0 and arr[0].Cout > 32) else 32)
+
+    def launch(_keep=keep):
+        L.check(lib.falnet_conv2d_multi(arr, n, L.stream_ptr()), name)
+    return _timed(f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t", sum(c.flops for c in calls), 0, launch, name)
 
 
 def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):

@@ -97,6 +97,9 @@ typedef struct {
                                   -2 is returned when the variant does not apply */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
+/* n <= 4 gather launches of one family (same dtype / Cout / packed rows, NHWC output, no split-K) in ONE grid:
+ * the four output-parity classes of a stride-2 data gradient */
+int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream);
 /* symbol (as rocprofv3 reports it) of the kernel falnet_conv2d launches for this descriptor */
 int falnet_conv2d_kernel_name(const falnet_conv_t* p, char* buf, int len);
 
