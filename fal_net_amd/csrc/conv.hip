@@ -1412,9 +1412,9 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
     int variant = p.variant;
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG(variant >= 0 && variant <= 7, "conv2d: unknown variant %d", variant);
-    if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || ((variant == 3 || variant == 5 || variant == 6) && ctot / (64 / esz) < 2) ||
-                         (variant >= 6 && p.OH < 16))) {
+    FALNET_CHECK_ARG(variant >= 0 && variant <= 9, "conv2d: unknown variant %d", variant);
+    if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || ((variant == 3 || variant == 5 || variant == 6 || variant == 8) && ctot / (64 / esz) < 2) ||
+                         ((variant == 6 || variant == 7) && p.OH < 16))) {
         falnet_set_error("conv2d: variant %d not applicable to this launch", variant);
         return -2;
     }
@@ -1433,15 +1433,16 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.kcb = 64; c.tps = 1; c.adb = 0; c.th = 0; c.nwaves = 4;
         return 0;
     }
-    c.th = variant >= 6 ? 16 : 8;
-    c.nwaves = variant >= 6 ? 8 : 4;
+    c.th = variant >= 8 ? 4 : (variant >= 6 ? 16 : 8);  // variants 8/9: 4x32-position blocks for small images (more workgroups)
+    c.nwaves = (variant == 6 || variant == 7) ? 8 : 4;
     const int tiles = p.B * ((p.OW + PT_TW - 1) / PT_TW) * ((p.OH + c.th - 1) / c.th);
     const bool bn128 = p.w_rows % 128 == 0 && p.Cout > 64 && (c.th == 16 || tiles >= 256);
     switch (variant) {
         case 2: c.bn = bn128 ? 128 : (bn64 ? 64 : 32); c.kcb = 128; c.tps = 1; c.adb = ctot / (128 / esz) > 1; break;
         case 3: case 6: c.bn = bn128 ? 128 : (bn64 ? 64 : 32); c.kcb = 64; c.tps = 1; c.adb = 1; break;
+        case 8: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 1; c.adb = 1; break;
         case 5: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 9; c.adb = 1; break;
-        default: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 9; c.adb = 0; break;  // 4, 7
+        default: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 9; c.adb = 0; break;  // 4, 7, 9
     }
     return 0;
 }
@@ -1499,7 +1500,9 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     TRY_PATCH(T, 64, 64, 9, false, 8, 4) TRY_PATCH(T, 32, 64, 9, false, 8, 4)                                             \
     TRY_PATCH(T, 64, 64, 9, true, 8, 4) TRY_PATCH(T, 32, 64, 9, true, 8, 4)                                               \
     TRY_PATCH(T, 128, 64, 1, true, 16, 8) TRY_PATCH(T, 64, 64, 1, true, 16, 8) TRY_PATCH(T, 32, 64, 1, true, 16, 8)      \
-    TRY_PATCH(T, 64, 64, 9, false, 16, 8) TRY_PATCH(T, 32, 64, 9, false, 16, 8)
+    TRY_PATCH(T, 64, 64, 9, false, 16, 8) TRY_PATCH(T, 32, 64, 9, false, 16, 8)                                           \
+    TRY_PATCH(T, 64, 64, 1, true, 4, 4) TRY_PATCH(T, 32, 64, 1, true, 4, 4)                                               \
+    TRY_PATCH(T, 64, 64, 9, false, 4, 4) TRY_PATCH(T, 32, 64, 9, false, 4, 4)
         if (p.dtype == FALNET_BF16) { PATCH_TABLE(bf16_t) } else { PATCH_TABLE(float) }
 #undef PATCH_TABLE
 #undef TRY_PATCH

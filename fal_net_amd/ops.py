@@ -239,7 +239,7 @@ def conv_multi_call(calls, name="conv multi"):
     return _timed(f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t", sum(c.flops for c in calls), 0, launch, name)
 
 
-def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
+def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=5):
     """Fastest (variant, ksplit) for this launch.  Candidates: gather (with split-K when the launch would
     otherwise occupy only a fraction of the 256 CUs), and the halo-patch variants where applicable."""
     st = L.stream_ptr()
@@ -249,11 +249,14 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     if wgs < 256 and M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
         cands += [(1, k) for k in (2, 4, 8, 16) if wgs * k <= 2048]
     cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1)]
+    if wgs < 512:
+        cands += [(8, 1), (9, 1)]
     best, best_t = (1, 1), None
     for v, k in cands:
         d.variant, d.ksplit = v, k
         if lib.falnet_conv2d(ref, st) != 0:  # -2: variant not applicable to this launch
             continue
+        lib.falnet_conv2d(ref, st)  # second warm-up: caches / clocks settled before timing
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

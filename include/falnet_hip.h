@@ -93,7 +93,7 @@ typedef struct {
     int64_t splitk_ws_bytes;
     int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
-                                  6/7 = 3/4 on a 16x32-position block with 8 waves;
+                                  6/7 = 3/4 on a 16x32-position block with 8 waves, 8/9 = 3/4 on a 4x32 block;
                                   -2 is returned when the variant does not apply */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);

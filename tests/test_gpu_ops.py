@@ -154,7 +154,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 8):
+    for variant in range(1, 10):
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
