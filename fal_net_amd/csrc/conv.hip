@@ -1278,6 +1278,32 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
 // One block = one 32(cout) x 32(packed cin) tile of one layer, all taps, staged through LDS: the OIHW reads are
 // runs of taps*32 contiguous floats, the wf rows ([co][tap][32 cin]) and wd rows ([cin][tap][32 cout]) are written as
 // 32 contiguous elements.  (The element-per-thread version gathered with stride `taps` and scattered 2-byte writes.)
+template <typename T, int TAPS>
+__device__ __forceinline__ void pack_tile(const falnet_pack_t& d, int rel, float (&tile)[32][32 * 9 + 1]) {
+    const int ctiles = d.cin_pad / 32;
+    const int co0 = (rel / ctiles) * 32, cp0 = (rel % ctiles) * 32;
+    constexpr int rowlen = 32 * TAPS;
+    // packed columns cp0..cp0+31 map to a contiguous run of real channels (group boundaries are multiples of 32)
+    const int ci0 = cp0 < d.c0_pad ? cp0 : d.c0_real + (cp0 - d.c0_pad);
+    const int ci_end = cp0 < d.c0_pad ? d.c0_real : d.cin;   // exclusive bound of valid real channels for this tile
+    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
+        const int r = e / rowlen, k = e % rowlen;            // r: cout row of the tile, k = cil*TAPS + t
+        const int co = co0 + r, ci = ci0 + k / TAPS;
+        tile[r][k] = (co < d.cout && ci < ci_end) ? d.w[((int64_t)co * d.cin + ci0) * TAPS + k] : 0.f;
+    }
+    __syncthreads();
+    T* wf = reinterpret_cast<T*>(d.wf);
+    T* wd = reinterpret_cast<T*>(d.wd);
+    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
+        const int c = e % 32, t = (e / 32) % TAPS, r = e / (32 * TAPS);
+        if (wf) wf[((int64_t)(co0 + r) * TAPS + t) * d.cin_pad + cp0 + c] = from_f32<T>(tile[r][c * TAPS + t]);       // r = cout row, c = cin
+        if (wd) wd[((int64_t)(cp0 + r) * TAPS + t) * d.cout_pad + co0 + c] = from_f32<T>(tile[c][r * TAPS + t]);      // r = cin row, c = cout
+    }
+}
+
+// One block = one 32(cout) x 32(packed cin) tile of one layer, all taps, staged through LDS: the OIHW reads are
+// runs of taps*32 contiguous floats, the wf rows ([co][tap][32 cin]) and wd rows ([cin][tap][32 cout]) are written as
+// 32 contiguous elements.  taps is 9 or 1 (compile-time divisions).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_pack_t* __restrict__ descs, int n) {
     __shared__ float tile[32][32 * 9 + 1];
@@ -1285,29 +1311,12 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
     const int li = find_entry(descs, n, entry_begin);
     const falnet_pack_t d = descs[li];
     const int rel = blockIdx.x - d.block_begin;
-    const int ctiles = d.cin_pad / 32;
-    const int co0 = (rel / ctiles) * 32, cp0 = (rel % ctiles) * 32;
-    const int taps = d.taps, rowlen = 32 * taps;
-    // packed columns cp0..cp0+31 map to a contiguous run of real channels (group boundaries are multiples of 32)
-    const int ci0 = cp0 < d.c0_pad ? cp0 : d.c0_real + (cp0 - d.c0_pad);
-    const int ci_end = cp0 < d.c0_pad ? d.c0_real : d.cin;   // exclusive bound of valid real channels for this tile
-    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
-        const int r = e / rowlen, k = e % rowlen;            // r: cout row of the tile, k = cil*taps + t
-        const int co = co0 + r, ci = ci0 + k / taps;
-        tile[r][k] = (co < d.cout && ci < ci_end) ? d.w[((int64_t)co * d.cin + ci0) * taps + k] : 0.f;
-    }
-    __syncthreads();
-    T* wf = reinterpret_cast<T*>(d.wf);
-    T* wd = reinterpret_cast<T*>(d.wd);
-    for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
-        const int c = e % 32, t = (e / 32) % taps, r = e / (32 * taps);
-        if (wf) wf[((int64_t)(co0 + r) * taps + t) * d.cin_pad + cp0 + c] = from_f32<T>(tile[r][c * taps + t]);       // r = cout row, c = cin
-        if (wd) wd[((int64_t)(cp0 + r) * taps + t) * d.cout_pad + co0 + c] = from_f32<T>(tile[c][r * taps + t]);      // r = cin row, c = cout
-    }
+    if (d.taps == 9) pack_tile<T, 9>(d, rel, tile);
+    else pack_tile<T, 1>(d, rel, tile);
 }
 
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
-    FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "pack_weights_batched: bad argument");
+    FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9 or 1, n <= 64)");
     if (dtype == FALNET_BF16)
         hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
     else

@@ -152,19 +152,31 @@ class FalnetPlan:
                 gin, IH, IW, cg, gin.shape[3], addend=addend, actout=actout, actout_kind=kind,
                 weight_offset_elems=off, name="dgrad " + name, flops=fl1 * pc.taps))
         else:
-            # the four output-parity classes of the stride-2 data gradient go out as ONE launch (blockIdx.z = class)
-            members = []
+            # the four output-parity classes of the stride-2 data gradient: ONE launch (blockIdx.z = class) or, for
+            # the tiny bottleneck layers where split-K matters more, four separately autotuned launches -- timed here
+            members, singles = [], []
             for py in range(2):
                 for px in range(2):
                     th, tw = (IH - py + 1) // 2, (IW - px + 1) // 2
                     if th <= 0 or tw <= 0:
                         continue
-                    members.append(ops.conv_call(
-                        self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th,
-                        tw, gin, IH, IW, cg, gin.shape[3], out_step=(2, 2, py, px), addend=addend, actout=actout,
-                        actout_kind=kind, weight_offset_elems=off, name=f"dgrad{py}{px} " + name,
-                        flops=fl1 * len(ops.dgrad_taps_s2(py, px)), autotune=False))
-            self.bwd_body.append(ops.conv_multi_call(members, name="dgrad(s2 x4) " + name))
+                    args = (self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th, tw, gin, IH, IW,
+                            cg, gin.shape[3])
+                    kw = dict(out_step=(2, 2, py, px), addend=addend, actout=actout, actout_kind=kind, weight_offset_elems=off,
+                              name=f"dgrad{py}{px} " + name, flops=fl1 * len(ops.dgrad_taps_s2(py, px)))
+                    members.append(ops.conv_call(*args, autotune=False, **kw))
+                    singles.append(ops.conv_call(*args, **kw))
+            multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
+
+            def separate(calls=tuple(singles)):
+                for c in calls:
+                    c()
+            import os as _os
+            chosen = ops.best_of(multi, separate) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
+            if chosen is multi:
+                self.bwd_body.append(multi)
+            else:
+                self.bwd_body.extend(singles)
 
     def _wgrad(self, pc, srcs, IH, IW, gout, name=""):
         OH, OW = gout.shape[1], gout.shape[2]

@@ -18,8 +18,11 @@ pc.pack_call()()
 srcs_t = [torch.randn(B, H, W, ops.pad_c(g), device=DEV).to(dtype) for g in groups]
 if kind == "conv":
     out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
+    addend = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if os.environ.get("ADD") == "1" else None
+    actout = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if os.environ.get("ACTOUT") == "1" else None
     call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
-                         H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU)
+                         H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU if actout is None else L.ACT_NONE, addend=addend,
+                         actout=actout, actout_kind=L.ACT_ELU if actout is not None else L.ACT_NONE)
     call.desc.variant = int(sys.argv[6])
     run = call
 else:
