@@ -112,8 +112,11 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
 
     from fal_net_amd import loss_functions as LF
@@ -215,10 +218,12 @@ def main():
         result["kernel_breakdown_ms_per_step"] = {t: round(a["ms"] / 3, 4) for t, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.height, args.width, args.levels)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's banner sits in the C stdio buffer: flush it so the JSON is the LAST line
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

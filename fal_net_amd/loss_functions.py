@@ -33,6 +33,7 @@ class _VggPlan:
         self.busy = False
         code = L.dtype_code(dtype)
         self.fwd, self.bwd = [], []
+        _conv = lambda *a, **kw: ops.conv_call(*a, ws_owner=("vgg", id(self)), **kw)  # own split-K scratch per plan instance
         pcs = owner._packed
         x_in = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
         x0 = torch.empty(B, H, W, ops.pad_c(3), dtype=dtype, device=device)
@@ -44,7 +45,7 @@ class _VggPlan:
             for idx in convs:
                 pc = pcs[idx]
                 y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device)
-                self.fwd.append(ops.conv_call(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
+                self.fwd.append(_conv(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
                                               1, B, h, w, y, h, w, pc.cout, pc.cout, bias=pc.bias, act=L.ACT_RELU,
                                               name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9))
                 acts.append((pc, cur, y, h, w))
@@ -74,7 +75,7 @@ class _VggPlan:
                 if x is x0:
                     # first conv: data gradient wrt the 3-channel image
                     gin = torch.empty(B, h, w, ops.pad_c(3), dtype=dtype, device=device)
-                    self.bwd.append(ops.conv_call(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
+                    self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
                                                   ops.pad_c(3), 1, B, h, w, gin, h, w, ops.pad_c(3), ops.pad_c(3), name="vgg dgrad0",
                                                   flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.g_in = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
@@ -85,7 +86,7 @@ class _VggPlan:
                     # but a pooled map's gradient must NOT be masked -> only mask when x came from a conv)
                     from_pool = any(x is o for o in self.outs)
                     gin = torch.empty_like(x)
-                    self.bwd.append(ops.conv_call(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
+                    self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
                                                   pc.cin_pad, 1, B, h, w, gin, h, w, pc.cin_pad, pc.cin_pad,
                                                   actout=None if from_pool else x,
                                                   actout_kind=L.ACT_NONE if from_pool else L.ACT_RELU, name="vgg dgrad",

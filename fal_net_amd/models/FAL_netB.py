@@ -118,6 +118,10 @@ class FalnetPlan:
         self._build()
 
     # ---- helpers ----
+    def _conv_call(self, *a, **kw):
+        """ops.conv_call with this plan's own split-K scratch (plans run concurrently on different streams)."""
+        return ops.conv_call(*a, ws_owner=("falnet", id(self)), **kw)
+
     def _act(self, name, h, w, c):
         t = torch.empty(self.B, h, w, c, dtype=self.dtype, device=self.device)
         self.buf[name] = t
@@ -131,7 +135,7 @@ class FalnetPlan:
     def _conv_fwd(self, pc, srcs, IH, IW, out, act, addend=None, name=""):
         B = self.B
         OH, OW = out.shape[1], out.shape[2]
-        self.fwd.append(ops.conv_call(self.dtype, srcs, IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(pc.ksize), pc.taps,
+        self.fwd.append(self._conv_call(self.dtype, srcs, IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(pc.ksize), pc.taps,
                                       pc.cout_pad, pc.stride, B, OH, OW, out, OH, OW, out.shape[3], out.shape[3],
                                       bias=pc.bias, addend=addend, act=act, name="fwd " + name,
                                       flops=2 * B * OH * OW * pc.cout * pc.cin * pc.taps))
@@ -147,7 +151,7 @@ class FalnetPlan:
         src = [ops.nhwc_src(gout)]
         fl1 = 2 * B * OH * OW * pc.cout * pc.groups_real[group]  # algorithmic flops per tap
         if pc.stride == 1:
-            self.bwd_body.append(ops.conv_call(
+            self.bwd_body.append(self._conv_call(
                 self.dtype, src, OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(pc.ksize), pc.taps, cg, 1, B, IH, IW,
                 gin, IH, IW, cg, gin.shape[3], addend=addend, actout=actout, actout_kind=kind,
                 weight_offset_elems=off, name="dgrad " + name, flops=fl1 * pc.taps))
@@ -164,8 +168,8 @@ class FalnetPlan:
                             cg, gin.shape[3])
                     kw = dict(out_step=(2, 2, py, px), addend=addend, actout=actout, actout_kind=kind, weight_offset_elems=off,
                               name=f"dgrad{py}{px} " + name, flops=fl1 * len(ops.dgrad_taps_s2(py, px)))
-                    members.append(ops.conv_call(*args, autotune=False, **kw))
-                    singles.append(ops.conv_call(*args, **kw))
+                    members.append(self._conv_call(*args, autotune=False, **kw))
+                    singles.append(self._conv_call(*args, **kw))
             multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
 
             def separate(calls=tuple(singles)):
@@ -180,10 +184,12 @@ class FalnetPlan:
 
     def _wgrad(self, pc, srcs, IH, IW, gout, name=""):
         OH, OW = gout.shape[1], gout.shape[2]
+        self._buckets_seen = getattr(self, "_buckets_seen", set()) | {self._bucket}
         gw = self.model._grad_view(pc.weight)
         gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
         call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
-                               pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps)
+                               pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
+                               bucket=self._bucket)
         self._side_call(call)
 
     def _side_call(self, call):
@@ -262,7 +268,7 @@ class FalnetPlan:
         # ---- 1x1 conv0 -> planar f32 logits, MED head ----
         pc0 = pcs["conv0_1x1"]
         dlog0 = self._f32("dlog0", B, N, H, W)
-        self.fwd.append(ops.conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
+        self.fwd.append(self._conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
                                       1, B, H, W, dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pc0.bias,
                                       name="fwd conv0(1x1)", flops=2 * B * H * W * N * N))
         disp, pan, stats = self._f32("disp", B, 1, H, W), self._f32("p_im0", B, 3, H, W), self._f32("stats", B, 4, H, W)
@@ -285,6 +291,12 @@ class FalnetPlan:
                                    L.ptr(g_pan if has_pan else None), L.ptr(g_dlog0), B, N, H, W,
                                    nbytes=(2 * N + 7) * H * W * 4 * B)
         self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
+        # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
+        # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: encoder levels 0-3.  After a bucket's
+        # last wgrad its slab reduce / bias-gradient launches run and model._bucket_ready(i) lets the trainer start that
+        # bucket's share of the step's all-reduce while backward continues.
+        self._bucket = 0
+        self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
         G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, NHWC
         self.bwd_body.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(g_dlog0), L.ptr(G0), B, N, H, W, pad_c(N), code))
         self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
@@ -320,8 +332,12 @@ class FalnetPlan:
             if lvl < 6:
                 g_ipre[lvl + 1] = tgt
         # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)
+        self._finish.append((0, len(self.bwd_body)))
         # encoder, bottom (level 6) to top (level 0)
         for i in range(6, -1, -1):
+            if i == 3:
+                self._finish.append((1, len(self.bwd_body)))
+            self._bucket = 1 if i >= 4 else 2
             cname, rname, ch = _ENC[i]
             hh, ww = sizes[i]
             gz = gc[i]
@@ -336,10 +352,24 @@ class FalnetPlan:
             self._wgrad(pcc, srcs, ih, iw, g_a, name=cname)
             if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                 self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
-        # one batched slab reduce + one batched bias-gradient launch for all layers, after the last wgrad
-        reduce_all, bias_all = self.wbatch.finalize()
-        self._side_call(reduce_all)
-        self._side_call(bias_all)
+        self._finish.append((2, len(self.bwd_body)))
+        # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
+        # trainer's hook (asynchronous all-reduce of that range of the flat gradient buffer)
+        finals = self.wbatch.finalize()
+        body, self.bwd_body = self.bwd_body, []
+        pos = 0
+        for bucket, at in self._finish:
+            self.bwd_body.extend(body[pos:at])
+            pos = at
+            if bucket in finals:
+                red, bias = finals[bucket]
+
+                def finish(red=red, bias=bias, bucket=bucket):
+                    red()
+                    bias()
+                    self.model._bucket_ready(bucket)
+                self._side_call(finish)
+        self.bwd_body.extend(body[pos:])
 
     # ---- execution ----
     def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
@@ -465,6 +495,24 @@ class FAL_net(nn.Module):
         self._gviews = {id(p): self._flat_grad[off:off + p.numel()].view(p.shape) for (n, p), off in zip(named, self._offsets)}
         self._plans = {}
         self._build_packed()
+
+    def gradient_buckets(self):
+        """Contiguous element ranges of the flat gradient buffer, in the order backward finalises them."""
+        named = self._trainable_named()
+        first = {}
+        for (n, p), off in zip(named, self._offsets):
+            if n.startswith("backbone.deconv6"):
+                first.setdefault("dec", off)
+            if n.startswith("backbone.conv4."):
+                first.setdefault("enc4", off)
+        total = self._flat.numel()
+        return [(first["dec"], total), (first["enc4"], first["dec"]), (0, first["enc4"])]
+
+    def _bucket_ready(self, bucket):
+        hook = getattr(self, "bucket_hook", None)
+        if hook is not None:
+            lo, hi = self.gradient_buckets()[bucket]
+            hook(bucket, self._flat_grad[lo:hi])
 
     def flat_parameters(self):
         return self._flat

@@ -169,7 +169,7 @@ def _fill_taps(d, taps):
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
               act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
-              autotune=True):
+              autotune=True, ws_owner=None):
     """Build one falnet_conv2d launch; returns a zero-argument callable."""
     lib = L.lib()
     d = L.Conv()
@@ -192,7 +192,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.dtype = L.dtype_code(dtype)
     d.variant = 0
     d.ksplit = 1
-    ws = _splitk_workspace(out.device) if out.is_cuda and out_layout == L.OUT_NHWC else None
+    ws = _splitk_workspace(out.device, ws_owner) if out.is_cuda and out_layout == L.OUT_NHWC else None
     d.splitk_ws = 0 if ws is None else ws.data_ptr()
     d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
     ref = C.byref(d)
@@ -214,9 +214,10 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
 _SPLITK_WS = {}
 
 
-def _splitk_workspace(device, nbytes=32 << 20):
-    """Per-device f32 scratch shared by all split-K conv launches (they are stream-ordered)."""
-    key = (device.type, device.index)
+def _splitk_workspace(device, owner=None, nbytes=32 << 20):
+    """f32 scratch for split-K conv launches.  One buffer per (device, owner): launches that share a buffer must be
+    stream-ordered, and different plans (backbone, each VGG plan instance) run concurrently on different streams."""
+    key = (device.type, device.index, owner)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]
@@ -359,7 +360,7 @@ class WgradBatch:
         self.items, self.bias = [], []
         self.ws = None
 
-    def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0):
+    def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0, bucket=0):
         lib = L.lib()
         d = L.Wgrad()
         d.nsrc = len(srcs)
@@ -391,56 +392,66 @@ class WgradBatch:
         def launch(_keep=keep):
             L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
         c0_real, c0_pad = pc.group_channels()
-        self.items.append(dict(d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
+        self.items.append(dict(bucket=bucket, d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
         if grad_b is not None:
-            self.bias.append(dict(g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
+            self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
         sym = f"_Z21wgrad3x3_patch_kernelI{tn}Ev14falnet_wgrad_tiiii" if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 
     def finalize(self):
-        """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables."""
+        """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables.
+        Returns {bucket: (reduce_call, bias_call)}: one batched slab reduce and one batched bias-gradient launch per
+        gradient bucket (buckets are finalised -- and all-reduced -- as backward passes them)."""
         lib = L.lib()
         total = sum((it["bytes"] + 255) // 256 * 256 for it in self.items)
         self.ws = torch.empty(max(total, 256) // 4, dtype=torch.float32, device=self.device)
-        red = (L.ReduceDesc * len(self.items))()
-        off, blk = 0, 0
-        for i, it in enumerate(self.items):
+        off = 0
+        for it in self.items:
             it["d"].partial = self.ws.data_ptr() + off
-            blocks = it["cout"] * ((it["cin_total"] + 63) // 64)
-            groups = 1
-            if it["nsplit"] >= 16 and blocks < 1024:
-                groups = (1024 + blocks - 1) // blocks
-            groups = max(1, min(groups, it["nsplit"] // 8))
-            r = red[i]
-            r.partial, r.grad = self.ws.data_ptr() + off, it["grad"].data_ptr()
-            r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
-            r.cout, r.cin, r.c0_real, r.c0_pad, r.groups, r.block_begin = it["cout"], it["cin"], it["c0_real"], it["c0_pad"], groups, blk
-            blk += blocks * groups
+            it["partial"] = self.ws.data_ptr() + off
             off += (it["bytes"] + 255) // 256 * 256
-        self.red_dev = torch.frombuffer(bytearray(bytes(red)), dtype=torch.uint8).to(self.device)
-        n_red, red_blocks = len(self.items), blk
-        bias = (L.BiasGradDesc * max(len(self.bias), 1))()
-        blk = 0
-        for i, it in enumerate(self.bias):
-            segs = it["gC"] // 8
-            rows = 256 // min(segs, 256)
-            blocks = int(max(1, min(256, (it["npix"] + rows * 64 - 1) // (rows * 64))))
-            b = bias[i]
-            b.g, b.db, b.npix, b.gC, b.cout, b.blocks, b.block_begin = it["g"].data_ptr(), it["db"].data_ptr(), it["npix"], it["gC"], it["cout"], blocks, blk
-            blk += blocks
-        self.bias_dev = torch.frombuffer(bytearray(bytes(bias)), dtype=torch.uint8).to(self.device)
-        n_bias, bias_blocks, code = len(self.bias), blk, L.dtype_code(self.dtype)
+        out, self._tables = {}, []
+        code = L.dtype_code(self.dtype)
+        for bucket in sorted({it["bucket"] for it in self.items}):
+            items = [it for it in self.items if it["bucket"] == bucket]
+            red = (L.ReduceDesc * len(items))()
+            blk = 0
+            for i, it in enumerate(items):
+                blocks = it["cout"] * ((it["cin_total"] + 63) // 64)
+                groups = 1
+                if it["nsplit"] >= 16 and blocks < 1024:
+                    groups = (1024 + blocks - 1) // blocks
+                groups = max(1, min(groups, it["nsplit"] // 8))
+                r = red[i]
+                r.partial, r.grad = it["partial"], it["grad"].data_ptr()
+                r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
+                r.cout, r.cin, r.c0_real, r.c0_pad, r.groups, r.block_begin = it["cout"], it["cin"], it["c0_real"], it["c0_pad"], groups, blk
+                blk += blocks * groups
+            red_dev = torch.frombuffer(bytearray(bytes(red)), dtype=torch.uint8).to(self.device)
+            biases = [b for b in self.bias if b["bucket"] == bucket]
+            bias = (L.BiasGradDesc * max(len(biases), 1))()
+            bblk = 0
+            for i, it in enumerate(biases):
+                segs = it["gC"] // 8
+                rows = 256 // min(segs, 256)
+                blocks = int(max(1, min(256, (it["npix"] + rows * 64 - 1) // (rows * 64))))
+                b = bias[i]
+                b.g, b.db, b.npix, b.gC, b.cout, b.blocks, b.block_begin = it["g"].data_ptr(), it["db"].data_ptr(), it["npix"], it["gC"], it["cout"], blocks, bblk
+                bblk += blocks
+            bias_dev = torch.frombuffer(bytearray(bytes(bias)), dtype=torch.uint8).to(self.device)
+            self._tables += [red_dev, bias_dev]
 
-        def reduce_all():
-            L.check(lib.falnet_wgrad_reduce_batched(L.ptr(self.red_dev), n_red, red_blocks, L.stream_ptr()), "wgrad_reduce_batched")
+            def reduce_all(red_dev=red_dev, n=len(items), blocks=blk):
+                L.check(lib.falnet_wgrad_reduce_batched(L.ptr(red_dev), n, blocks, L.stream_ptr()), "wgrad_reduce_batched")
 
-        def bias_all():
-            if n_bias:
-                L.check(lib.falnet_bias_grad_batched(L.ptr(self.bias_dev), n_bias, bias_blocks, code, L.stream_ptr()), "bias_grad_batched")
-        return (_timed("wgrad_reduce_batched", 0, 0, reduce_all, "wgrad_reduce_batched"),
-                _timed("bias_grad_batched", 0, 0, bias_all, "bias_grad_batched"))
+            def bias_all(bias_dev=bias_dev, n=len(biases), blocks=bblk):
+                if n:
+                    L.check(lib.falnet_bias_grad_batched(L.ptr(bias_dev), n, blocks, code, L.stream_ptr()), "bias_grad_batched")
+            out[bucket] = (_timed("wgrad_reduce_batched", 0, 0, reduce_all, "wgrad_reduce_batched"),
+                           _timed("bias_grad_batched", 0, 0, bias_all, "bias_grad_batched"))
+        return out
 
 
 def simple_call(fn_name, *args, name=None, nbytes=0):

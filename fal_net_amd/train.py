@@ -11,6 +11,10 @@ from . import _lib as L
 from .loss_functions import rec_loss_fnc, smoothness, vgg
 
 
+import os as _os
+_FORCE_DIST = _os.environ.get("FALNET_FORCE_DIST") == "1"  # exercise the collective path with world_size 1 (tests)
+
+
 class FlatAdam:
     """Adam(betas, eps, weight_decay=0) over `model.flat_parameters()` (torch.optim.Adam semantics).
 
@@ -46,13 +50,34 @@ class FlatAdam:
                                              b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
 
 
+def enable_overlapped_allreduce(model):
+    """Install the bucket hook: as backward finalises each contiguous range of the flat gradient buffer (decoder first,
+    deep encoder levels next, the small shallow levels last) its share of the step's all-reduce is launched
+    asynchronously (RCCL stream) while backward continues.  Logically still ONE sum over the flat buffer per step."""
+    if getattr(model, "bucket_hook", None) is not None or getattr(model, "_no_overlap", False):
+        return
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DIST):
+        return
+    model._pending_reduces = []
+
+    def hook(bucket, flat_slice):
+        model._pending_reduces.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True))
+    model.bucket_hook = hook
+
+
 def allreduce_gradients(model):
-    """The step's single collective: sum of the flat f32 gradient buffer over ranks (RCCL over xGMI).
-    Returns the scale (1/world) to fold into the optimiser."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """The step's single collective: sum of the flat f32 gradient buffer over ranks (RCCL over xGMI), pipelined in
+    buckets behind backward when the hook is installed.  Returns the scale (1/world) to fold into the optimiser."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DIST):
+        return 1.0
+    pending = getattr(model, "_pending_reduces", None)
+    if pending:
+        for w in pending:
+            w.wait()  # current stream waits for the collective
+        pending.clear()
+    else:
         dist.all_reduce(model.flat_gradients(), op=dist.ReduceOp.SUM)
-        return 1.0 / dist.get_world_size()
-    return 1.0
+    return 1.0 / dist.get_world_size()
 
 
 _AUX_STREAMS = {}
@@ -88,6 +113,7 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
     """One iteration of Train_Stage1_K.py:233-262 (forward, VGG, losses, backward, all-reduce, Adam).
     Returns device scalars (no host sync)."""
     opt.zero_grad()
+    enable_overlapped_allreduce(model)
     W = left.shape[3]
     min_disp = max_disp * min_disp_arg / max_disp_arg  # :237
     join_vgg = vgg_label_async(right) if a_p > 0 else None  # :241-244, overlapped with the model forward
@@ -118,6 +144,7 @@ class GraphedStage1Step:
         self.model, self.opt, self.kw = model, opt, kw
         self.left, self.right, self.max_disp = left, right, max_disp
         self.multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        model._no_overlap, model.bucket_hook = True, None  # collectives are not captured: one eager all-reduce after the graph
         s = torch.cuda.Stream(device=left.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):  # warm-up off the default stream: builds plans, autotunes, allocates optimiser state

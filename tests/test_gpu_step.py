@@ -151,3 +151,20 @@ def test_bf16_step_runs_and_tracks_f32():
           float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)))
     assert abs(l16 - l32) / l32 < 2e-2
     assert float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)) > 0.98
+
+
+def test_collective_path_world1(tmp_path):
+    """The N>1 code path on one GPU: RCCL process group of size 1, bucketed asynchronous all-reduce behind backward,
+    1/world folded into Adam -- the step must reproduce the single-process result."""
+    import subprocess, sys, json
+    env = dict(os.environ, FALNET_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    outs = []
+    for e in (env, dict(os.environ)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64",
+                            "--width", "128", "--no-cpu-baseline", "--no-roofline", "--dtype", "f32"], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+        assert r.stdout.strip().splitlines()[-1] == line  # the JSON is the last line even with RCCL's banner
+        outs.append(json.loads(line)["config"]["final_loss"])
+    assert abs(outs[0] - outs[1]) < 1e-5 * abs(outs[1]), outs
