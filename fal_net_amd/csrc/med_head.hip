@@ -131,6 +131,134 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_kernel(
     }
 }
 
+// Forward, LDS-staged form (used when the row fits: W <= 2048).  The first version read every logit three times
+// per pixel with 4-byte lane loads (x, x+k, x+k+1): TA-bound at ~1.9 TB/s.  Here the workgroup streams CH plane rows of
+// its image row into LDS with coalesced 16-byte loads (each logit leaves HBM/L2 exactly once) and the three taps
+// become LDS reads; per-pixel softmax state lives in registers across chunks (PPT pixels per thread).
+template <int PPT>
+__global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_lds_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
+    const float* __restrict__ max_disp, float* __restrict__ disp, float* __restrict__ p_im0,
+    float* __restrict__ stats, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    const int WP = (W + 7) & ~3;                                      // row pitch in floats: >= W+4, multiple of 4 (zero tail)
+    float* lrow = reinterpret_cast<float*>(smem + sizeof(PlaneTab));  // [3][WP]
+    float* prow = lrow + 3 * WP;                                      // [CH][WP]
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    const bool want_pan = p_im0 != nullptr;
+    for (int i = threadIdx.x; i < 3 * WP; i += blockDim.x) {
+        const int c = i / WP, x = i % WP;
+        lrow[i] = (want_pan && x < W) ? left[((int64_t)b * 3 + c) * HW + (int64_t)y * W + x] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CH * WP; i += blockDim.x)
+        if (i % WP >= W) prow[i] = 0.f;                               // zero tail of every plane row (out-of-range taps read 0)
+    const float* Lrow = dlog0 + (int64_t)b * N * HW + (int64_t)y * W;
+    const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(Lrow) & 15) == 0) && ((HW & 3) == 0);
+
+    float m0[PPT], z0[PPT], dacc[PPT], mw[PPT], zw[PPT], p0[PPT], p1[PPT], p2[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        m0[q] = mw[q] = -INFINITY;
+        z0[q] = dacc[q] = zw[q] = p0[q] = p1[q] = p2[q] = 0.f;
+    }
+    for (int n0 = 0; n0 < N; n0 += CH) {
+        __syncthreads();                                              // previous chunk fully consumed (and tab/lrow ready)
+        if (vec4) {
+            const int w4 = W >> 2;
+            for (int i = threadIdx.x; i < CH * w4; i += blockDim.x) {
+                const int j = i / w4, q = i % w4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q];
+                *reinterpret_cast<float4*>(prow + j * WP + 4 * q) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < CH * W; i += blockDim.x) {
+                const int j = i / W, x = i % W;
+                prow[j * WP + x] = n0 + j < N ? Lrow[(int64_t)(n0 + j) * HW + x] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int x = threadIdx.x + q * HEAD_THREADS;
+            if (x >= W) continue;
+            float l0[CH], lw[CH];
+            float cm0 = -INFINITY, cmw = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int n = n0 + j;
+                if (n < N) {
+                    const float* pr = prow + j * WP;
+                    l0[j] = pr[x];
+                    const int i0 = min(x + tab.k[n], W);
+                    const float a = tab.a[n];
+                    lw[j] = (1.f - a) * pr[i0] + a * pr[i0 + 1];      // zero tail: OOB logit is 0, not -inf
+                } else {
+                    l0[j] = -INFINITY;
+                    lw[j] = -INFINITY;
+                }
+                cm0 = fmaxf(cm0, l0[j]);
+                cmw = fmaxf(cmw, lw[j]);
+            }
+            if (cm0 > m0[q]) {
+                const float s = __expf(m0[q] - cm0);
+                z0[q] *= s;
+                dacc[q] *= s;
+                m0[q] = cm0;
+            }
+            if (cmw > mw[q]) {
+                const float s = __expf(mw[q] - cmw);
+                zw[q] *= s;
+                p0[q] *= s;
+                p1[q] *= s;
+                p2[q] *= s;
+                mw[q] = cmw;
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int n = n0 + j;
+                if (n < N) {
+                    const float e = __expf(l0[j] - m0[q]);
+                    z0[q] += e;
+                    dacc[q] += tab.d[n] * e;
+                    const float ew = __expf(lw[j] - mw[q]);
+                    zw[q] += ew;
+                    if (want_pan) {
+                        const int i0 = min(x + tab.k[n], W);
+                        const float a = tab.a[n];
+                        p0[q] += ew * ((1.f - a) * lrow[i0] + a * lrow[i0 + 1]);
+                        p1[q] += ew * ((1.f - a) * lrow[WP + i0] + a * lrow[WP + i0 + 1]);
+                        p2[q] += ew * ((1.f - a) * lrow[2 * WP + i0] + a * lrow[2 * WP + i0 + 1]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int x = threadIdx.x + q * HEAD_THREADS;
+        if (x >= W) continue;
+        const int64_t pix = (int64_t)y * W + x;
+        if (disp) disp[(int64_t)b * HW + pix] = dacc[q] / z0[q];
+        if (want_pan) {
+            const float r = 1.f / zw[q];
+            p_im0[((int64_t)b * 3 + 0) * HW + pix] = p0[q] * r;
+            p_im0[((int64_t)b * 3 + 1) * HW + pix] = p1[q] * r;
+            p_im0[((int64_t)b * 3 + 2) * HW + pix] = p2[q] * r;
+        }
+        if (stats) {
+            float* st = stats + (int64_t)b * 4 * HW + pix;
+            st[0] = m0[q];
+            st[HW] = z0[q];
+            st[2 * HW] = mw[q];
+            st[3 * HW] = zw[q];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- backward
 // grad_dlog0[n, x'] = (1-a) gwl_n(x'-k) + a gwl_n(x'-k-1) + gd(x') sm_n(x') (d_n - disp(x'))
 //   gwl_n(x) = Dprob_n(x) (sum_c gp_c(x) S_{c,n}(x) - q(x)),  q = sum_c gp_c p_c
@@ -287,6 +415,10 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_masks_kernel(
 }
 
 // ---------------------------------------------------------------------------------------- C-ABI
+#include <stdlib.h>
+// FALNET_HEAD_V1=1: first forward kernel (per-lane global taps) instead of the LDS-staged one (A/B, tests)
+static const bool g_head_v1 = [] { const char* e = getenv("FALNET_HEAD_V1"); return e && e[0] == '1'; }();
+
 static int check_head(int B, int N, int H, int W) {
     FALNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "med_head: empty shape B=%d H=%d W=%d", B, H, W);
     FALNET_CHECK_ARG(N >= 2 && N <= HEAD_MAXN, "med_head: N=%d outside [2,%d]", N, HEAD_MAXN);
@@ -300,6 +432,26 @@ extern "C" int falnet_med_head_fwd(const float* dlog0, const float* left, const 
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp, "med_head_fwd: null input");
     FALNET_CHECK_ARG(!p_im0 || left, "med_head_fwd: p_im0 requested without left image");
+    const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
+    const size_t WP = (size_t)((W + 7) & ~3);
+    const size_t lds2 = sizeof(PlaneTab) + (3 + CH) * WP * sizeof(float);
+    if (ppt <= 8 && lds2 <= 64 * 1024 && !g_head_v1) {
+#define LAUNCH_HEAD(P)                                                                                                   \
+    hipLaunchKernelGGL(med_head_fwd_lds_kernel<P>, dim3(B * H), dim3(HEAD_THREADS), lds2, (hipStream_t)stream, dlog0, left, \
+                       min_disp, max_disp, disp, p_im0, stats, N, H, W)
+        switch (ppt) {
+            case 1: LAUNCH_HEAD(1); break;
+            case 2: LAUNCH_HEAD(2); break;
+            case 3: LAUNCH_HEAD(3); break;
+            case 4: LAUNCH_HEAD(4); break;
+            case 5: LAUNCH_HEAD(5); break;
+            case 6: LAUNCH_HEAD(6); break;
+            case 7: LAUNCH_HEAD(7); break;
+            default: LAUNCH_HEAD(8); break;
+        }
+#undef LAUNCH_HEAD
+        FALNET_RETURN_LAUNCH();
+    }
     const size_t lds = sizeof(PlaneTab) + (size_t)3 * (W + 2) * sizeof(float);
     hipLaunchKernelGGL(med_head_fwd_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
                        min_disp, max_disp, disp, p_im0, stats, N, H, W);
