@@ -94,3 +94,16 @@ def test_bf16_forward_deviation():
     dev = rel(d16, d32)
     print("bf16 disp deviation (max-norm rel):", dev, " abs_rel:", float(((d16 - d32).abs() / d32).mean()))
     assert dev < 0.1
+
+
+def test_highres_n96_forward_vs_oracle():
+    """BASELINE configs[4] shape: 384x1280, N=96 planes (f32 path vs the CPU oracle; B=1 keeps the oracle in seconds)."""
+    left, right, mn, mx = synthetic.synthetic_pair(1, 384, 1280, seed=96)
+    sd = synthetic.seeded_falnetb_state_dict(96)
+    with torch.no_grad():
+        ref = O.falnet_forward(sd, left, mn, mx, ret_disp=True, ret_pan=True)
+    m = FAL_netB({"state_dict": sd}, no_levels=96).to(DEV).eval()
+    with torch.no_grad():
+        pan, disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV), ret_disp=True, ret_pan=True)
+    assert rel(disp, ref[1]) < F32_TOL
+    assert rel(pan, ref[0]) < F32_TOL

@@ -168,3 +168,20 @@ def test_collective_path_world1(tmp_path):
         assert r.stdout.strip().splitlines()[-1] == line  # the JSON is the last line even with RCCL's banner
         outs.append(json.loads(line)["config"]["final_loss"])
     assert abs(outs[0] - outs[1]) < 1e-5 * abs(outs[1]), outs
+
+
+def test_highres_n96_bf16_step_properties():
+    """configs[4]-shaped Stage-1 step (384x1280, N=96, bf16; B=2): size-independent properties -- finite loss that
+    decreases over a few Adam steps, disparities inside [min_disp, max_disp], synthesised view a convex blend."""
+    left, right, mn, mx = synthetic.synthetic_pair(2, 384, 1280, seed=5)
+    m = build(96, torch.bfloat16).train()
+    opt = train.FlatAdam(m, lr=1e-4)
+    losses = []
+    for _ in range(4):
+        out = train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+        losses.append(float(out["loss"]))
+    LF.set_compute_dtype(torch.float32)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    d = out["ldisp"]
+    assert float(d.min()) >= 2.0 - 1e-2 and float(d.max()) <= 300.0 + 1e-2
+    assert float(out["rpan"].abs().max()) <= float(left.abs().max()) + 1e-3
