@@ -95,15 +95,20 @@ def main():
                          'data_transforms.py) are outside the hot path (SURVEY.md 8f-3).')
     steps_per_epoch = args.epoch_size or 100
     best = -1
+    # synthetic mode: a small pool of seeded batches resident in HBM, cycled (generating 25 MB of noise on the CPU every
+    # step would make the script loader-bound; a real loader prefetches asynchronously)
+    pool = []
+    for k in range(4):
+        l_, r_, _, mx_ = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width, seed=1234 + rank + 977 * k, max_disp=args.max_disp)
+        pool.append((l_.to(dev), r_.to(dev), mx_.to(dev)))
     for epoch in range(args.start_epoch, args.epochs):
         opt.param_groups[0]['lr'] = lr_at(epoch)
         m_model.train()
         losses, rec_losses = utils.AverageMeter(), utils.AverageMeter()
         end = time.time()
         for i in range(steps_per_epoch):
-            left, right, mn, mx = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width,
-                                                           seed=1234 + rank + 977 * (epoch * steps_per_epoch + i), max_disp=args.max_disp)
-            out = train.stage1_step(m_model, opt, left.to(dev), right.to(dev), mx.to(dev), a_p=args.a_p, a_sm=args.a_sm,
+            left, right, mx = pool[i % len(pool)]
+            out = train.stage1_step(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
                                     min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
             if i % args.print_freq == 0:
                 losses.update(float(out['loss']), args.batch_size)

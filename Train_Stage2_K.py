@@ -59,13 +59,16 @@ def main():
     if not args.synthetic:
         raise SystemExit('only --synthetic input is wired in this build (data pipeline out of scope, SURVEY.md 8f-3)')
     steps = args.epoch_size or 100
+    pool = []
+    for k in range(4):  # seeded batches resident in HBM, cycled (see Train_Stage1_K.py)
+        l_, r_, _, mx_ = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width, seed=4321 + rank + 977 * k, max_disp=args.max_disp)
+        pool.append((l_.to(dev), r_.to(dev), mx_.to(dev)))
     for epoch in range(args.start_epoch, args.epochs):
         opt.param_groups[0]['lr'] = args.lr * (0.5 ** sum(1 for m in args.milestones if epoch >= m))
         t0 = time.time()
         for i in range(steps):
-            left, right, mn, mx = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width,
-                                                           seed=4321 + rank + 977 * (epoch * steps + i), max_disp=args.max_disp)
-            out = train.stage2_step(m_model, fix_model, opt, left.to(dev), right.to(dev), mx.to(dev), a_p=args.a_p, a_sm=args.a_sm,
+            left, right, mx = pool[i % len(pool)]
+            out = train.stage2_step(m_model, fix_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
                                     a_mr=args.a_mr, min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
             if i % args.print_freq == 0 and rank == 0:
                 print(json.dumps({'epoch': epoch, 'iter': i, 'loss': float(out['loss']), 'rec': float(out['rec']),
