@@ -71,6 +71,7 @@ SIGNATURES = {
     "falnet_channel_pad": [_I],
     "falnet_debug_set": [_I, _I],
     "falnet_conv2d": [C.POINTER(Conv), _P],
+    "falnet_conv3x3_c3": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_conv2d_multi": [C.POINTER(Conv), _I, _P],
     "falnet_conv2d_kernel_name": [C.POINTER(Conv), C.c_char_p, _I],
     "falnet_wgrad_workspace_bytes": [C.POINTER(Wgrad)],

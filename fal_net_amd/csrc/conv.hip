@@ -794,6 +794,93 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
     }
 }
 
+// ------------------------------------------------------------------------------------------ first layer (Cin = 3)
+// conv 3x3 / stride 1 / pad 1 on a 3-channel planar f32 image (FAL_netB.py:99 conv0; VGG19 features[0]): K = 27.  The
+// generic kernels pad the 3 channels to 32 (K = 288, ~10x wasted MFMA work and a layout-conversion launch in front).
+// Here the (8+2)x(32+2)x3 patch is staged planar in LDS straight from the NCHW f32 input, every lane builds its
+// K = 32 (27 + 5 zeros) im2col fragment from it (k = c*9 + tap: the OIHW flattening, so the f32 master weights are used
+// as they are, no packing), two bf16 MFMAs (sixteen f32 ones) per 32x32 output tile: purely output-write bound.
+template <typename T, int NT>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
+                                                                  const falnet_conv_t p, int tiles_x, int tiles_y) {
+    constexpr int PH = PT_TH + 2, PW = PT_PW;
+    __shared__ __attribute__((aligned(16))) char lds[4 * 32 * (NT * 32 + 4) * 4];  // epilogue staging; front part doubles as patch + weights
+    float* patch = reinterpret_cast<float*>(lds);            // [3][PH][PW] f32
+    float* wl = patch + 3 * PH * PW;                         // [NT*32][32] f32, k-major rows (zero padded k >= 27)
+    static_assert((3 * PH * PW + NT * 32 * 32) * 4 <= (int)sizeof(lds), "patch + weights must fit in the staging area");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int tix = bid % tiles_x;
+    bid /= tiles_x;
+    const int tiy = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int ty0 = tiy * PT_TH, tx0 = tix * PT_TW;
+    const int64_t HW = (int64_t)p.IH * p.IW;
+    for (int i = tid; i < 3 * PH * PW; i += CONV_THREADS) {
+        const int c = i / (PH * PW), rem = i % (PH * PW), pr = rem / PW, pc = rem % PW;
+        const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
+        patch[i] = (vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) ? x[((int64_t)b * 3 + c) * HW + (int64_t)vy * p.IW + vx] : 0.f;
+    }
+    for (int i = tid; i < NT * 32 * 32; i += CONV_THREADS) {
+        const int co = i >> 5, k = i & 31;
+        wl[i] = (co < p.Cout && k < 27) ? w_oihw[co * 27 + k] : 0.f;
+    }
+    __syncthreads();
+    constexpr int MT = PT_TH / 4;  // rows per wave
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+    // im2col element k of output pixel (row, r): patch[c][row + t/3][r + t%3], k = c*9 + t
+    auto a_elem = [&](int row, int k) -> float {
+        if (k >= 27) return 0.f;
+        const int c = k / 9, t = k % 9;
+        return patch[(c * PH + row + t / 3) * PW + r + t % 3];
+    };
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfr[nt][j] = (bf16_t)wl[(nt * 32 + r) * 32 + ks * 16 + h * 8 + j];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x8 afr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) afr[j] = (bf16_t)a_elem(wave * MT + mt, ks * 16 + h * 8 + j);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = wl[(nt * 32 + r) * 32 + ks * 2 + h];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a = a_elem(wave * MT + mt, ks * 2 + h);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // patch / weights are dead: the same LDS becomes the per-wave epilogue staging slabs
+    float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
+    const int cstride = p.out_cstride;
+    epilogue_nhwc<T, MT, NT>(p, acc, stage, 0, lane, [&](int mt, int row) -> int64_t {
+        const int y = ty0 + wave * MT + mt, xx = tx0 + row;
+        return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
+    });
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 // dW[co, tap, ci] = sum_p G[p, co] * In[nbr(p, tap), ci]: both operands are pixel-major (the contraction
 // index is the slow one), so the LDS tiles are [pixel][channel] and the MFMA operands are read transposed:
@@ -1540,6 +1627,31 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         const unsigned eg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         if (p.dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(eg), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(eg), dim3(256), 0, st, p);
+    }
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int Cout,
+                                 int act, int dtype, void* stream) {
+    FALNET_CHECK_ARG(x_nchw && w_oihw && out && B > 0 && H > 0 && W > 0, "conv3x3_c3: bad argument");
+    FALNET_CHECK_ARG(Cout == 32 || Cout == 64, "conv3x3_c3: Cout must be 32 or 64 (got %d)", Cout);
+    falnet_conv_t p = {};
+    p.IH = p.OH = H;
+    p.IW = p.OW = W;
+    p.out = out;
+    p.Cout = Cout;
+    p.out_cstride = Cout;
+    p.bias = bias;
+    p.act = act;
+    const int tiles_x = (W + PT_TW - 1) / PT_TW, tiles_y = (H + PT_TH - 1) / PT_TH;
+    const dim3 grid((unsigned)(B * tiles_x * tiles_y));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FALNET_BF16) {
+        if (Cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<bf16_t, 2>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<bf16_t, 1>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
+    } else {
+        if (Cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<float, 2>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<float, 1>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
     }
     FALNET_RETURN_LAUNCH();
 }

@@ -36,18 +36,20 @@ class _VggPlan:
         _conv = lambda *a, **kw: ops.conv_call(*a, ws_owner=("vgg", id(self)), **kw)  # own split-K scratch per plan instance
         pcs = owner._packed
         x_in = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
-        x0 = torch.empty(B, H, W, ops.pad_c(3), dtype=dtype, device=device)
-        self.x_in, self.keep = x_in, [x0]
-        self.fwd.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(x_in), L.ptr(x0), B, 3, H, W, ops.pad_c(3), code))
+        x0 = x_in  # the first conv reads the planar f32 image directly (falnet_conv3x3_c3): no layout conversion
+        self.x_in, self.keep = x_in, []
         cur, h, w = x0, H, W
         self.outs, acts = [], []  # acts: (pc, input tensor, relu output tensor, h, w)
         for convs in _SLICES:
             for idx in convs:
                 pc = pcs[idx]
                 y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device)
-                self.fwd.append(_conv(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
-                                              1, B, h, w, y, h, w, pc.cout, pc.cout, bias=pc.bias, act=L.ACT_RELU,
-                                              name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9))
+                if cur is x0:
+                    self.fwd.append(ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)"))
+                else:
+                    self.fwd.append(_conv(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
+                                          1, B, h, w, y, h, w, pc.cout, pc.cout, bias=pc.bias, act=L.ACT_RELU,
+                                          name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9))
                 acts.append((pc, cur, y, h, w))
                 cur = y
             pooled = torch.empty(B, h // 2, w // 2, cur.shape[3], dtype=dtype, device=device)

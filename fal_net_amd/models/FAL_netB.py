@@ -225,8 +225,10 @@ class FalnetPlan:
         mn, mx = self._f32("min_disp", B), self._f32("max_disp", B)
         flow = torch.zeros(B, pad_c(1), dtype=dt, device=dev)
         self.buf["flow"] = flow
+        # NHWC copy of the image: only the first layer's weight gradient reads it (the forward uses the planar image
+        # directly, falnet_conv3x3_c3), so the conversion runs in backward on the side stream
         x0 = self._act("x0", H, W, pad_c(3))
-        self.fwd.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(left), L.ptr(x0), B, 3, H, W, pad_c(3), code))
+        self._x0_convert = ops.simple_call("falnet_nchw_to_nhwc", L.ptr(left), L.ptr(x0), B, 3, H, W, pad_c(3), code)
 
         # ---- encoder ----
         sizes = [(H, W)]
@@ -246,7 +248,10 @@ class FalnetPlan:
                 srcs = [ops.nhwc_src(c[i - 1])]
             self._enc_srcs = getattr(self, "_enc_srcs", {})
             self._enc_srcs[i] = (srcs, ih, iw)
-            self._conv_fwd(pcs[cname], srcs, ih, iw, a[i], L.ACT_ELU, name=cname)
+            if i == 0:
+                self.fwd.append(ops.conv_c3_call(dt, left, pcs[cname], a[0], L.ACT_ELU, name="fwd conv0(c3)"))
+            else:
+                self._conv_fwd(pcs[cname], srcs, ih, iw, a[i], L.ACT_ELU, name=cname)
             self._conv_fwd(pcs[rname + ".conv1"], [ops.nhwc_src(a[i])], hh, ww, h_[i], L.ACT_ELU, name=rname + ".conv1")
             self._conv_fwd(pcs[rname + ".conv2"], [ops.nhwc_src(h_[i])], hh, ww, c[i], L.ACT_ELU, addend=a[i],
                            name=rname + ".conv2")
@@ -297,6 +302,7 @@ class FalnetPlan:
         # bucket's share of the step's all-reduce while backward continues.
         self._bucket = 0
         self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
+        self._side_call(self._x0_convert)
         G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, NHWC
         self.bwd_body.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(g_dlog0), L.ptr(G0), B, N, H, W, pad_c(N), code))
         self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")

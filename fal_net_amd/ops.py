@@ -113,6 +113,19 @@ class PackedConv:
         return c0_real, c0_pad
 
 
+def conv_c3_call(dtype, x_planar, pc, out, act, name="conv0(c3)"):
+    """First-layer launch (falnet_conv3x3_c3): planar f32 image + f32 OIHW master weights -> NHWC activation."""
+    lib = L.lib()
+    B, C, H, W = x_planar.shape
+    assert C == 3 and pc.cin == 3 and pc.cout in (32, 64) and out.shape == (B, H, W, pc.cout)
+    args = (L.ptr(x_planar), L.ptr(pc.weight), L.ptr(pc.bias), L.ptr(out), B, H, W, pc.cout, act, L.dtype_code(dtype))
+    tn, nt = ("DF16b" if dtype == torch.bfloat16 else "f"), pc.cout // 32
+
+    def launch(_keep=(x_planar, pc, out)):
+        L.check(lib.falnet_conv3x3_c3(*args, L.stream_ptr()), name)
+    return _timed(f"_Z17conv3x3_c3_kernelI{tn}Li{nt}EEvPKfS1_13falnet_conv_tii", 2 * B * H * W * pc.cout * 27, 0, launch, name)
+
+
 def pack_all_call(pcs, dtype, device):
     """ONE launch that re-packs every layer's f32 OIHW master weight into its wf / wd operands."""
     lib = L.lib()

@@ -97,6 +97,10 @@ typedef struct {
                                   -2 is returned when the variant does not apply */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
+/* First layer: 3x3 / stride 1 / pad 1 convolution of a 3-channel planar f32 image (FAL_netB.py:99 conv0, VGG19 features[0];
+ * loss_functions.py:21) with the f32 OIHW weights as they are -> NHWC `dtype` [B][H][W][Cout], Cout in {32, 64}, bias + act fused. */
+int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int Cout,
+                      int act, int dtype, void* stream);
 /* n <= 4 gather launches of one family (same dtype / Cout / packed rows, NHWC output, no split-K) in ONE grid:
  * the four output-parity classes of a stride-2 data gradient */
 int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream);

@@ -168,6 +168,23 @@ def test_conv_every_kernel_variant(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,cout,act", [(2, 16, 64, 32, L.ACT_ELU), (1, 9, 13, 64, L.ACT_RELU), (2, 37, 70, 32, L.ACT_NONE),
+                                            (1, 75, 250, 64, L.ACT_RELU)])
+def test_conv_first_layer_c3(B, H, W, cout, act, dtype):
+    """falnet_conv3x3_c3: the Cin=3 first layers (FAL_netB.py:127 conv0, VGG features[0]) straight from the planar f32 image."""
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + cout)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(cout, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = packed(w, b, [3], 1, dtype)
+    out = torch.full((B, H, W, cout), float("nan"), dtype=dtype, device=DEV)
+    ops.conv_c3_call(dtype, x.to(DEV), pc, out, act)()
+    ref = F.conv2d(x, w, b, padding=1)
+    ref = F.elu(ref) if act == L.ACT_ELU else F.relu(ref) if act == L.ACT_RELU else ref
+    assert rel(to_nchw(out, cout), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_planar_output(dtype):
     case = (2, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False)
     xs, w, b = _conv_inputs(case)
