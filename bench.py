@@ -193,7 +193,8 @@ def main():
             with open(args.launch_table, "w") as f:
                 for name, (ms, cnt, flops, tag) in sorted(per.items(), key=lambda kv: -kv[1][0]):
                     us = ms * 1e3 / cnt
-                    f.write(f"{us:8.1f} us  {flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  {name:44s} {tag}\n")
+                    f.write(f"{ms * 1e3 / 3:8.1f} us/step {cnt // 3:3d} x {us:8.1f} us  "
+                            f"{flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  {name:44s} {tag}\n")
         total_ms = sum(a["ms"] for a in agg.values()) / 3
         dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
         d = agg[dom_tag]

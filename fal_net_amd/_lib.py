@@ -35,7 +35,7 @@ class Conv(C.Structure):
                 ("out_cstride", C.c_int32), ("out_layout", C.c_int32), ("bias", C.c_void_p),
                 ("addend", C.c_void_p), ("act", C.c_int32), ("actout", C.c_void_p),
                 ("actout_kind", C.c_int32), ("dtype", C.c_int32), ("ksplit", C.c_int32), ("splitk_ws", C.c_void_p),
-                ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32)]
+                ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32), ("pool_out", C.c_void_p)]
 
 
 class Wgrad(C.Structure):

@@ -74,9 +74,14 @@ template <> struct Vec8<float> {
 };
 
 // RowOff: functor row(0..31 of slab mt) -> element offset of the output pixel's channel 0, or -1
-template <typename T, int MT, int NT, typename RowOff>
+// PoolOff (optional, MT even): slabs are consecutive image rows and slab rows consecutive columns; called for odd mt /
+// even row, returns the element offset of the 2x2-pooled pixel in p.pool_out or -1.  The horizontal neighbour lives in
+// lane^CS (one shuffle), the vertical one in the previous slab (kept in registers).
+struct NoPool { static constexpr bool enabled = false; __device__ int64_t operator()(int, int) const { return -1; } };
+template <typename T, int MT, int NT, typename RowOff, typename PoolOff = NoPool>
 __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], float* stage, int nbase, int lane,
-                                              RowOff rowoff) {
+                                              RowOff rowoff, PoolOff pooloff = PoolOff()) {
+    constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
     constexpr int PITCHF = NT * 32 + 4;
     constexpr int CS = NT * 4;          // 8-channel segments per row
     constexpr int RPP = 64 / CS;        // rows per pass
@@ -106,6 +111,9 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
         }
     };
     if (addend || actout) prefetch(0, 0);
+    T* pool_out = reinterpret_cast<T*>(p.pool_out);
+    const bool pooling = POOL && pool_out != nullptr;
+    Vec8<T> hprev[POOL ? PASSES : 1];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int buf = NBUF == 2 ? (mt & 1) : 0;
@@ -120,6 +128,7 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * RPP + rsub;
             const int64_t o = rowoff(mt, row);
+            Vec8<T> t;
             if (o >= 0 && nok) {
                 const float4 x0 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8);
                 const float4 x1 = *reinterpret_cast<const float4*>(stage + row * PITCHF + cs * 8 + 4);
@@ -134,9 +143,33 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] *= act_grad_from_out(actv[buf][ps].get(i), p.actout_kind);
                 }
-                Vec8<T> t;
                 t.set8(v);
-                t.store(out + o + n);
+                if (!POOL || out) t.store(out + o + n);
+            } else if (POOL) {
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                t.set8(z);  // never reaches a valid pooled pixel (floor semantics); defined value for the shuffle
+            }
+            if constexpr (POOL) {
+                if (pooling) {  // workgroup-uniform
+                    float m[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = t.get(i);
+                        m[i] = fmaxf(a, __shfl_xor(a, CS));  // column neighbour: row ^ 1
+                    }
+                    if ((mt & 1) == 0) {
+                        hprev[ps].set8(m);  // exact: the values are already rounded to T
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], hprev[ps].get(i));
+                        const int64_t po = (row & 1) ? (int64_t)-1 : pooloff(mt, row);
+                        if (po >= 0 && nok) {
+                            Vec8<T> q;
+                            q.set8(m);
+                            q.store(pool_out + po + n);
+                        }
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -787,10 +820,20 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
         static_assert(NWAVES * 32 * (NT * 32 + 4) * 4 <= (ADB ? 2 : 1) * A_BYTES + ((PIPE || DBS) ? 2 : 1) * B_BYTES, "staging must fit in the LDS buffers");
         const int cstride = p.out_cstride;
-        epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, [&](int mt, int row) -> int64_t {
+        auto rowoff = [&](int mt, int row) -> int64_t {
             const int y = ty0 + wm * MT + mt, x = tx0 + row;
             return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
-        });
+        };
+        if constexpr (MT % 2 == 0) {
+            // fused 2x2 max pool (p.pool_out): block rows start even and every wave owns an even number of rows
+            auto pooloff = [&](int mt, int row) -> int64_t {
+                const int py = (ty0 + wm * MT + mt) >> 1, px = (tx0 + row) >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+            };
+            epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, rowoff, pooloff);
+        } else {
+            epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, rowoff);
+        }
     }
 }
 
@@ -1298,7 +1341,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_
         float s = 0.f;
         if (cp0 + cl < d.cin_total) {
             const float* src = d.partial + ((int64_t)t * d.w_rows + co) * d.cin_total + cp0 + cl;
-            for (int k = s0; k < s1; ++k) s += src[k * slab];
+            int k = s0;
+            for (; k + 8 <= s1; k += 8) {  // eight slab loads in flight; the summation order stays sequential
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(k + j) * slab];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            for (; k < s1; ++k) s += src[k * slab];
         }
         tile[cl * d.ntaps + t] = s;
     }
@@ -1524,6 +1575,10 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     c.flip = flip;
     c.swap = planar ? 1 : 0;
     c.patch = variant >= 2;
+    if (p.pool_out && !c.patch) {
+        falnet_set_error("conv2d: the fused max pool needs a halo-patch variant (dense 3x3 stride-1 launch)");
+        return -2;
+    }
     if (!c.patch) {
         c.bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (bn64 ? 64 : 32);
         c.kcb = 64; c.tps = 1; c.adb = 0; c.th = 0; c.nwaves = 4;
@@ -1539,6 +1594,10 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         case 8: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 1; c.adb = 1; break;
         case 5: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 9; c.adb = 1; break;
         default: c.bn = bn64 ? 64 : 32; c.kcb = 64; c.tps = 9; c.adb = 0; break;  // 4, 7, 9
+    }
+    if (p.pool_out && (c.th / (c.nwaves / (c.bn >= 128 ? 2 : 1))) % 2 != 0) {
+        falnet_set_error("conv2d: variant %d gives every wave an odd number of rows: no fused max pool", variant);
+        return -2;
     }
     return 0;
 }
@@ -1572,7 +1631,8 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG(p.ntaps >= 1 && p.ntaps <= 9 && p.w_taps >= 1, "conv2d: ntaps=%d", p.ntaps);
     for (int t = 0; t < p.ntaps; ++t) FALNET_CHECK_ARG(p.tap_w[t] >= 0 && p.tap_w[t] < p.w_taps, "conv2d: tap_w[%d] out of range", t);
     FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0 && p.IH > 0 && p.IW > 0 && p.OH > 0 && p.OW > 0, "conv2d: empty shape");
-    FALNET_CHECK_ARG(p.weight && p.out && p.Cout > 0 && p.w_rows >= p.Cout && p.w_rows % 32 == 0, "conv2d: bad weight/out (Cout=%d w_rows=%d)", p.Cout, p.w_rows);
+    FALNET_CHECK_ARG(p.weight && (p.out || p.pool_out) && p.Cout > 0 && p.w_rows >= p.Cout && p.w_rows % 32 == 0, "conv2d: bad weight/out (Cout=%d w_rows=%d)", p.Cout, p.w_rows);
+    FALNET_CHECK_ARG(!p.pool_out || (p.out_layout == FALNET_OUT_NHWC && !p.actout && p.ksplit <= 1), "conv2d: pool_out needs a plain NHWC forward launch");
     FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");

@@ -28,9 +28,11 @@ _SLICES = ((0, 2), (5, 7), (10, 12, 14, 16))
 class _VggPlan:
     """Static launch plan of VGG19 features[0:19] forward + data-gradient for one (B,H,W,dtype)."""
 
-    def __init__(self, owner, B, H, W, dtype, device):
+    def __init__(self, owner, B, H, W, dtype, device, need_grad=True):
+        """need_grad=False (label features, Train_Stage1_K.py:241-244 under no_grad): the convs in front of a pool keep only
+        their pooled map (fused pool, no full-resolution store) and no backward launches are built."""
         self.B, self.H, self.W, self.dtype, self.device = B, H, W, dtype, device
-        self.busy = False
+        self.busy, self.need_grad = False, need_grad
         code = L.dtype_code(dtype)
         self.fwd, self.bwd = [], []
         _conv = lambda *a, **kw: ops.conv_call(*a, ws_owner=("vgg", id(self)), **kw)  # own split-K scratch per plan instance
@@ -43,20 +45,33 @@ class _VggPlan:
         for convs in _SLICES:
             for idx in convs:
                 pc = pcs[idx]
-                y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device)
+                last = idx == convs[-1]
+                pooled = torch.empty(B, h // 2, w // 2, pc.cout, dtype=dtype, device=device) if last else None
+                y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device) if (need_grad or not last) else None
+                kw = dict(bias=pc.bias, act=L.ACT_RELU, name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9)
+                args = (dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, h, w)
+                fused = False
                 if cur is x0:
                     self.fwd.append(ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)"))
-                else:
-                    self.fwd.append(_conv(dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad,
-                                          1, B, h, w, y, h, w, pc.cout, pc.cout, bias=pc.bias, act=L.ACT_RELU,
-                                          name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9))
+                elif last and os.environ.get("FALNET_FUSED_POOL", "1") == "1":
+                    try:  # 2x2 max pool in the conv epilogue: the full-resolution map is not re-read (nor written at all for labels)
+                        self.fwd.append(_conv(*args, y, h, w, pc.cout, pc.cout, pool_out=pooled, **kw))
+                        fused = True
+                    except ValueError:
+                        pass
+                if not fused and cur is not x0:
+                    if y is None:
+                        y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device)
+                    self.fwd.append(_conv(*args, y, h, w, pc.cout, pc.cout, **kw))
+                if last and not fused:
+                    self.fwd.append(ops.simple_call("falnet_maxpool2_fwd", L.ptr(y), L.ptr(pooled), B, h, w, pc.cout, code))
                 acts.append((pc, cur, y, h, w))
                 cur = y
-            pooled = torch.empty(B, h // 2, w // 2, cur.shape[3], dtype=dtype, device=device)
-            self.fwd.append(ops.simple_call("falnet_maxpool2_fwd", L.ptr(cur), L.ptr(pooled), B, h, w, cur.shape[3], code))
             acts.append(("pool", cur, pooled, h, w))
             self.outs.append(pooled)
             cur, h, w = pooled, h // 2, w // 2
+        if not need_grad:
+            return
         # ---- backward: gradients of the three pooled outputs -> gradient of the planar f32 input ----
         self.gouts = [torch.empty_like(o) for o in self.outs]
         g_next = None  # gradient wrt `cur` of the step being undone (post-pool tensor of the slice below)
@@ -163,12 +178,12 @@ class Vgg19_pc(nn.Module):
             self._packed_key, self._plans = key, {}
 
     def _plan(self, B, H, W, dtype, device, hold):
-        pool = self._plans.setdefault((B, H, W), [])
+        pool = self._plans.setdefault((B, H, W, hold), [])  # hold = the call needs a backward (plan busy until it ran)
         for p in pool:
             if not p.busy:
                 p.busy = hold
                 return p
-        p = _VggPlan(self, B, H, W, dtype, device)
+        p = _VggPlan(self, B, H, W, dtype, device, need_grad=hold)
         p.busy = hold
         pool.append(p)
         return p

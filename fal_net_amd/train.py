@@ -8,6 +8,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import ops
 from .loss_functions import rec_loss_fnc, smoothness, vgg
 
 
@@ -93,6 +94,9 @@ def _aux_stream(device):
 def vgg_label_async(label):
     """VGG features of a label image on an auxiliary HIP stream: independent of the network forward, so it runs
     concurrently with it and fills the CUs the small backbone layers leave idle.  Returns (features, join)."""
+    if ops.TIMER is not None:  # instrumented pass (bench.py roofline): serial launches so per-kernel times are uncontended
+        feats_serial = vgg(label)
+        return lambda: feats_serial
     main = torch.cuda.current_stream()
     aux = _aux_stream(label.device)
     aux.wait_stream(main)

@@ -95,6 +95,10 @@ typedef struct {
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
                                   6/7 = 3/4 on a 16x32-position block with 8 waves, 8/9 = 3/4 on a 4x32 block;
                                   -2 is returned when the variant does not apply */
+    void* pool_out;            /* optional fused 2x2/stride-2 max pool of the (activated) output: NHWC `dtype`
+                                  [B][OH/2][OW/2][out_cstride] (nn.MaxPool2d(2,2) after the VGG slices,
+                                  loss_functions.py:21-29).  Halo-patch variants with an even number of rows per wave
+                                  only (-2 otherwise); with pool_out set, `out` may be NULL (only the pooled map is kept) */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
 /* First layer: 3x3 / stride 1 / pad 1 convolution of a 3-channel planar f32 image (FAL_netB.py:99 conv0, VGG19 features[0];

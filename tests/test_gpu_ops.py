@@ -168,6 +168,46 @@ def test_conv_every_kernel_variant(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,cin,cout,H,W,keep_full", [(2, 64, 64, 16, 64, True), (1, 64, 128, 24, 40, False), (2, 128, 128, 128, 256, True),
+                                                     (1, 256, 256, 16, 32, False), (1, 64, 64, 11, 37, True)])
+def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
+    """pool_out: relu(conv) and nn.MaxPool2d(2,2) of it from ONE launch (VGG slices, loss_functions.py:21-29), on every
+    halo-patch variant that supports it; with out=NULL only the pooled map is produced.  Odd H/W: floor semantics."""
+    case = (B, [cin], cout, H, W, 1, 3, True, L.ACT_RELU, False)
+    xs, w, b = _conv_inputs(case, seed=5)
+    ref = _ref_conv(case, xs, w, b)
+    pc = packed(w, b, [cin], 1, dtype)
+    x_t = to_nhwc(xs[0], dtype)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        out = torch.empty(B, H, W, cout, dtype=dtype, device=DEV) if keep_full else None
+        pooled = torch.empty(B, H // 2, W // 2, cout, dtype=dtype, device=DEV)
+        call = ops.conv_call(dtype, [ops.nhwc_src(x_t)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out, H, W,
+                             cout, cout, bias=pc.bias, act=L.ACT_RELU, pool_out=pooled)
+    finally:
+        ops.AUTOTUNE = old
+    ran = []
+    for variant in range(1, 10):
+        call.desc.variant = variant
+        pooled.fill_(float("nan"))
+        if out is not None:
+            out.fill_(float("nan"))
+        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+        if rc == -2:
+            continue
+        assert rc == 0, (variant, L.lib().falnet_last_error())
+        tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+        assert rel(to_nchw(pooled, cout), F.max_pool2d(ref, 2, 2)) < tol, variant
+        if out is not None:
+            assert rel(to_nchw(out, cout), ref) < tol, variant
+            # the pooled map is exactly the max of the stored (rounded) full-resolution values
+            assert torch.equal(pooled.float(), F.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)), variant
+        ran.append(variant)
+    assert 1 not in ran and 4 in ran and len(ran) >= 3, ran
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,cout,act", [(2, 16, 64, 32, L.ACT_ELU), (1, 9, 13, 64, L.ACT_RELU), (2, 37, 70, 32, L.ACT_NONE),
                                             (1, 75, 250, 64, L.ACT_RELU)])
 def test_conv_first_layer_c3(B, H, W, cout, act, dtype):
