@@ -35,7 +35,8 @@ class Conv(C.Structure):
                 ("out_cstride", C.c_int32), ("out_layout", C.c_int32), ("bias", C.c_void_p),
                 ("addend", C.c_void_p), ("act", C.c_int32), ("actout", C.c_void_p),
                 ("actout_kind", C.c_int32), ("dtype", C.c_int32), ("ksplit", C.c_int32), ("splitk_ws", C.c_void_p),
-                ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32), ("pool_out", C.c_void_p)]
+                ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32), ("pool_out", C.c_void_p),
+                ("pool_mode", C.c_int32), ("pool_actout_kind", C.c_int32), ("pool_actout", C.c_void_p)]
 
 
 class Wgrad(C.Structure):
@@ -90,6 +91,7 @@ SIGNATURES = {
     "falnet_act_bwd": [_P, _P, _P, _L, _I, _I, _P],
     "falnet_med_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "falnet_med_head_bwd_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_med_masks_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_l1_fwd": [_P, _P, _P, _I, _I, _L, _F, _P, _I, _P],
     "falnet_l1_bwd": [_P, _P, _P, _I, _I, _L, _F, _P, _P, _I, _P],

@@ -12,6 +12,7 @@
 //   f32 : v_mfma_f32_32x32x2_f32 (exact f32, the parity path); K is walked in a lane-half-permuted order
 //         (half h owns k in [8h, 8h+8)) so that each lane's operands are two ds_read_b128.
 // Wave tiling: 4 waves, 128 positions x {32,64,128} channels per workgroup.
+#include <limits.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -151,19 +152,27 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
             }
             if constexpr (POOL) {
                 if (pooling) {  // workgroup-uniform
+                    const bool sum = p.pool_mode == 1;
                     float m[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float a = t.get(i);
-                        m[i] = fmaxf(a, __shfl_xor(a, CS));  // column neighbour: row ^ 1
+                        const float nb = __shfl_xor(a, CS);  // column neighbour: row ^ 1
+                        m[i] = sum ? a + nb : fmaxf(a, nb);
                     }
                     if ((mt & 1) == 0) {
-                        hprev[ps].set8(m);  // exact: the values are already rounded to T
+                        hprev[ps].set8(m);  // max: exact (the values are already rounded to T)
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], hprev[ps].get(i));
+                        for (int i = 0; i < 8; ++i) m[i] = sum ? m[i] + hprev[ps].get(i) : fmaxf(m[i], hprev[ps].get(i));
                         const int64_t po = (row & 1) ? (int64_t)-1 : pooloff(mt, row);
                         if (po >= 0 && nok) {
+                            if (p.pool_actout) {
+                                Vec8<T> av;
+                                av.load(reinterpret_cast<const T*>(p.pool_actout) + po + n);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) m[i] *= act_grad_from_out(av.get(i), p.pool_actout_kind);
+                            }
                             Vec8<T> q;
                             q.set8(m);
                             q.store(pool_out + po + n);
@@ -843,85 +852,125 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
 // Here the (8+2)x(32+2)x3 patch is staged planar in LDS straight from the NCHW f32 input, every lane builds its
 // K = 32 (27 + 5 zeros) im2col fragment from it (k = c*9 + tap: the OIHW flattening, so the f32 master weights are used
 // as they are, no packing), two bf16 MFMAs (sixteen f32 ones) per 32x32 output tile: purely output-write bound.
+#define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, next patch prefetched behind the epilogue
 template <typename T, int NT>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
-                                                                  const falnet_conv_t p, int tiles_x, int tiles_y) {
-    constexpr int PH = PT_TH + 2, PW = PT_PW;
-    __shared__ __attribute__((aligned(16))) char lds[4 * 32 * (NT * 32 + 4) * 4];  // epilogue staging; front part doubles as patch + weights
-    float* patch = reinterpret_cast<float*>(lds);            // [3][PH][PW] f32
-    float* wl = patch + 3 * PH * PW;                         // [NT*32][32] f32, k-major rows (zero padded k >= 27)
-    static_assert((3 * PH * PW + NT * 32 * 32) * 4 <= (int)sizeof(lds), "patch + weights must fit in the staging area");
+                                                                  const falnet_conv_t p, int groups_x, int tiles_y) {
+    constexpr int PH = PT_TH + 2, PW = PT_PW, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
+    __shared__ __attribute__((aligned(16))) float patch[NEL];                       // [3][PH][PW] f32
+    __shared__ __attribute__((aligned(16))) float stage_all[4 * 32 * (NT * 32 + 4)];  // per-wave epilogue staging slabs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     int bid = blockIdx.x;
-    const int tix = bid % tiles_x;
-    bid /= tiles_x;
+    const int gx = bid % groups_x;
+    bid /= groups_x;
     const int tiy = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int ty0 = tiy * PT_TH, tx0 = tix * PT_TW;
+    const int ty0 = tiy * PT_TH;
     const int64_t HW = (int64_t)p.IH * p.IW;
-    for (int i = tid; i < 3 * PH * PW; i += CONV_THREADS) {
-        const int c = i / (PH * PW), rem = i % (PH * PW), pr = rem / PW, pc = rem % PW;
-        const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
-        patch[i] = (vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) ? x[((int64_t)b * 3 + c) * HW + (int64_t)vy * p.IW + vx] : 0.f;
-    }
-    for (int i = tid; i < NT * 32 * 32; i += CONV_THREADS) {
-        const int co = i >> 5, k = i & 31;
-        wl[i] = (co < p.Cout && k < 27) ? w_oihw[co * 27 + k] : 0.f;
-    }
-    __syncthreads();
-    constexpr int MT = PT_TH / 4;  // rows per wave
-    f32x16 acc[MT][NT];
+    // this thread's patch elements: (channel, row, column) are the same for every tile, only tx0 moves
+    int p_off[SLOTS], p_col[SLOTS];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int u = 0; u < SLOTS; ++u) {
+        const int i = tid + u * CONV_THREADS;
+        const int c = i / (PH * PW), rem = i % (PH * PW), pr = rem / PW, pc = rem % PW;
+        const int vy = ty0 - 1 + pr;
+        p_col[u] = pc - 1;
+        p_off[u] = (i < NEL && vy >= 0 && vy < p.IH) ? (int)(c * HW + (int64_t)vy * p.IW) + pc - 1 : INT_MIN;  // (-1 is a valid offset)
+    }
+    const float* xb = x + (int64_t)b * 3 * HW;
+    float pv[SLOTS];
+    auto patch_load = [&](int tx0) {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int vx = tx0 + p_col[u];
+            pv[u] = (p_off[u] != INT_MIN && vx >= 0 && vx < p.IW) ? xb[p_off[u] + tx0] : 0.f;
+        }
+    };
+    const int tix0 = gx * C3_TPW;
+    patch_load(tix0 * PT_TW);
+    // B fragments straight from the f32 OIHW master weights (k = c*9 + tap is their flattening): lane (r, h) owns
+    // cout nt*32 + r and the k values its MFMA operand slot covers; 6.9 KB in all, L2-resident
+    constexpr int KS = sizeof(T) == 2 ? 2 : 16, KJ = sizeof(T) == 2 ? 8 : 1;
+    float wv[KS][NT][KJ];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
-    // im2col element k of output pixel (row, r): patch[c][row + t/3][r + t%3], k = c*9 + t
-    auto a_elem = [&](int row, int k) -> float {
-        if (k >= 27) return 0.f;
-        const int c = k / 9, t = k % 9;
-        return patch[(c * PH + row + t / 3) * PW + r + t % 3];
-    };
+            for (int j = 0; j < KJ; ++j) {
+                const int co = nt * 32 + r, k = (ks * 2 + h) * KJ + j;
+                wv[ks][nt][j] = (co < p.Cout && k < 27) ? w_oihw[co * 27 + k] : 0.f;
+            }
+    bf16x8 bfr[sizeof(T) == 2 ? 2 : 1][NT];
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bfr[NT];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bfr[nt][j] = (bf16_t)wl[(nt * 32 + r) * 32 + ks * 16 + h * 8 + j];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                bf16x8 afr;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) afr[j] = (bf16_t)a_elem(wave * MT + mt, ks * 16 + h * 8 + j);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[nt], acc[mt][nt], 0, 0, 0);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            float bfr[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[nt] = wl[(nt * 32 + r) * 32 + ks * 2 + h];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float a = a_elem(wave * MT + mt, ks * 2 + h);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bfr[nt], acc[mt][nt], 0, 0, 0);
-            }
-        }
+                for (int j = 0; j < 8; ++j) bfr[ks][nt][j] = (bf16_t)wv[ks][nt][j];
     }
-    __syncthreads();  // patch / weights are dead: the same LDS becomes the per-wave epilogue staging slabs
-    float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
+    constexpr int MT = PT_TH / 4;  // rows per wave
+    // im2col element k of output pixel (row, r): patch[c][row + t/3][r + t%3], k = c*9 + t.  k0 / k1 are the k of lane
+    // half 0 / 1 and compile-time after unrolling, so the LDS offset is a select between two immediates
+    auto a_elem = [&](const float* base, int k0, int k1) -> float {
+        const int o0 = k0 < 27 ? ((k0 / 9) * PH + (k0 % 9) / 3) * PW + (k0 % 9) % 3 : 0;
+        const int o1 = k1 < 27 ? ((k1 / 9) * PH + (k1 % 9) / 3) * PW + (k1 % 9) % 3 : 0;
+        const float v = base[h ? o1 : o0];
+        return ((h ? k1 : k0) < 27) ? v : 0.f;
+    };
+    float* stage = stage_all + wave * (32 * (NT * 32 + 4));
     const int cstride = p.out_cstride;
-    epilogue_nhwc<T, MT, NT>(p, acc, stage, 0, lane, [&](int mt, int row) -> int64_t {
-        const int y = ty0 + wave * MT + mt, xx = tx0 + row;
-        return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
-    });
+    const int tiles_x = (p.OW + PT_TW - 1) / PT_TW;
+    for (int tt = 0; tt < C3_TPW; ++tt) {
+        const int tix = tix0 + tt;
+        if (tix >= tiles_x) break;  // workgroup-uniform
+        const int tx0 = tix * PT_TW;
+        if (tt > 0) __syncthreads();  // every wave has read the previous patch
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int i = tid + u * CONV_THREADS;
+            if (i < NEL) patch[i] = pv[u];
+        }
+        __syncthreads();
+        if (tt + 1 < C3_TPW && tix + 1 < tiles_x) patch_load(tx0 + PT_TW);  // in flight behind the MFMAs and the epilogue
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float* base = patch + (wave * MT + mt) * PW + r;
+                    bf16x8 afr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) afr[j] = (bf16_t)a_elem(base, ks * 16 + j, ks * 16 + 8 + j);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ks][nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float a = a_elem(patch + (wave * MT + mt) * PW + r, ks * 2, ks * 2 + 1);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[ks][nt][0], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        epilogue_nhwc<T, MT, NT>(p, acc, stage, 0, lane, [&](int mt, int row) -> int64_t {
+            const int y = ty0 + wave * MT + mt, xx = tx0 + row;
+            return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
+        });
+    }
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -1632,7 +1681,8 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     for (int t = 0; t < p.ntaps; ++t) FALNET_CHECK_ARG(p.tap_w[t] >= 0 && p.tap_w[t] < p.w_taps, "conv2d: tap_w[%d] out of range", t);
     FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0 && p.IH > 0 && p.IW > 0 && p.OH > 0 && p.OW > 0, "conv2d: empty shape");
     FALNET_CHECK_ARG(p.weight && (p.out || p.pool_out) && p.Cout > 0 && p.w_rows >= p.Cout && p.w_rows % 32 == 0, "conv2d: bad weight/out (Cout=%d w_rows=%d)", p.Cout, p.w_rows);
-    FALNET_CHECK_ARG(!p.pool_out || (p.out_layout == FALNET_OUT_NHWC && !p.actout && p.ksplit <= 1), "conv2d: pool_out needs a plain NHWC forward launch");
+    FALNET_CHECK_ARG(!p.pool_out || (p.out_layout == FALNET_OUT_NHWC && !p.actout && p.ksplit <= 1 && (p.pool_mode == 0 || p.pool_mode == 1)),
+                     "conv2d: pool_out needs a plain NHWC launch (no actout / split-K) and pool_mode 0|1");
     FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");
@@ -1703,7 +1753,7 @@ extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const
     p.out_cstride = Cout;
     p.bias = bias;
     p.act = act;
-    const int tiles_x = (W + PT_TW - 1) / PT_TW, tiles_y = (H + PT_TH - 1) / PT_TH;
+    const int tiles_x = ((W + PT_TW - 1) / PT_TW + C3_TPW - 1) / C3_TPW /* groups of C3_TPW tiles */, tiles_y = (H + PT_TH - 1) / PT_TH;
     const dim3 grid((unsigned)(B * tiles_x * tiles_y));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FALNET_BF16) {

@@ -11,6 +11,33 @@ static inline int ew_grid(int64_t n) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+__device__ __forceinline__ void store8_as(float* p, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8_as(bf16_t* p, const float (&v)[8]) {
+    uint4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
+        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = q;
+}
+__device__ __forceinline__ void load8_as(const float* p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8_as(const bf16_t* p, float (&v)[8]) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned w = (&q.x)[i];
+        v[2 * i] = __uint_as_float(w << 16);
+        v[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+    }
+}
+
 // planar f32 -> NHWC T.  A 64-pixel x Cpad tile goes through LDS so that both the planar reads
 // (64 consecutive pixels per channel) and the NHWC writes (Cpad contiguous per pixel) are coalesced.
 template <typename T>
@@ -27,6 +54,20 @@ __global__ __launch_bounds__(EW_THREADS) void nchw_to_nhwc_kernel(const float* _
         tile[px * ld + c] = (c < C && p < HW) ? src[((int64_t)b * C + c) * HW + p] : 0.f;
     }
     __syncthreads();
+    if (Cpad % 8 == 0) {  // 8 channels (16 B bf16 / 32 B f32) per thread
+        const int cg = Cpad / 8;
+        for (int i = threadIdx.x; i < 64 * cg; i += blockDim.x) {
+            const int px = i / cg, c0 = (i % cg) * 8;
+            const int64_t p = p0 + px;
+            if (p < HW) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[px * ld + c0 + j];
+                store8_as(dst + ((int64_t)b * HW + p) * Cpad + c0, v);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 64 * Cpad; i += blockDim.x) {
         const int px = i / Cpad, c = i % Cpad;
         const int64_t p = p0 + px;
@@ -129,6 +170,40 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_kernel(const T* __res
     }
 }
 
+// 8 channels per thread (C % 8 == 0): 16-B loads / stores
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                      T* __restrict__ gx, int B, int H, int W, int C) {
+    const int OH = H / 2, OW = W / 2, cg = C / 8;
+    const int64_t total = (int64_t)B * OH * OW * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * 8, ox = (int)((i / cg) % OW), oy = (int)((i / ((int64_t)cg * OW)) % OH);
+        const int b = (int)(i / ((int64_t)cg * OW * OH));
+        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c0;
+        const int64_t off[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+        float xv[4][8], g[8], o[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load8_as(x + base + off[j], xv[j]);
+        load8_as(gy + (((int64_t)b * OH + oy) * OW + ox) * C + c0, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float best = xv[0][e];
+            int arg = 0;
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (xv[j][e] > best) {
+                    best = xv[j][e];
+                    arg = j;
+                }
+            const float ge = best > 0.f ? g[e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j][e] = j == arg ? ge : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) store8_as(gx + base + off[j], o[j]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                              T* __restrict__ gx, int64_t n, int kind) {
@@ -203,6 +278,16 @@ extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy,
     (void)y;
     FALNET_CHECK_ARG(x && gy && gx && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0,
                      "maxpool2_bwd: bad argument (even H, W required)");
+    if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx) & 15) == 0) {
+        const int64_t tv = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+        if (dtype == FALNET_BF16)
+            hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<bf16_t>, dim3(ew_grid(tv)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                               (const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, B, H, W, C);
+        else
+            hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<float>, dim3(ew_grid(tv)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                               (const float*)x, (const float*)gy, (float*)gx, B, H, W, C);
+        FALNET_RETURN_LAUNCH();
+    }
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
     if (dtype == FALNET_BF16)
         hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,

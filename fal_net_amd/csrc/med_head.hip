@@ -260,16 +260,33 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_lds_kernel(
 }
 
 // ---------------------------------------------------------------------------------------- backward
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
+        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = q;
+}
 // grad_dlog0[n, x'] = (1-a) gwl_n(x'-k) + a gwl_n(x'-k-1) + gd(x') sm_n(x') (d_n - disp(x'))
 //   gwl_n(x) = Dprob_n(x) (sum_c gp_c(x) S_{c,n}(x) - q(x)),  q = sum_c gp_c p_c
 // Each (n, x') is owned by exactly one lane (gather form of the transposed warp): no atomics.
 // LDS rows (index x+1, one zero column in front and two behind):
 //   rowU[3] = gp_c / Zw, rowV = q / Zw, rowM = Mw   (at the *source* pixel x)
+// OUT = float: planar f32 [B][N][H][W] (the reference layout).  OUT = bf16_t / NHWC = true: pixel-major
+// [B][H][W][cpad] in the conv stack's compute dtype, channels >= N zero -- what the 1x1 logits conv's data / weight
+// gradient launches read, so no planar round trip + layout conversion launch in between.
+template <typename OUT, bool NHWC>
 __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
     const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
     const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
     const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,
-    float* __restrict__ gdlog0, int N, int H, int W) {
+    OUT* __restrict__ gdlog0, int N, int H, int W, int cpad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
     const int WP = W + 3;
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
     }
     __syncthreads();
     const float* Lrow = dlog0 + (int64_t)b * N * HW + rowoff;
-    float* Grow = gdlog0 + (int64_t)b * N * HW + rowoff;
+    OUT* Grow = NHWC ? gdlog0 + ((int64_t)b * HW + rowoff) * cpad : gdlog0 + (int64_t)b * N * HW + rowoff;
 
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         // per-pixel constants across planes
@@ -330,7 +347,14 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
             gd = gdisp[(int64_t)b * HW + rowoff + x];
             dsp = disp[(int64_t)b * HW + rowoff + x];
         }
-        for (int n = 0; n < N; ++n) {
+        float gv[8];
+        const int nend = NHWC ? cpad : N;
+        for (int n = 0; n < nend; ++n) {
+            if (NHWC && n >= N) {  // zero padding channels
+                gv[n & 7] = 0.f;
+                if ((n & 7) == 7) store8(Grow + (int64_t)x * cpad + (n - 7), gv);
+                continue;
+            }
             const float* Ln = Lrow + (int64_t)n * HW;
             const float Lc = Ln[x];
             float g = 0.f;
@@ -357,7 +381,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
                 }
             }
             if (has_disp) g += gd * __expf(Lc - m0) * rz0 * (tab.d[n] - dsp);
-            Grow[(int64_t)n * HW + x] = g;
+            if constexpr (NHWC) {
+                gv[n & 7] = g;
+                if ((n & 7) == 7) store8(Grow + (int64_t)x * cpad + (n - 7), gv);
+            } else {
+                Grow[(int64_t)n * HW + x] = (OUT)g;
+            }
         }
     }
 }
@@ -467,8 +496,28 @@ extern "C" int falnet_med_head_bwd(const float* dlog0, const float* left, const 
     FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd: grad_p_im0 needs left and p_im0");
     FALNET_CHECK_ARG(!grad_disp || disp, "med_head_bwd: grad_disp needs disp");
     const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
-    hipLaunchKernelGGL(med_head_bwd_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
-                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0, N, H, W);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<float, false>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
+                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0, N, H, W, 0);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, const float* min_disp,
+                                        const float* max_disp, const float* disp, const float* p_im0,
+                                        const float* stats, const float* grad_disp, const float* grad_p_im0,
+                                        void* grad_dlog0_nhwc, int cpad, int dtype, int B, int N, int H, int W, void* stream) {
+    if (int r = check_head(B, N, H, W)) return r;
+    FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && grad_dlog0_nhwc, "med_head_bwd_nhwc: null input");
+    FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd_nhwc: grad_p_im0 needs left and p_im0");
+    FALNET_CHECK_ARG(!grad_disp || disp, "med_head_bwd_nhwc: grad_disp needs disp");
+    FALNET_CHECK_ARG(cpad >= N && cpad % 8 == 0, "med_head_bwd_nhwc: cpad=%d must be a multiple of 8 >= N", cpad);
+    FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16, "med_head_bwd_nhwc: bad dtype %d", dtype);
+    const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
+    if (dtype == FALNET_BF16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<bf16_t, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
+                           min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (bf16_t*)grad_dlog0_nhwc, N, H, W, cpad);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<float, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
+                           min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (float*)grad_dlog0_nhwc, N, H, W, cpad);
     FALNET_RETURN_LAUNCH();
 }
 

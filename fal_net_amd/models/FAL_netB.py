@@ -14,6 +14,8 @@ fused Adam launch operate on that buffer, see fal_net_amd/train.py).
 torch.bfloat16 (bf16 MFMA with f32 accumulation; the throughput path).  Parameters, the MED head,
 losses and Adam stay f32 in both.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -140,10 +142,24 @@ class FalnetPlan:
                                       bias=pc.bias, addend=addend, act=act, name="fwd " + name,
                                       flops=2 * B * OH * OW * pc.cout * pc.cin * pc.taps))
 
-    def _dgrad(self, pc, group, gout, gin, IH, IW, addend=None, actout=None, name=""):
+    def _dgrad(self, pc, group, gout, gin, IH, IW, addend=None, actout=None, name="", sum2x2_into=None, sum2x2_actout=None):
         """Append launches computing gin = dgrad_group(gout) [+ addend] [* elu'(actout)].
-        gin lives on the conv's (virtual) input grid IH x IW; gout on its output grid."""
+        gin lives on the conv's (virtual) input grid IH x IW; gout on its output grid.
+        sum2x2_into: instead of storing gin, store its 2x2 block sums * elu'(sum2x2_actout) (the adjoint of the exact 2x
+        nearest upsampling in front of a deconv, FAL_netB.py:58) -- raises ValueError when no fused kernel applies."""
         B = self.B
+        if sum2x2_into is not None:
+            assert pc.stride == 1 and addend is None and actout is None
+            OH, OW = gout.shape[1], gout.shape[2]
+            off = sum(pc.groups_pad[:group]) * pc.taps * pc.cout_pad
+            cg = pc.groups_pad[group]
+            call = self._conv_call(
+                self.dtype, [ops.nhwc_src(gout)], OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(pc.ksize), pc.taps, cg, 1, B, IH, IW,
+                None, IH, IW, cg, sum2x2_into.shape[3], weight_offset_elems=off, name="dgrad+sum2x2 " + name,
+                flops=2 * B * OH * OW * pc.cout * pc.groups_real[group] * pc.taps, pool_out=sum2x2_into, pool_mode=1,
+                pool_actout=sum2x2_actout, pool_actout_kind=L.ACT_ELU if sum2x2_actout is not None else L.ACT_NONE)
+            self.bwd_body.append(call)
+            return
         OH, OW = gout.shape[1], gout.shape[2]
         off = sum(pc.groups_pad[:group]) * pc.taps * pc.cout_pad
         cg = pc.groups_pad[group]
@@ -288,13 +304,13 @@ class FalnetPlan:
 
         # =========================== backward plan ===========================
         g_disp, g_pan = self._f32("g_disp", B, 1, H, W), self._f32("g_pan", B, 3, H, W)
-        g_dlog0 = self._f32("g_dlog0", B, N, H, W)
+        G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, written NHWC by the head backward itself
 
         def head_bwd(has_disp, has_pan):
-            return ops.simple_call("falnet_med_head_bwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
+            return ops.simple_call("falnet_med_head_bwd_nhwc", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
                                    L.ptr(pan), L.ptr(stats), L.ptr(g_disp if has_disp else None),
-                                   L.ptr(g_pan if has_pan else None), L.ptr(g_dlog0), B, N, H, W,
-                                   nbytes=(2 * N + 7) * H * W * 4 * B)
+                                   L.ptr(g_pan if has_pan else None), L.ptr(G0), pad_c(N), code, B, N, H, W,
+                                   name="falnet_med_head_bwd", nbytes=(N + 7) * H * W * 4 * B + B * H * W * pad_c(N) * G0.element_size())
         self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
         # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
         # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: encoder levels 0-3.  After a bucket's
@@ -303,8 +319,6 @@ class FalnetPlan:
         self._bucket = 0
         self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
         self._side_call(self._x0_convert)
-        G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, NHWC
-        self.bwd_body.append(ops.simple_call("falnet_nchw_to_nhwc", L.ptr(g_dlog0), L.ptr(G0), B, N, H, W, pad_c(N), code))
         self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
         g_dlog = self._act("g_dlog", H, W, pad_c(N))
         self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
@@ -330,11 +344,19 @@ class FalnetPlan:
                 tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
                 self._dgrad(pcd, 0, g_dpre, tgt, hh, ww, actout=below, name=dname)
             else:
-                g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
-                self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
                 tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
-                self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
-                                                     ww, bh, bw, below_ch, code))
+                fused = False
+                if (2 * bh, 2 * bw) == (hh, ww) and os.environ.get("FALNET_FUSED_UPSUM", "1") == "1":
+                    try:  # exact 2x: the 2x2 block sum and elu'(below) ride in the data-gradient epilogue (no full-res g_up)
+                        self._dgrad(pcd, 0, g_dpre, None, hh, ww, name=dname, sum2x2_into=tgt, sum2x2_actout=below)
+                        fused = True
+                    except ValueError:
+                        pass
+                if not fused:
+                    g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
+                    self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
+                    self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
+                                                         ww, bh, bw, below_ch, code))
             if lvl < 6:
                 g_ipre[lvl + 1] = tgt
         # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)

@@ -182,7 +182,7 @@ def _fill_taps(d, taps):
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
               act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
-              autotune=True, ws_owner=None, pool_out=None):
+              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE):
     """Build one falnet_conv2d launch; returns a zero-argument callable.  `pool_out`: fused 2x2 max pool of the output
     (halo-patch kernels only; `out` may then be None when only the pooled map is needed)."""
     lib = L.lib()
@@ -199,6 +199,8 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.osy, d.osx, d.ooy, d.oox = out_step
     d.out, d.OH, d.OW, d.Cout, d.out_cstride, d.out_layout = (0 if out is None else out.data_ptr()), OH, OW, Cout, out_cstride, out_layout
     d.pool_out = 0 if pool_out is None else pool_out.data_ptr()
+    d.pool_mode, d.pool_actout_kind = pool_mode, pool_actout_kind
+    d.pool_actout = 0 if pool_actout is None else pool_actout.data_ptr()
     dev_t = out if out is not None else pool_out
     d.bias = 0 if bias is None else bias.data_ptr()
     d.addend = 0 if addend is None else addend.data_ptr()
@@ -212,7 +214,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.splitk_ws = 0 if ws is None else ws.data_ptr()
     d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
     ref = C.byref(d)
-    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out)
+    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout)
     if AUTOTUNE and autotune and out_layout == L.OUT_NHWC and dev_t.is_cuda:
         d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
     if pool_out is not None and lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:

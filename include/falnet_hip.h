@@ -95,10 +95,16 @@ typedef struct {
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
                                   6/7 = 3/4 on a 16x32-position block with 8 waves, 8/9 = 3/4 on a 4x32 block;
                                   -2 is returned when the variant does not apply */
-    void* pool_out;            /* optional fused 2x2/stride-2 max pool of the (activated) output: NHWC `dtype`
-                                  [B][OH/2][OW/2][out_cstride] (nn.MaxPool2d(2,2) after the VGG slices,
-                                  loss_functions.py:21-29).  Halo-patch variants with an even number of rows per wave
-                                  only (-2 otherwise); with pool_out set, `out` may be NULL (only the pooled map is kept) */
+    void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
+                                  [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,
+                                  loss_functions.py:21-29); pool_mode 1: sum, then multiplied by d act / d pre taken from
+                                  pool_actout (the adjoint of F.interpolate(scale 2, nearest) in front of a deconv,
+                                  FAL_netB.py:58, fused into that conv's data-gradient launch).  Halo-patch variants with an
+                                  even number of rows per wave only (-2 otherwise); with pool_out set, `out` may be NULL
+                                  (only the reduced map is kept) */
+    int32_t pool_mode;
+    int32_t pool_actout_kind;  /* FALNET_ACT_* of pool_actout */
+    const void* pool_actout;   /* NHWC like pool_out, or NULL */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
 /* First layer: 3x3 / stride 1 / pad 1 convolution of a 3-channel planar f32 image (FAL_netB.py:99 conv0, VGG19 features[0];
@@ -211,6 +217,12 @@ int falnet_med_head_bwd(const float* dlog0, const float* left, const float* min_
                         const float* disp, const float* p_im0, const float* stats,
                         const float* grad_disp, const float* grad_p_im0, float* grad_dlog0,
                         int B, int N, int H, int W, void* stream);
+/* the same gradient written pixel-major in the conv stack's layout: `dtype` NHWC [B][H][W][cpad], channels >= N zero
+ * (cpad % 8 == 0) -- feeds the 1x1 logits conv's data / weight gradient launches without a planar round trip */
+int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, const float* min_disp, const float* max_disp,
+                             const float* disp, const float* p_im0, const float* stats,
+                             const float* grad_disp, const float* grad_p_im0, void* grad_dlog0_nhwc, int cpad, int dtype,
+                             int B, int N, int H, int W, void* stream);
 /* occlusion masks (FAL_netB.py:264-273,291-292), no grad: maskR = min(1, sum_n shift_{+s_n}(softmax(dlog0)_n)),
  * maskL = min(1, sum_n shift_{-s_n}(Dprob_n)).  Dprob is rebuilt from the logits and `stats`. */
 int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp, const float* stats,

@@ -208,6 +208,41 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 64), (1, 128, 64, 24, 96), (1, 32, 96, 128, 256)])
+def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
+    """pool_mode 1: the 2x2 block sums of the conv output times elu'(low-resolution activation) -- the adjoint of the exact 2x
+    nearest upsampling (FAL_netB.py:58) folded into the deconv's data-gradient launch; the full-resolution map is not stored."""
+    case = (B, [cin], cout, H, W, 1, 3, False, L.ACT_NONE, False)
+    xs, w, b = _conv_inputs(case, seed=9)
+    full = _ref_conv(case, xs, w, None)
+    low_act = torch.randn(B, cout, H // 2, W // 2, generator=torch.Generator().manual_seed(3))
+    low_act = torch.where(low_act > 0, low_act, torch.expm1(low_act))  # an ELU output
+    ref = F.avg_pool2d(full, 2, 2) * 4 * torch.where(low_act > 0, torch.ones_like(low_act), low_act + 1)
+    pc = packed(w, None, [cin], 1, dtype)
+    x_t, act_t = to_nhwc(xs[0], dtype), to_nhwc(low_act, dtype)
+    ref = F.avg_pool2d(full, 2, 2) * 4 * torch.where(to_nchw(act_t, cout) > 0, torch.ones_like(low_act), to_nchw(act_t, cout) + 1)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV)
+        call = ops.conv_call(dtype, [ops.nhwc_src(x_t)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, None, H, W,
+                             pc.cout_pad, pc.cout_pad, pool_out=pooled, pool_mode=1, pool_actout=act_t, pool_actout_kind=L.ACT_ELU)
+    finally:
+        ops.AUTOTUNE = old
+    ran = []
+    for variant in range(1, 10):
+        call.desc.variant = variant
+        pooled.fill_(float("nan"))
+        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+        if rc == -2:
+            continue
+        assert rc == 0, (variant, L.lib().falnet_last_error())
+        assert rel(to_nchw(pooled, cout), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL), variant
+        ran.append(variant)
+    assert 4 in ran and len(ran) >= 2, ran
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,W,cout,act", [(2, 16, 64, 32, L.ACT_ELU), (1, 9, 13, 64, L.ACT_RELU), (2, 37, 70, 32, L.ACT_NONE),
                                             (1, 75, 250, 64, L.ACT_RELU)])
 def test_conv_first_layer_c3(B, H, W, cout, act, dtype):
@@ -366,6 +401,15 @@ def test_med_head(B, N, H, W, maxd):
     L.check(lib.falnet_med_head_bwd(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
                                     L.ptr(gd_d), L.ptr(gp_d), L.ptr(gl), B, N, H, W, L.stream_ptr()))
     assert rel(gl, dlog0.grad) < F32_TOL
+    # the same gradient written pixel-major (what the 1x1 logits conv's gradient launches consume): f32 identical to
+    # the planar one, bf16 = its rounding; padding channels zero
+    for dt in (torch.float32, torch.bfloat16):
+        cp = ops.pad_c(N)
+        gn = torch.full((B, H, W, cp), float("nan"), dtype=dt, device=DEV)
+        L.check(lib.falnet_med_head_bwd_nhwc(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
+                                             L.ptr(gd_d), L.ptr(gp_d), L.ptr(gn), cp, L.dtype_code(dt), B, N, H, W, L.stream_ptr()))
+        assert torch.equal(gn[..., :N].float(), gl.permute(0, 2, 3, 1).to(dt).float())
+        assert cp == N or float(gn[..., N:].float().abs().max()) == 0.0
     # disparity-only backward
     dlog0.grad = None
     (O.med_head(dlog0, left, mn, mx)["disp"] * gd).sum().backward()

@@ -13,6 +13,6 @@ for f in sorted(glob.glob("gpurun_out/pmc_${tag}_*/*/*counter_collection.csv")):
         k = r["Kernel_Name"][:60]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     for k, d in agg.items():
-        if "conv3x3" in k or "wgrad3x3" in k or "conv_igemm" in k:
+        if "conv3x3" in k or "wgrad3x3" in k or "conv_igemm" in k or "falnet" in k or "_kernel" in k and "at::" not in k:
             print(k, {c: f"{v:.3g}" for c, v in d.items()})
 PY

@@ -8,6 +8,25 @@ from fal_net_amd import _lib as L, ops
 ops.AUTOTUNE = False
 DEV, dtype, B = "cuda", torch.bfloat16, 8
 kind = sys.argv[1]
+if kind == "c3":  # first-layer kernel: prof_one.py c3 <cout 32|64> <H> <W>
+    cout, H, W = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    w = torch.nn.Parameter(torch.randn(cout, 3, 3, 3, device=DEV) * 0.2)
+    bias = torch.nn.Parameter(torch.randn(cout, device=DEV) * 0.1)
+    pc = ops.PackedConv("t", w, bias, [3], 1)
+    x = torch.randn(B, 3, H, W, device=DEV)
+    out = torch.empty(B, H, W, cout, dtype=dtype, device=DEV)
+    run = ops.conv_c3_call(dtype, x, pc, out, L.ACT_RELU)
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"c3 3->{cout} @{H}x{W}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us")
+    sys.exit(0)
 groups = [int(x) for x in sys.argv[2].split("+")]
 cout, H, W = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 cin = sum(groups)
