@@ -187,6 +187,152 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
     }
 }
 
+// ---- direct epilogue (halo-patch and first-layer kernels) ---------------------------------------------------------
+// With the MFMA operands exchanged (A = weights, B = pixels) the 32x32 C/D tile puts one PIXEL on each lane and sixteen
+// channels in its accumulators: acc[j] = channel 8*(j>>2) + 4*h + (j&3) of the tile, i.e. four groups of four consecutive
+// channels, lane halves h = 0/1 interleaved.  f32: every group is one 16-B store.  bf16: a group is 8 B; one
+// v_permlane32_swap per dword exchanges the upper half's group k with the lower half's group k+1, after which lanes 0-31
+// hold channels 8k..8k+7 and lanes 32-63 channels 8k+8..8k+15 of their pixel: one 16-B store per group pair
+// (cdna_hip_programming.md T21).  No LDS staging, no wave barriers; residual / activation-output operands are read in
+// the same 16-B chunks and un-swapped with the same (involutive) exchange.
+__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {  // lanes 32-63 of a <-> lanes 0-31 of b
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const bf16_t l = (bf16_t)lo, u = (bf16_t)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, u) << 16);
+}
+// this lane's 16 channels (accumulator order) of pixel offset o (-1: none) from an NHWC tensor; cbase = first channel of the tile
+template <typename T>
+__device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o, int cbase, int h, int Cout, float (&v)[16]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 c[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cb = cbase + 16 * q + 8 * h;
+            c[q] = (o >= 0 && cb < Cout) ? *reinterpret_cast<const uint4*>(base + o + cb) : make_uint4(0, 0, 0, 0);
+            half_swap(c[q].x, c[q].z);
+            half_swap(c[q].y, c[q].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned w0 = (k & 1) ? c[k >> 1].z : c[k >> 1].x, w1 = (k & 1) ? c[k >> 1].w : c[k >> 1].y;
+            v[4 * k + 0] = __uint_as_float(w0 << 16);
+            v[4 * k + 1] = __uint_as_float(w0 & 0xffff0000u);
+            v[4 * k + 2] = __uint_as_float(w1 << 16);
+            v[4 * k + 3] = __uint_as_float(w1 & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cbase + 8 * k + 4 * h;
+            const float4 f = (o >= 0 && cb < Cout) ? *reinterpret_cast<const float4*>(base + o + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[4 * k + 0] = f.x;
+            v[4 * k + 1] = f.y;
+            v[4 * k + 2] = f.z;
+            v[4 * k + 3] = f.w;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int cbase, int h, int Cout, const float (&v)[16]) {
+    if constexpr (sizeof(T) == 2) {
+        unsigned w[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[k][0] = pack_bf16x2(v[4 * k + 0], v[4 * k + 1]);
+            w[k][1] = pack_bf16x2(v[4 * k + 2], v[4 * k + 3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half_swap(w[2 * q][0], w[2 * q + 1][0]);
+            half_swap(w[2 * q][1], w[2 * q + 1][1]);
+            const int cb = cbase + 16 * q + 8 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<uint4*>(base + o + cb) = make_uint4(w[2 * q][0], w[2 * q][1], w[2 * q + 1][0], w[2 * q + 1][1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cbase + 8 * k + 4 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<float4*>(base + o + cb) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+    }
+}
+// PixOff(mt) -> element offset of channel 0 of this lane's pixel in slab mt (or -1); PoolOff(mt) (odd mt, even column)
+// -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool>
+__device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], int nbase, int lane, PixOff pixoff,
+                                                PoolOff pooloff = PoolOff()) {
+    constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
+    const int h = lane >> 5;
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    T* out = reinterpret_cast<T*>(p.out);
+    T* pool_out = reinterpret_cast<T*>(p.pool_out);
+    const bool pooling = POOL && pool_out != nullptr;
+    const bool psum = p.pool_mode == 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cbase = nbase + nt * 32;
+        float bias[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
+            bias[j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        }
+        float hp[16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t o = pixoff(mt);
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[j];
+            if (addend) {  // workgroup-uniform branches: the half swaps inside need every lane
+                float a[16];
+                tile_load<T>(addend, o, cbase, h, p.Cout, a);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] += a[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = apply_act(v[j], p.act);
+            if (actout) {
+                float a[16];
+                tile_load<T>(actout, o, cbase, h, p.Cout, a);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] *= act_grad_from_out(a[j], p.actout_kind);
+            }
+            if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
+            if constexpr (POOL) {
+                if (pooling) {
+                    float m[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const float nb = __shfl_xor(v[j], 1);  // column neighbour (lane ^ 1: same half, same row)
+                        m[j] = psum ? v[j] + nb : fmaxf(v[j], nb);
+                    }
+                    if ((mt & 1) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) hp[j] = m[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) m[j] = psum ? m[j] + hp[j] : fmaxf(m[j], hp[j]);
+                        const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
+                        if (p.pool_actout) {
+                            float a[16];
+                            tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m[j] *= act_grad_from_out(a[j], p.pool_actout_kind);
+                        }
+                        tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int MT, int NT, bool SWAP>
 __device__ __forceinline__ void mma_tile(const char* __restrict__ As, const char* __restrict__ Bs, int arow0, int brow0,
                                          int lane, f32x16 (&acc)[MT][NT]) {
@@ -506,7 +652,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
 // the MFMAs of step i (three fragment sets in flight): the ~128-cycle ds_read latency is covered by two steps of
 // MFMAs instead of being exposed in front of every small MFMA group, so one or two waves per SIMD keep the matrix
 // pipe busy.  a_of(step, mt) / b_of(step, nt) return the 16-B fragment address of this lane.
-template <typename T, int MT, int NT, int NSTEP, typename AOf, typename BOf>
+template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, typename AOf, typename BOf>
 __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT]) {
     uint4 fa[3][MT], fb[3][NT];
     auto load = [&](int step, int slot) {
@@ -533,8 +679,9 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][mt]),
-                                                                          __builtin_bit_cast(bf16x8, fb[sl][nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = SWAPAB  // exchanged operands: pixels on lanes, channels in the accumulators (epilogue_direct)
+                        ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[sl][nt]), __builtin_bit_cast(bf16x8, fa[sl][mt]), acc[mt][nt], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][mt]), __builtin_bit_cast(bf16x8, fb[sl][nt]), acc[mt][nt], 0, 0, 0);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -542,8 +689,9 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fa[sl][mt].x)[e]),
-                                                                           __uint_as_float((&fb[sl][nt].x)[e]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = SWAPAB
+                            ? __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fb[sl][nt].x)[e]), __uint_as_float((&fa[sl][mt].x)[e]), acc[mt][nt], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fa[sl][mt].x)[e]), __uint_as_float((&fb[sl][nt].x)[e]), acc[mt][nt], 0, 0, 0);
         }
     }
 }
@@ -706,7 +854,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         constexpr int t0 = decltype(t0c)::value, NTAPS = decltype(ntapsc)::value;
         const char* ab = A + a_lane;
         const char* bb = Btile + b_lane;
-        mma_steps<T, MT, NT, NTAPS * KSEG>(
+        mma_steps<T, MT, NT, NTAPS * KSEG, true>(
             [&](int st, int mt) { const int t = t0 + st / KSEG, ks = st % KSEG;
                                   return ab + (mt * PT_PW * PITCH + ((t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
             [&](int st, int nt) { const int tt = st / KSEG, ks = st % KSEG;
@@ -823,25 +971,23 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         }
     }
 
-    // ---- epilogue (same contract as the gather kernel): per-wave LDS staging, 16-B stores ----
-    __syncthreads();  // every wave is done with the A/B buffers
+    // ---- epilogue (same contract as the gather kernel), straight from the accumulators: 16-B stores, no LDS ----
     {
-        float* stage = reinterpret_cast<float*>(lds) + wave * (32 * (NT * 32 + 4));
-        static_assert(NWAVES * 32 * (NT * 32 + 4) * 4 <= (ADB ? 2 : 1) * A_BYTES + ((PIPE || DBS) ? 2 : 1) * B_BYTES, "staging must fit in the LDS buffers");
         const int cstride = p.out_cstride;
-        auto rowoff = [&](int mt, int row) -> int64_t {
-            const int y = ty0 + wm * MT + mt, x = tx0 + row;
+        const int x = tx0 + r;
+        auto pixoff = [&](int mt) -> int64_t {
+            const int y = ty0 + wm * MT + mt;
             return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
         };
         if constexpr (MT % 2 == 0) {
-            // fused 2x2 max pool (p.pool_out): block rows start even and every wave owns an even number of rows
-            auto pooloff = [&](int mt, int row) -> int64_t {
-                const int py = (ty0 + wm * MT + mt) >> 1, px = (tx0 + row) >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+            // fused 2x2 reduction (p.pool_out): block rows start even and every wave owns an even number of rows
+            auto pooloff = [&](int mt) -> int64_t {
+                const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
                 return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
             };
-            epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, rowoff, pooloff);
+            epilogue_direct<T, MT, NT>(p, acc, n0 + wn * WTN, lane, pixoff, pooloff);
         } else {
-            epilogue_nhwc<T, MT, NT>(p, acc, stage, n0 + wn * WTN, lane, rowoff);
+            epilogue_direct<T, MT, NT>(p, acc, n0 + wn * WTN, lane, pixoff);
         }
     }
 }
@@ -858,7 +1004,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
                                                                   const falnet_conv_t p, int groups_x, int tiles_y) {
     constexpr int PH = PT_TH + 2, PW = PT_PW, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
     __shared__ __attribute__((aligned(16))) float patch[NEL];                       // [3][PH][PW] f32
-    __shared__ __attribute__((aligned(16))) float stage_all[4 * 32 * (NT * 32 + 4)];  // per-wave epilogue staging slabs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     int bid = blockIdx.x;
@@ -920,7 +1065,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
         const float v = base[h ? o1 : o0];
         return ((h ? k1 : k0) < 27) ? v : 0.f;
     };
-    float* stage = stage_all + wave * (32 * (NT * 32 + 4));
     const int cstride = p.out_cstride;
     const int tiles_x = (p.OW + PT_TW - 1) / PT_TW;
     for (int tt = 0; tt < C3_TPW; ++tt) {
@@ -952,7 +1096,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
 #pragma unroll
                     for (int j = 0; j < 8; ++j) afr[j] = (bf16_t)a_elem(base, ks * 16 + j, ks * 16 + 8 + j);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[ks][nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][nt], afr, acc[mt][nt], 0, 0, 0);
                 }
             }
         } else {
@@ -962,12 +1106,12 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
                 for (int mt = 0; mt < MT; ++mt) {
                     const float a = a_elem(patch + (wave * MT + mt) * PW + r, ks * 2, ks * 2 + 1);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wv[ks][nt][0], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ks][nt][0], a, acc[mt][nt], 0, 0, 0);
                 }
             }
         }
-        epilogue_nhwc<T, MT, NT>(p, acc, stage, 0, lane, [&](int mt, int row) -> int64_t {
-            const int y = ty0 + wave * MT + mt, xx = tx0 + row;
+        epilogue_direct<T, MT, NT>(p, acc, 0, lane, [&](int mt) -> int64_t {  // operands exchanged above: pixels on lanes
+            const int y = ty0 + wave * MT + mt, xx = tx0 + r;
             return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
         });
     }
