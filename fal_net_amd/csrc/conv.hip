@@ -260,11 +260,44 @@ __device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int 
         }
     }
 }
+// activation / activation-gradient on one 16-value tile: the (workgroup-uniform) kind is switched ONCE per tile
+__device__ __forceinline__ void act16(float (&v)[16], int act) {
+    if (act == FALNET_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = v[j] > 0.f ? v[j] : (__expf(v[j]) - 1.f);
+    } else if (act == FALNET_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+}
+__device__ __forceinline__ void actgrad16(float (&v)[16], const float (&y)[16], int kind) {
+    if (kind == FALNET_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= y[j] > 0.f ? 1.f : y[j] + 1.f;
+    } else if (kind == FALNET_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+    }
+}
+// bias of this lane's 16 channels per 32-channel tile (accumulator order)
+template <int NT>
+__device__ __forceinline__ void load_bias16(const falnet_conv_t& p, int nbase, int h, float (&bias)[NT][16]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = nbase + nt * 32 + 8 * (j >> 2) + 4 * h + (j & 3);
+            bias[nt][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        }
+}
+__device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
 // PixOff(mt) -> element offset of channel 0 of this lane's pixel in slab mt (or -1); PoolOff(mt) (odd mt, even column)
 // -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
 template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool>
-__device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], int nbase, int lane, PixOff pixoff,
-                                                PoolOff pooloff = PoolOff()) {
+__device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
+                                                PixOff pixoff, PoolOff pooloff = PoolOff()) {
     constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
     const int h = lane >> 5;
     const T* addend = reinterpret_cast<const T*>(p.addend);
@@ -276,54 +309,52 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cbase = nbase + nt * 32;
-        float bias[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
-            bias[j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
-        }
         float hp[16];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t o = pixoff(mt);
             float v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[j];
+            for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
             if (addend) {  // workgroup-uniform branches: the half swaps inside need every lane
                 float a[16];
                 tile_load<T>(addend, o, cbase, h, p.Cout, a);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] += a[j];
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = apply_act(v[j], p.act);
+            act16(v, p.act);
             if (actout) {
                 float a[16];
                 tile_load<T>(actout, o, cbase, h, p.Cout, a);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] *= act_grad_from_out(a[j], p.actout_kind);
+                actgrad16(v, a, p.actout_kind);
             }
             if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
             if constexpr (POOL) {
                 if (pooling) {
                     float m[16];
+                    if (psum) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float nb = __shfl_xor(v[j], 1);  // column neighbour (lane ^ 1: same half, same row)
-                        m[j] = psum ? v[j] + nb : fmaxf(v[j], nb);
+                        for (int j = 0; j < 16; ++j) m[j] = v[j] + lane_xor1(v[j]);  // column neighbour (same half, same row)
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) m[j] = fmaxf(v[j], lane_xor1(v[j]));
                     }
                     if ((mt & 1) == 0) {
 #pragma unroll
                         for (int j = 0; j < 16; ++j) hp[j] = m[j];
                     } else {
+                        if (psum) {
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) m[j] = psum ? m[j] + hp[j] : fmaxf(m[j], hp[j]);
+                            for (int j = 0; j < 16; ++j) m[j] += hp[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m[j] = fmaxf(m[j], hp[j]);
+                        }
                         const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
                         if (p.pool_actout) {
                             float a[16];
                             tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) m[j] *= act_grad_from_out(a[j], p.pool_actout_kind);
+                            actgrad16(m, a, p.pool_actout_kind);
                         }
                         tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
                     }
@@ -652,8 +683,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
 // the MFMAs of step i (three fragment sets in flight): the ~128-cycle ds_read latency is covered by two steps of
 // MFMAs instead of being exposed in front of every small MFMA group, so one or two waves per SIMD keep the matrix
 // pipe busy.  a_of(step, mt) / b_of(step, nt) return the 16-B fragment address of this lane.
-template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, typename AOf, typename BOf>
-__device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT]) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// Hook(step) runs after the MFMAs of every step, pinned in program order: work that must ISSUE while the matrix pipe is
+// busy (global loads of the next block, the previous block's stores) instead of in front of / behind the whole sequence.
+template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, typename AOf, typename BOf, typename Hook = NoHook>
+__device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT], Hook hook = Hook()) {
     uint4 fa[3][MT], fb[3][NT];
     auto load = [&](int step, int slot) {
 #pragma unroll
@@ -692,6 +726,11 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
                         acc[mt][nt] = SWAPAB
                             ? __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fb[sl][nt].x)[e]), __uint_as_float((&fa[sl][mt].x)[e]), acc[mt][nt], 0, 0, 0)
                             : __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float((&fa[sl][mt].x)[e]), __uint_as_float((&fb[sl][nt].x)[e]), acc[mt][nt], 0, 0, 0);
+        }
+        if constexpr (!std::is_same<Hook, NoHook>::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            hook(st);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -973,6 +1012,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
 
     // ---- epilogue (same contract as the gather kernel), straight from the accumulators: 16-B stores, no LDS ----
     {
+        float bias[NT][16];
+        load_bias16<NT>(p, n0 + wn * WTN, h, bias);
         const int cstride = p.out_cstride;
         const int x = tx0 + r;
         auto pixoff = [&](int mt) -> int64_t {
@@ -985,11 +1026,205 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
                 const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
                 return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
             };
-            epilogue_direct<T, MT, NT>(p, acc, n0 + wn * WTN, lane, pixoff, pooloff);
+            epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * WTN, lane, pixoff, pooloff);
         } else {
-            epilogue_direct<T, MT, NT>(p, acc, n0 + wn * WTN, lane, pixoff);
+            epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * WTN, lane, pixoff);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ weight-stationary 3x3
+// The halo-patch kernels above re-stage the nine weight tap tiles for every 8x32-position block: with <= 64 input channels
+// that is ~2/3 of the bytes a workgroup pulls through its CU's load path (~10 B/clk), which is what bounds them
+// (PMC: DESIGN.md).  For these layers (the full-resolution ones: VGG conv1_2/2_1, iconv1, deconv1, the level-0/1 residual
+// blocks and their data gradients) ALL weights of a BN-channel slice fit in LDS next to one patch, so a persistent
+// workgroup loads them ONCE and then streams blocks: per block only the (8+2)x(32+2) input patch crosses the load path,
+// prefetched into registers behind the previous block's MFMAs.  K chunks are 64 B (32 bf16 / 16 f32 channels), NCH <= 2.
+//   LDS: W [NCH][9][BN][80 B] + A [NCH][340][80 B]  (BN=64, NCH=2: 92 KB + 54 KB)
+//   4 waves, each 2 rows x BN channels of the block (MT = 2, NT = BN/32); epilogue straight from the accumulators.
+template <typename T, int BN, int NCH>
+__global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
+    // eight waves = two per SIMD: while one wave sits in a load / store issue or in its epilogue arithmetic the other one
+    // keeps the matrix pipe fed (in-kernel stamps at one wave per SIMD: MFMA 36 % of a block, load issue 25 %, epilogue 32 %).
+    //   BN = 64: 8x32 positions, waves 4 (rows) x 2 (32-channel halves);  BN = 32: 16x32 positions, waves 8 x 1.
+    constexpr int NTHR = 512, WAVES_N = BN / 32, WAVES_M = 8 / WAVES_N;
+    constexpr int MT = 2, NT = 1, TH = MT * WAVES_M;
+    constexpr int KCB = 64, PITCH = KCB + 16, SEGS = KCB / 16;
+    constexpr int NPIX = (TH + 2) * PT_PW;
+    constexpr int KCV = KCB / (int)sizeof(T), EPS = 16 / (int)sizeof(T);
+    constexpr int W_BYTES = NCH * 9 * BN * PITCH, A_BYTES = NCH * NPIX * PITCH;
+    constexpr int W_LOADS = NCH * 9 * BN * SEGS, W_SLOTS = (W_LOADS + NTHR - 1) / NTHR;
+    static_assert(W_BYTES + A_BYTES <= 160 * 1024, "weights + one patch must fit in LDS");
+    __shared__ __attribute__((aligned(16))) char lds[W_BYTES + A_BYTES];
+    char* Wl = lds;
+    char* Al = lds + W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- weights: once per workgroup.  LDS tile (chunk c, spatial tap t) <- packed tap (flip ? 8-t : t), channels [c*KCV, +KCV)
+    {
+        uint4 wreg[W_SLOTS];
+#pragma unroll
+        for (int u = 0; u < W_SLOTS; ++u) {
+            const int idx = tid + u * NTHR;
+            wreg[u] = make_uint4(0, 0, 0, 0);
+            if (idx < W_LOADS) {
+                const int seg = idx % SEGS, row = (idx / SEGS) % BN, t = (idx / (SEGS * BN)) % 9, c = idx / (SEGS * BN * 9);
+                if (n0 + row < p.w_rows && c * KCV < p.cin_total)
+                    wreg[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.weight) +
+                                                              ((int64_t)(n0 + row) * p.w_taps + (flip ? 8 - t : t)) * p.cin_total + c * KCV + seg * EPS);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < W_SLOTS; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < W_LOADS) {
+                const int seg = idx % SEGS, row = (idx / SEGS) % BN, tc = idx / (SEGS * BN);  // tc = c*9 + t
+                *reinterpret_cast<uint4*>(Wl + (tc * BN + row) * PITCH + seg * 16) = wreg[u];
+            }
+        }
+    }
+    // ---- patch slots of this thread, per chunk: (patch pixel, 16-B segment).  Chunk c = channels [c*KCV, +KCV) of the
+    // concatenated sources; its source and everything read from the descriptor are workgroup-uniform scalars hoisted here
+    // (a per-lane source index would turn every descriptor field into a vector memory load inside the block loop).
+    constexpr int C_LOADS = NPIX * SEGS, C_SLOTS = (C_LOADS + NTHR - 1) / NTHR;
+    const T* c_ptr[NCH];
+    int64_t c_sb[NCH], c_sy[NCH];
+    int c_sx[NCH], c_hs[NCH], c_ws[NCH];
+    bool c_ok[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int sidx = 0, c0 = c * KCV;
+        if (c0 >= p.src[0].C) {
+            c0 -= p.src[0].C;
+            sidx = 1;
+        }
+        c_ok[c] = sidx < p.nsrc && c0 < (sidx ? p.src[1].C : p.src[0].C);
+        c_ptr[c] = reinterpret_cast<const T*>(sidx ? p.src[1].ptr : p.src[0].ptr) + c0;
+        c_sb[c] = sidx ? p.src[1].sb : p.src[0].sb;
+        c_sy[c] = sidx ? p.src[1].sy : p.src[0].sy;
+        c_sx[c] = (int)(sidx ? p.src[1].sx : p.src[0].sx);
+        c_hs[c] = (sidx ? p.src[1].H : p.src[0].H) != p.IH ? 1 : 0;  // exact 2x nearest upsampling (checked by the dispatcher)
+        c_ws[c] = (sidx ? p.src[1].W : p.src[0].W) != p.IW ? 1 : 0;
+    }
+    int a_lds[C_SLOTS], a_pp[C_SLOTS];  // LDS byte offset inside a chunk's patch (-1: no slot); (seg*EPS << 16 | pr << 8 | pc)
+#pragma unroll
+    for (int u = 0; u < C_SLOTS; ++u) {
+        const int idx = tid + u * NTHR;
+        a_lds[u] = -1;
+        a_pp[u] = 0;
+        if (idx < C_LOADS) {
+            const int seg = idx % SEGS, px = idx / SEGS;
+            a_lds[u] = px * PITCH + seg * 16;
+            a_pp[u] = ((seg * EPS) << 16) | ((px / PT_PW) << 8) | (px % PT_PW);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (!c_ok[c]) {  // chunk beyond the sources: zero once
+#pragma unroll
+            for (int u = 0; u < C_SLOTS; ++u)
+                if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(Al + c * NPIX * PITCH + a_lds[u]) = make_uint4(0, 0, 0, 0);
+        }
+
+    const int ntiles = p.B * tiles_y * tiles_x;
+    uint4 areg[NCH][C_SLOTS];
+    auto patch_load = [&](int tile) {
+        const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int ty0 = tiy * TH, tx0 = tix * PT_TW;
+#pragma unroll
+        for (int u = 0; u < C_SLOTS; ++u) {
+            const int pp = a_pp[u];
+            const int vy = ty0 - 1 + ((pp >> 8) & 0xff), vx = tx0 - 1 + (pp & 0xff);
+            const bool ok = a_lds[u] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok && c_ok[c])
+                    v = *reinterpret_cast<const uint4*>(c_ptr[c] + (int64_t)b * c_sb[c] + (int64_t)(vy >> c_hs[c]) * c_sy[c] + (vx >> c_ws[c]) * c_sx[c] + (pp >> 16));
+                areg[c][u] = v;
+            }
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c_ok[c]) {
+#pragma unroll
+                for (int u = 0; u < C_SLOTS; ++u)
+                    if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(Al + c * NPIX * PITCH + a_lds[u]) = areg[c][u];
+            }
+    };
+
+    constexpr int KSEG = KCB / 32;
+    const int lane_k = sizeof(T) == 2 ? h * 16 : h * (KCB / 2);
+    constexpr int KSTRIDE = sizeof(T) == 2 ? 32 : 16;
+    const char* ab = Al + ((wm * MT) * PT_PW + r) * PITCH + lane_k;
+    const char* bb = Wl + (wn * 32 + r) * PITCH + lane_k;
+
+    float bias[NT][16];
+    load_bias16<NT>(p, n0 + wn * 32, h, bias);
+    int tile = blockIdx.x;
+    if (tile < ntiles) patch_load(tile);
+#ifdef FALNET_WS_STAMPS
+    // profiling build (tools/ws_stamps.py): per-phase s_memtime stamps of workgroup 0, every wave -> p.splitk_ws
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
+    int stamp_i = 0;
+#define WS_STAMP()                                                                                       \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        unsigned long long t_;                                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (stamp_out && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 4 && stamp_i < 256) stamp_out[(wave & 3) * 256 + stamp_i] = t_; \
+        ++stamp_i;                                                                                       \
+    } while (0)
+#else
+#define WS_STAMP() do {} while (0)
+#endif
+    for (; tile < ntiles; tile += gridDim.x) {
+        WS_STAMP();  // 0: loop top
+        __syncthreads();  // every wave has finished reading the previous patch (first pass: the weight / zero stores are ordered below)
+        WS_STAMP();  // 1: after barrier A
+        patch_store();
+        WS_STAMP();  // 2: after the patch stores (includes the wait for the prefetched loads)
+        __syncthreads();
+        WS_STAMP();  // 3: after barrier B
+        const int next = tile + gridDim.x;
+        if (next < ntiles) patch_load(next);  // in flight behind this block's MFMAs and epilogue
+        WS_STAMP();  // 4: prefetch issued
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+        // steps: (chunk, tap, k-segment), all operand addresses = lane base + immediate
+        mma_steps<T, MT, NT, NCH * 9 * KSEG, true>(
+            [&](int st, int mt) { const int c = st / (9 * KSEG), t = (st / KSEG) % 9, ks = st % KSEG;
+                                  return ab + ((c * NPIX + mt * PT_PW + (t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
+            [&](int st, int nt) { const int tc = st / KSEG, ks = st % KSEG;
+                                  return bb + ((tc * BN + nt * 32) * PITCH + ks * KSTRIDE); },
+            acc);
+        WS_STAMP();  // 5: MFMAs done (issued)
+        const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int ty0 = tiy * TH, x = tix * PT_TW + r;
+        const int cstride = p.out_cstride;
+        auto pixoff = [&](int mt) -> int64_t {
+            const int y = ty0 + wm * MT + mt;
+            return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
+        };
+        auto pooloff = [&](int mt) -> int64_t {
+            const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+            return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+        };
+        epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * 32, lane, pixoff, pooloff);
+        WS_STAMP();  // 6: epilogue done
+    }
+#undef WS_STAMP
 }
 
 // ------------------------------------------------------------------------------------------ first layer (Cin = 3)
@@ -1067,6 +1302,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
     };
     const int cstride = p.out_cstride;
     const int tiles_x = (p.OW + PT_TW - 1) / PT_TW;
+    float bias[NT][16];
+    load_bias16<NT>(p, 0, h, bias);
     for (int tt = 0; tt < C3_TPW; ++tt) {
         const int tix = tix0 + tt;
         if (tix >= tiles_x) break;  // workgroup-uniform
@@ -1110,7 +1347,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* _
                 }
             }
         }
-        epilogue_direct<T, MT, NT>(p, acc, 0, lane, [&](int mt) -> int64_t {  // operands exchanged above: pixels on lanes
+        epilogue_direct<T, MT, NT>(p, acc, bias, 0, lane, [&](int mt) -> int64_t {  // operands exchanged above: pixels on lanes
             const int y = ty0 + wave * MT + mt, xx = tx0 + r;
             return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
         });
@@ -1710,7 +1947,7 @@ static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t s
 
 // The dispatcher's decision for one launch; shared by falnet_conv2d and falnet_conv2d_kernel_name.
 struct ConvChoice {
-    int patch;               // 1: conv3x3_patch_kernel, 0: conv_igemm_kernel
+    int patch;               // 1: conv3x3_patch_kernel, 0: conv_igemm_kernel, 2: conv3x3_ws_kernel (kcb = chunks)
     int bn, kcb, tps, adb, th, nwaves, flip, swap;
 };
 
@@ -1752,7 +1989,24 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
     int variant = p.variant;
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG(variant >= 0 && variant <= 9, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG(variant >= 0 && variant <= 10, "conv2d: unknown variant %d", variant);
+    if (variant == 10) {
+        // weight-stationary persistent kernel: every K chunk of a BN-channel weight slice stays in LDS
+        bool ok = dense3x3 && ctot * esz <= 128 && ctot * esz % 64 == 0 && p.src[0].C * esz % 64 == 0;
+        for (int s = 0; s < p.nsrc && ok; ++s)  // sources at the launch size or exactly 2x upsampled
+            ok = (p.src[s].H == p.IH || 2 * p.src[s].H == p.IH) && (p.src[s].W == p.IW || 2 * p.src[s].W == p.IW) && p.src[s].C < 4096;
+        if (!ok) {
+            falnet_set_error("conv2d: variant 10 needs a dense 3x3 launch with <= 128 B of input channels per pixel");
+            return -2;
+        }
+        c.flip = flip;
+        c.swap = 0;
+        c.patch = 2;
+        c.bn = (p.w_rows % 64 == 0 && p.Cout > 32) ? 64 : 32;
+        c.kcb = ctot * esz / 64;  // chunks
+        c.tps = 9; c.adb = 0; c.th = c.bn == 64 ? 8 : 16; c.nwaves = 8;
+        return 0;
+    }
     if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || ((variant == 3 || variant == 5 || variant == 6 || variant == 8) && ctot / (64 / esz) < 2) ||
                          ((variant == 6 || variant == 7) && p.OH < 16))) {
         falnet_set_error("conv2d: variant %d not applicable to this launch", variant);
@@ -1802,7 +2056,9 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : "f";
-    if (c.patch)
+    if (c.patch == 2)
+        snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb);
+    else if (c.patch)
         snprintf(buf, len, "_Z20conv3x3_patch_kernelI%sLi%dELi%dELi%dELb%dELi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, c.tps, c.adb, c.th, c.nwaves);
     else
         snprintf(buf, len, "_Z17conv_igemm_kernelI%sLi%dELb%dEEv13falnet_conv_t", t, c.bn, c.swap);
@@ -1833,6 +2089,25 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 2) {
+        const int ws_th = c.bn == 64 ? 8 : 16;
+        const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;
+        const int ny = (p.Cout + c.bn - 1) / c.bn, ntiles = p.B * tiles_x * tiles_y;
+        int gx = 256 / ny;  // one persistent workgroup per CU (146 KB of LDS each)
+        if (gx < 1) gx = 1;
+        if (gx > ntiles) gx = ntiles;
+        const dim3 grid((unsigned)gx, (unsigned)ny);
+#define LAUNCH_WS(T, BN, NCH) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip)
+        if (p.dtype == FALNET_BF16) {
+            if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(bf16_t, 64, 2); else LAUNCH_WS(bf16_t, 64, 1); }
+            else { if (c.kcb == 2) LAUNCH_WS(bf16_t, 32, 2); else LAUNCH_WS(bf16_t, 32, 1); }
+        } else {
+            if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(float, 64, 2); else LAUNCH_WS(float, 64, 1); }
+            else { if (c.kcb == 2) LAUNCH_WS(float, 32, 2); else LAUNCH_WS(float, 32, 1); }
+        }
+#undef LAUNCH_WS
+        FALNET_RETURN_LAUNCH();
+    }
     if (c.patch) {
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + c.th - 1) / c.th;
         const dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + c.bn - 1) / c.bn));

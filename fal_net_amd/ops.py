@@ -286,7 +286,7 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     wgs = ((M + 127) // 128) * ((Cout + bn - 1) // bn)
     if wgs < 256 and M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
         cands += [(1, k) for k in (2, 4, 8, 16) if wgs * k <= 2048]
-    cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1)]
+    cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1), (10, 1)]
     if wgs < 512:
         cands += [(8, 1), (9, 1)]
     best, best_t = (1, 1), None

@@ -94,6 +94,7 @@ typedef struct {
     int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
                                   6/7 = 3/4 on a 16x32-position block with 8 waves, 8/9 = 3/4 on a 4x32 block;
+                                  10 weight-stationary persistent kernel (<= 128 B of input channels per pixel);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

@@ -130,7 +130,8 @@ def test_conv_forward(case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [PATCH_CASES[0], PATCH_CASES[1], PATCH_CASES[3], PATCH_CASES[4],
-                                  (2, [64], 128, 40, 70, 1, 3, True, L.ACT_ELU, True), (1, [32, 64], 64, 33, 64, 1, 3, False, L.ACT_ELU, False)])
+                                  (2, [64], 128, 40, 70, 1, 3, True, L.ACT_ELU, True), (1, [32, 64], 64, 33, 64, 1, 3, False, L.ACT_ELU, False),
+                                  (3, [32, 32], 49, 21, 75, 1, 3, True, L.ACT_NONE, True), (2, [64], 64, 64, 96, 1, 3, True, L.ACT_RELU, False)])
 def test_conv_every_kernel_variant(case, dtype):
     """Force each kernel variant (gather, halo-patch 128/64-B chunks, single/double stage, 16x32-block forms) on the
     same launch: all must agree with torch-CPU (the autotuner may pick any of them)."""
@@ -154,7 +155,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 10):
+    for variant in range(1, 11):
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -165,6 +166,7 @@ def test_conv_every_kernel_variant(case, dtype):
         assert rel(got, ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL), variant
         ran.append(variant)
     assert 1 in ran and 4 in ran and (7 in ran or H < 16)
+    assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (2 if dtype == torch.bfloat16 else 4) <= 128)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -188,7 +190,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 10):
+    for variant in range(1, 11):
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         if out is not None:
@@ -230,7 +232,7 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 10):
+    for variant in range(1, 11):
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
