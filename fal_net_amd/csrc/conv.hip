@@ -1502,7 +1502,12 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_
 
 #define WP_THREADS 192  // three waves: wave w owns the tap row dy = w-1 (taps 3w..3w+2)
 
-template <typename T>
+// CIT x COT = 32-channel tiles per workgroup along cin / cout (1x1, or 2x2 for bf16 layers with >= 64 channels on both
+// sides): every wave then owns 3 taps x CIT x COT accumulator tiles, and one A (gout) fragment feeds 3*CIT MFMAs, one B
+// (input) fragment COT of them -- half the LDS reads and half the global bytes per MFMA of the 1x1 form, whose ~2.7
+// transposed reads per MFMA and 21 KB per 72 MFMAs sit on the LDS / CU load path.  Channel planes are stored separately
+// ([plane][pixel][32 channels], 64-B rows) so the transposed-read addressing is the same for every plane.
+template <typename T, int CIT, int COT>
 __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
                                                                     int patches_per_split) {
     constexpr int EPS = 16 / (int)sizeof(T);
@@ -1510,8 +1515,9 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
     constexpr int SEGS = ROWB_ / 16;                // 4 (bf16) / 8 (f32)
     // no row padding: a ds_read_b64_tr_b16 32-lane half reads 4 rows x 64 B = exactly the 64 banks once
     constexpr int PITCH = ROWB_;
-    constexpr int G_BYTES = WP_TH * WP_TW * PITCH, I_BYTES = WP_NPIX * PITCH;
-    constexpr int G_LOADS = WP_TH * WP_TW * SEGS, I_LOADS = WP_NPIX * SEGS;
+    constexpr int G_PLANE = WP_TH * WP_TW * PITCH, I_PLANE = WP_NPIX * PITCH;
+    constexpr int G_BYTES = COT * G_PLANE, I_BYTES = CIT * I_PLANE;
+    constexpr int G_LOADS = WP_TH * WP_TW * SEGS * COT, I_LOADS = WP_NPIX * SEGS * CIT;
     constexpr int G_SLOTS = (G_LOADS + WP_THREADS - 1) / WP_THREADS;
     constexpr int I_SLOTS = (I_LOADS + WP_THREADS - 1) / WP_THREADS;
     __shared__ __attribute__((aligned(16))) char lds[2 * (G_BYTES + I_BYTES)];
@@ -1519,20 +1525,35 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
     auto Ibuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES) + G_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32, split = blockIdx.z;
+    const int ci0 = blockIdx.x * 32 * CIT, co0 = blockIdx.y * 32 * COT, split = blockIdx.z;
     const int c_first = p.src[0].C;
-    const int si = ci0 < c_first ? 0 : 1;
-    const falnet_src_t S = p.src[si];
-    const int cloc = ci0 < c_first ? ci0 : ci0 - c_first;
-    const bool ups = S.H != p.IH || S.W != p.IW;
+    // per cin tile: source, channel offset inside it, resize flags (workgroup-uniform; a 64-channel block may straddle
+    // the two sources of a fused concat)
+    const T* t_ptr[CIT];
+    int64_t t_sb[CIT], t_sy[CIT], t_sx[CIT];
+    int t_H[CIT], t_W[CIT];
+    bool t_ok[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) {
+        const int c = ci0 + 32 * t;
+        const bool second = c >= c_first;
+        t_ok[t] = c < p.cin_total;
+        t_ptr[t] = reinterpret_cast<const T*>(second ? p.src[1].ptr : p.src[0].ptr) + (second ? c - c_first : c);
+        t_sb[t] = second ? p.src[1].sb : p.src[0].sb;
+        t_sy[t] = second ? p.src[1].sy : p.src[0].sy;
+        t_sx[t] = second ? p.src[1].sx : p.src[0].sx;
+        t_H[t] = second ? p.src[1].H : p.src[0].H;
+        t_W[t] = second ? p.src[1].W : p.src[0].W;
+    }
     const int npatch = p.B * tiles_x * tiles_y;
     const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
 
-    // halo slots: (row, col) of the 6x34 patch per slot (division by 34 hoisted out of the patch loop)
+    // halo slots: (row, col) of the 6x34 patch per slot (division by 34 hoisted out of the patch loop); with CIT = 2 the
+    // eight 16-B segments of a pixel are consecutive lanes (one full 128-B line when both tiles share a source)
     short i_row[I_SLOTS], i_col[I_SLOTS];
 #pragma unroll
     for (int u = 0; u < I_SLOTS; ++u) {
-        const int pix = (tid + u * WP_THREADS) / SEGS;
+        const int pix = (tid + u * WP_THREADS) / (SEGS * CIT);
         i_row[u] = (short)(pix / WP_PW);
         i_col[u] = (short)(pix % WP_PW);
     }
@@ -1549,26 +1570,27 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #pragma unroll
         for (int u = 0; u < G_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            const int seg = idx % SEGS, pix = idx / SEGS;
+            const int seg = idx % (SEGS * COT), pix = idx / (SEGS * COT);
             const int y = y0 + pix / WP_TW, x = x0 + pix % WP_TW;  // WP_TW = 32: shifts
             uint4 v = make_uint4(0, 0, 0, 0);
             if (idx < G_LOADS && y < p.TH && x < p.TW && co0 + seg * EPS < p.gC)
                 v = *reinterpret_cast<const uint4*>(gbase + ((int64_t)y * p.TW + x) * p.gC + seg * EPS);
             R.g[u] = v;
         }
-        const T* ibase = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + cloc;
 #pragma unroll
         for (int u = 0; u < I_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            const int seg = idx % SEGS;
+            const int seg8 = idx % (SEGS * CIT), t = seg8 / SEGS, seg = seg8 % SEGS;
+            const bool t1 = CIT > 1 && t == 1;
             uint4 v = make_uint4(0, 0, 0, 0);
             int vy = y0 - 1 + i_row[u], vx = x0 - 1 + i_col[u];
-            if (idx < I_LOADS && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) {
-                if (ups) {
-                    vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
-                    vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
-                }
-                v = *reinterpret_cast<const uint4*>(ibase + (int64_t)vy * S.sy + (int64_t)vx * S.sx + seg * EPS);
+            if (idx < I_LOADS && (t1 ? t_ok[CIT - 1] : t_ok[0]) && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) {
+                const int sH = t1 ? t_H[CIT - 1] : t_H[0], sW = t1 ? t_W[CIT - 1] : t_W[0];
+                if (sH != p.IH) vy = (2 * sH == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * sH) / p.IH);
+                if (sW != p.IW) vx = (2 * sW == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * sW) / p.IW);
+                const T* ib = t1 ? t_ptr[CIT - 1] : t_ptr[0];
+                v = *reinterpret_cast<const uint4*>(ib + (int64_t)b * (t1 ? t_sb[CIT - 1] : t_sb[0]) + (int64_t)vy * (t1 ? t_sy[CIT - 1] : t_sy[0]) +
+                                                    (int64_t)vx * (t1 ? t_sx[CIT - 1] : t_sx[0]) + seg * EPS);
             }
             R.i[u] = v;
         }
@@ -1577,20 +1599,26 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #pragma unroll
         for (int u = 0; u < G_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + idx * 16) = R.g[u];   // pixel-major, unpadded: idx*16 B
+            const int seg8 = idx % (SEGS * COT), pix = idx / (SEGS * COT);
+            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + (seg8 / SEGS) * G_PLANE + (pix * SEGS + seg8 % SEGS) * 16) = R.g[u];
         }
 #pragma unroll
         for (int u = 0; u < I_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
-            if (idx < I_LOADS) *reinterpret_cast<uint4*>(Ibuf(buf) + idx * 16) = R.i[u];
+            const int seg8 = idx % (SEGS * CIT), pix = idx / (SEGS * CIT);
+            if (idx < I_LOADS) *reinterpret_cast<uint4*>(Ibuf(buf) + (seg8 / SEGS) * I_PLANE + (pix * SEGS + seg8 % SEGS) * 16) = R.i[u];
         }
     };
 
-    f32x16 acc[3];
+    f32x16 acc[3][CIT][COT];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+        for (int a = 0; a < CIT; ++a)
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[t][a][c][j] = 0.f;
 
     auto compute = [&](int cur) {
         const char* G = Gbuf(cur);
@@ -1605,30 +1633,42 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {  // K = 128 positions: image row ks>>1 of the patch, 16-position half ks&1
                 const int goff = ks * 16 * PITCH;
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + goff));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + goff + 4 * PITCH));
-                const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                bf16x8 av[COT];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int ioff = ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[dx], 0, 0, 0);
+                for (int c = 0; c < COT; ++c) {
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
+                    av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
+#pragma unroll
+                for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int ioff = a * I_PLANE + ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
+                        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
+                        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[dx][a][c], 0, 0, 0);
+                    }
             }
         } else {
             const int r = lane & 31, h = lane >> 5;
 #pragma unroll 8
             for (int ks = 0; ks < 64; ++ks) {  // 2 positions per MFMA
                 const int pos = ks * 2 + h;     // 0..127 inside the patch
-                const float a = *reinterpret_cast<const float*>(G + pos * PITCH + r * 4);
+                float av[COT];
+#pragma unroll
+                for (int c = 0; c < COT; ++c) av[c] = *reinterpret_cast<const float*>(G + c * G_PLANE + pos * PITCH + r * 4);
                 const int ipix = (pos >> 5) * WP_PW + (pos & 31);
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float bb = *reinterpret_cast<const float*>(I + (ipix + dx) * PITCH + r * 4);
-                    acc[dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[dx], 0, 0, 0);
-                }
+                for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float bb = *reinterpret_cast<const float*>(I + a * I_PLANE + (ipix + dx) * PITCH + r * 4);
+#pragma unroll
+                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bb, acc[dx][a][c], 0, 0, 0);
+                    }
             }
         }
     };
@@ -1649,15 +1689,205 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
     }
     // every wave owns its three taps: no cross-wave reduction
     const int r = lane & 31, h = lane >> 5;
-    const int ci = ci0 + r;
-    if (ci < p.cin_total) {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + dx) * w_rows) * p.cin_total;
+    for (int a = 0; a < CIT; ++a) {
+        const int ci = ci0 + 32 * a + r;
+        if (ci < p.cin_total) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int co = co0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dx][j];
+            for (int dx = 0; dx < 3; ++dx) {
+                float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int co = co0 + 32 * c + (j & 3) + 8 * (j >> 2) + 4 * h;
+                        if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dx][a][c][j];
+                    }
+            }
+        }
+    }
+}
+
+// 64 x 64 channels per workgroup, staged by LDS-DMA (bf16).  The 2x2-tile form above needs 192 accumulator registers per
+// wave, so one workgroup fits a CU and nothing overlaps the global-load issue of the next patch.  Here a patch (16 KB gout +
+// 26 KB halo) arrives as 42 global_load_lds_dwordx4 pieces (16 pixels x 64 B of one channel plane = 1 KiB, written
+// lane-linearly, no VGPR staging) spread over FOUR waves: waves 0-2 multiply (tap rows, 3 x 2 x 2 tiles each), wave 3 -- on
+// the SIMD the three-wave form leaves idle -- only moves data.  Three LDS buffers: the pieces of patch i+2 are in flight
+// while patch i+1 lands and patch i is multiplied; counted vmcnt + raw s_barrier (a __syncthreads() would drain the DMA).
+#define WPB_THREADS 256
+__global__ __launch_bounds__(WPB_THREADS) void wgrad3x3_big_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+                                                                   int patches_per_split) {
+    typedef bf16_t T;
+    constexpr int EPS = 8, PITCH = 64, CIT = 2, COT = 2;
+    constexpr int G_PER_PLANE = WP_TH * WP_TW / 16, I_PER_PLANE = (WP_NPIX + 15) / 16;  // 1-KiB DMA pieces per plane
+    constexpr int G_PLANE = WP_TH * WP_TW * PITCH, I_PLANE = I_PER_PLANE * 1024;        // halo plane rounded up to whole pieces
+    constexpr int G_BYTES = COT * G_PLANE, I_BYTES = CIT * I_PLANE;
+    constexpr int NPIECE = COT * G_PER_PLANE + CIT * I_PER_PLANE;
+    static_assert(NPIECE == 42, "the counted vmcnt waits below assume 42 pieces: waves 0,1 issue 11 each, waves 2,3 ten");
+    __shared__ __attribute__((aligned(16))) char lds[3 * (G_BYTES + I_BYTES)];
+    auto Gbuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES); };
+    auto Ibuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES) + G_BYTES; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int npatch = p.B * tiles_x * tiles_y;
+    const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
+    const int n = pend - pbeg;
+
+    // per cin tile: source, channel offset, resize (workgroup-uniform; a 64-channel block may straddle a fused concat)
+    const int c_first = p.src[0].C;
+    const T* t_ptr[CIT];
+    int64_t t_sb[CIT], t_sy[CIT], t_sx[CIT];
+    int t_H[CIT], t_W[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) {
+        const int c = ci0 + 32 * t;
+        const bool second = c >= c_first;
+        t_ptr[t] = reinterpret_cast<const T*>(second ? p.src[1].ptr : p.src[0].ptr) + (second ? c - c_first : c);
+        t_sb[t] = second ? p.src[1].sb : p.src[0].sb;
+        t_sy[t] = second ? p.src[1].sy : p.src[0].sy;
+        t_sx[t] = second ? p.src[1].sx : p.src[0].sx;
+        t_H[t] = second ? p.src[1].H : p.src[0].H;
+        t_W[t] = second ? p.src[1].W : p.src[0].W;
+    }
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int lseg = lane & 3, lpix = lane >> 2;
+    auto coords = [&](int patch, int& b, int& y0, int& x0) {
+        int q = patch;
+        const int tix = q % tiles_x;
+        q /= tiles_x;
+        const int tiy = q % tiles_y;
+        b = q / tiles_y;
+        y0 = tiy * WP_TH;
+        x0 = tix * WP_TW;
+    };
+    // Piece id -> wave: id % 4.  Every wave issues EXACTLY its share for every patch (the counted waits depend on it):
+    // coordinates outside the image are clamped to a valid pixel and zero() overwrites those lanes' 16 B once the patch has
+    // landed (border patches only).  cin_total and gC are multiples of 64 here (dispatcher): whole planes are never absent.
+    auto issue = [&](int patch, int buf) {
+        int b, y0, x0;
+        coords(patch, b, y0, x0);
+        const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC + co0 + lseg * EPS;
+#pragma unroll
+        for (int id = 0; id < NPIECE; ++id) {
+            if ((id & 3) != wave) continue;  // wave-uniform
+            if (id < COT * G_PER_PLANE) {
+                const int c = id / G_PER_PLANE, k = id % G_PER_PLANE;
+                const int pix = k * 16 + lpix;
+                const int y = min(y0 + pix / WP_TW, p.TH - 1), x = min(x0 + pix % WP_TW, p.TW - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)(gbase + ((int64_t)y * p.TW + x) * p.gC + c * 32), (lptr_t)(Gbuf(buf) + c * G_PLANE + k * 1024), 16, 0, 0);
+            } else {
+                const int t = (id - COT * G_PER_PLANE) / I_PER_PLANE, k = (id - COT * G_PER_PLANE) % I_PER_PLANE;
+                const int pix = min(k * 16 + lpix, WP_NPIX - 1);  // the last piece's spare lanes re-read the last pixel into the plane's slack
+                int vy = min(max(y0 - 1 + pix / WP_PW, 0), p.IH - 1), vx = min(max(x0 - 1 + pix % WP_PW, 0), p.IW - 1);
+                if (t_H[t] != p.IH) vy = (2 * t_H[t] == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * t_H[t]) / p.IH);
+                if (t_W[t] != p.IW) vx = (2 * t_W[t] == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * t_W[t]) / p.IW);
+                __builtin_amdgcn_global_load_lds((gptr_t)(t_ptr[t] + (int64_t)b * t_sb[t] + (int64_t)vy * t_sy[t] + (int64_t)vx * t_sx[t] + lseg * EPS),
+                                                 (lptr_t)(Ibuf(buf) + t * I_PLANE + k * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto zero = [&](int patch, int buf) {  // this wave's pieces of a landed border patch: zero the lanes that were clamped
+        int b, y0, x0;
+        coords(patch, b, y0, x0);
+        const bool border = y0 == 0 || x0 == 0 || y0 + WP_TH + 1 > p.IH || x0 + WP_TW + 1 > p.IW || y0 + WP_TH > p.TH || x0 + WP_TW > p.TW;
+        if (!border) return;  // workgroup-uniform
+#pragma unroll
+        for (int id = 0; id < NPIECE; ++id) {
+            if ((id & 3) != wave) continue;
+            if (id < COT * G_PER_PLANE) {
+                const int c = id / G_PER_PLANE, k = id % G_PER_PLANE;
+                const int pix = k * 16 + lpix;
+                if (y0 + pix / WP_TW >= p.TH || x0 + pix % WP_TW >= p.TW)
+                    *reinterpret_cast<uint4*>(Gbuf(buf) + c * G_PLANE + k * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+            } else {
+                const int t = (id - COT * G_PER_PLANE) / I_PER_PLANE, k = (id - COT * G_PER_PLANE) % I_PER_PLANE;
+                const int pix = k * 16 + lpix;
+                const int vy = y0 - 1 + pix / WP_PW, vx = x0 - 1 + pix % WP_PW;
+                if (pix < WP_NPIX && (vy < 0 || vy >= p.IH || vx < 0 || vx >= p.IW))
+                    *reinterpret_cast<uint4*>(Ibuf(buf) + t * I_PLANE + k * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto wait_one_patch_in_flight = [&]() {  // all but this wave's pieces of the newest patch have landed
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    };
+
+    f32x16 acc[3][CIT][COT];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int a = 0; a < CIT; ++a)
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[t][a][c][j] = 0.f;
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q4 = i16 >> 2, pc = i16 & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    const int lane_off = (kh * 8 + q4) * PITCH + (cb * 16 + pc * 4) * 2;
+
+    if (n > 0) issue(pbeg, 0);
+    if (n > 1) issue(pbeg + 1, 1);
+    if (n > 1) wait_one_patch_in_flight();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (n > 0) zero(pbeg, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, b2 = 2;  // LDS buffers of patch i and of patch i+2 (patch j lives in buffer j % 3)
+    for (int i = 0; i < n; ++i) {
+        if (i + 2 < n) issue(pbeg + i + 2, b2);  // buffer (i+2)%3 = (i-1)%3: released by the barrier that ended iteration i-1
+        if (wave < 3) {  // tap row dy = wave - 1
+            const char* gl = Gbuf(cur) + lane_off;
+            const char* il = Ibuf(cur) + wave * (WP_PW * PITCH) + lane_off;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {  // K = 128 positions: image row ks>>1 of the patch, 16-position half ks&1
+                const int goff = ks * 16 * PITCH;
+                bf16x8 av[COT];
+#pragma unroll
+                for (int c = 0; c < COT; ++c) {
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
+                    av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int a = 0; a < CIT; ++a)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int ioff = a * I_PLANE + ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
+                        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
+                        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[dx][a][c], 0, 0, 0);
+                    }
+            }
+        }
+        if (i + 2 < n) wait_one_patch_in_flight();  // this wave's pieces of patch i+1 have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i + 1 < n) zero(pbeg + i + 1, cur == 2 ? 0 : cur + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of patch i and zero stores are done
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        b2 = b2 == 2 ? 0 : b2 + 1;
+    }
+    if (wave == 3) return;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < CIT; ++a) {
+        const int ci = ci0 + 32 * a + r;
+        if (ci < p.cin_total) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+                for (int c = 0; c < COT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int co = co0 + 32 * c + (j & 3) + 8 * (j >> 2) + 4 * h;
+                        if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dx][a][c][j];
+                    }
             }
         }
     }
@@ -2249,11 +2479,19 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
         const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
         const int npatch = p.B * tiles_x * tiles_y;
         const int pps = (npatch + p.nsplit - 1) / p.nsplit;
+        // variant 2: 64 x 64 channels per workgroup (bf16, both channel counts multiples of 64); 0 / other: 32 x 32
+        const bool big = p.variant == 2 && p.dtype == FALNET_BF16 && p.cin_total % 64 == 0 && w_rows % 64 == 0;
+        FALNET_CHECK_ARG(p.variant != 2 || big, "wgrad: variant 2 needs bf16 and channel counts that are multiples of 64");
+        if (big) {
+            const dim3 grid(p.cin_total / 64, w_rows / 64, p.nsplit);
+            hipLaunchKernelGGL(wgrad3x3_big_kernel, grid, dim3(WPB_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            FALNET_RETURN_LAUNCH();
+        }
         const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
         if (p.dtype == FALNET_BF16)
-            hipLaunchKernelGGL(wgrad3x3_patch_kernel<bf16_t>, grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
         else
-            hipLaunchKernelGGL(wgrad3x3_patch_kernel<float>, grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<float, 1, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
         FALNET_RETURN_LAUNCH();
     }
     const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);

@@ -329,10 +329,11 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     M = B * TH * TW
     slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
     dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
+    big = _wgrad_big(dtype, dense, pc.cin_pad, pad_c(gC))
     if dense:
-        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32)
+        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 1)
         npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-        nsplit = max(1, min((768 + tiles - 1) // tiles, npatch))
+        nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
     else:
         tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
         nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
@@ -340,7 +341,7 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     d.nsplit = nsplit
     d.partial = ws.data_ptr()
     d.dtype = L.dtype_code(dtype)
-    d.variant = 0
+    d.variant = 2 if big else 0
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
     c0_real, c0_pad = pc.group_channels()
@@ -365,7 +366,17 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     def call(accumulate=0):
         t_wgrad(accumulate)
         t_reduce(accumulate)
+    call.desc = d
     return call
+
+
+def _wgrad_big(dtype, dense, cin_pad, cout_pad):
+    """64 x 64-channel workgroup tiles of the halo-patch weight-gradient kernel (falnet_wgrad variant 2, LDS-DMA staged).
+    Opt-in (FALNET_WGRAD_BIG=1): measured 1.2-1.6x SLOWER than the 32 x 32 form on MI355X -- with one workgroup per CU the
+    per-CU fill rate (~25 GB/s of 64-B pieces) bounds it, while the small form hides its (2x larger) traffic behind 3-4
+    resident workgroups and L2 hits.  Kept for the next round's work on the staging path."""
+    return (dense and dtype == torch.bfloat16 and cin_pad % 64 == 0 and cout_pad % 64 == 0
+            and os.environ.get("FALNET_WGRAD_BIG", "0") == "1")
 
 
 class WgradBatch:
@@ -396,15 +407,16 @@ class WgradBatch:
         M = B * TH * TW
         slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
         dense = len(taps) == 9 and stride_in == 1 and TW >= 16
+        big = _wgrad_big(self.dtype, dense, pc.cin_pad, pad_c(gC))
         if dense:
-            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32)
+            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 1)
             npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-            nsplit = max(1, min((768 + tiles - 1) // tiles, npatch))
+            nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
         else:
             tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
             nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
         nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
-        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), 0
+        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (2 if big else 0)
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
         dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
@@ -417,7 +429,8 @@ class WgradBatch:
         if grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
-        sym = f"_Z21wgrad3x3_patch_kernelI{tn}Ev14falnet_wgrad_tiiii" if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
+        sym = ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi1EEv14falnet_wgrad_tiiii") \
+            if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 
     def finalize(self):

@@ -140,7 +140,9 @@ typedef struct {
     int32_t nsplit;
     float* partial;            /* workspace */
     int32_t dtype;
-    int32_t variant;           /* 0 heuristic, 1 force the per-tap kernel */
+    int32_t variant;           /* 0 heuristic (halo-patch kernel, 32x32 channels per workgroup, when dense 3x3 stride 1),
+                                  1 force the per-tap kernel, 2 halo-patch with 64x64 channels per workgroup (bf16, channel
+                                  counts multiples of 64) */
 } falnet_wgrad_t;
 int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p);
 int falnet_wgrad(const falnet_wgrad_t* p, void* stream);

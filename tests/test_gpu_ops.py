@@ -75,6 +75,7 @@ PATCH_CASES = [
     (2, [64], 128, 128, 256, 1, 3, True, L.ACT_RELU, False),    # BN=128 (>=256 tiles), single chunk in bf16
     (2, [128], 128, 128, 256, 1, 3, False, L.ACT_ELU, True),    # BN=128, double-buffered patch
     (1, [32], 96, 16, 48, 1, 3, False, L.ACT_NONE, False),      # Cout=96 (N=96 planes)
+    (2, [32, 32], 49, 12, 40, 1, 3, True, L.ACT_NONE, False),   # iconv1-like: a 64-channel weight-gradient block straddles both sources
 ]
 
 
@@ -337,6 +338,30 @@ def test_conv_backward(case, dtype):
         assert rel(gb, b.grad) < tol
     call(1)  # accumulate
     assert rel(gw, 2 * w.grad) < tol
+
+
+@pytest.mark.parametrize("case", [PATCH_CASES[2], PATCH_CASES[4], PATCH_CASES[8], (1, [64], 64, 9, 37, 1, 3, False, L.ACT_ELU, False)])
+def test_wgrad_big_tiles(case, monkeypatch):
+    """falnet_wgrad variant 2 (64x64 channels per workgroup, LDS-DMA staging, opt-in) against autograd: border patches
+    (clamped DMA + zero fix-up), ragged tiles, a 64-channel block straddling two concatenated sources."""
+    monkeypatch.setenv("FALNET_WGRAD_BIG", "1")
+    B, groups, Cout, H, W, stride, k, bias, act, res = case
+    dtype = torch.bfloat16
+    xs, w, b = _conv_inputs(case, seed=21)
+    xs = [x.requires_grad_(False) for x in xs]
+    wp = w.clone().requires_grad_(True)
+    g = torch.randn(B, Cout, H, W, generator=torch.Generator().manual_seed(22))
+    (F.conv2d(torch.cat(xs, 1), wp, None, padding=1) * g).sum().backward()
+    pc = packed(w, None, groups, 1, dtype)
+    srcs_t = [to_nhwc(x, dtype) for x in xs]
+    g_t = to_nhwc(g, dtype)
+    gw = torch.zeros_like(pc.weight.data)
+    ws = torch.empty(32 << 20, device=DEV)
+    call = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, g_t, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W,
+                           pc, gw, None, ws)
+    assert call.desc.variant == 2
+    call(0)
+    assert rel(gw, wp.grad) < BF16_TOL
 
 
 def test_upsample_bwd_and_pool():

@@ -51,6 +51,8 @@ else:
     c = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W,
                         pc, gw, None, ws)
     run = lambda: c(0)
+    if os.environ.get("WGRAD_VARIANT"):  # diagnostic builds (-DFALNET_WGRAD_DIAG): 3 = no MFMA work, 4 = no DMA
+        c.desc.variant = int(os.environ["WGRAD_VARIANT"])
 for _ in range(10):
     run()
 torch.cuda.synchronize()
