@@ -2487,6 +2487,14 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
             hipLaunchKernelGGL(wgrad3x3_big_kernel, grid, dim3(WPB_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
             FALNET_RETURN_LAUNCH();
         }
+        if (p.variant == 3 || p.variant == 4) {  // 32 x 64 / 64 x 32 channels per workgroup (register staged, two workgroups per CU)
+            const bool co2 = p.variant == 3;
+            FALNET_CHECK_ARG(p.dtype == FALNET_BF16 && (co2 ? w_rows : p.cin_total) % 64 == 0, "wgrad: variant %d needs bf16 and a channel count that is a multiple of 64", p.variant);
+            const dim3 grid(p.cin_total / (co2 ? 32 : 64), w_rows / (co2 ? 64 : 32), p.nsplit);
+            if (co2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 2>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 2, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+            FALNET_RETURN_LAUNCH();
+        }
         const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
         if (p.dtype == FALNET_BF16)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);

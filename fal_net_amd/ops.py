@@ -7,6 +7,7 @@ step is just that list replayed -- no per-step allocation, no Python tensor math
 """
 import ctypes as C
 import os
+import sys
 
 import torch
 
@@ -277,6 +278,9 @@ def conv_multi_call(calls, name="conv multi"):
     return _timed(f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t", sum(c.flops for c in calls), 0, launch, name)
 
 
+_AUTOTUNE_LOG = os.environ.get("FALNET_AUTOTUNE_LOG") == "1"
+
+
 def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     """Fastest (variant, ksplit) for this launch.  Candidates: gather (with split-K when the launch would
     otherwise occupy only a fraction of the 256 CUs), and the halo-patch variants where applicable."""
@@ -293,6 +297,9 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     for v, k in cands:
         d.variant, d.ksplit = v, k
         if lib.falnet_conv2d(ref, st) != 0:  # -2: variant not applicable to this launch
+            if _AUTOTUNE_LOG:
+                print(f"[autotune] M={M} w_rows={w_rows} Cout={Cout} v{v} k{k}: n/a ({lib.falnet_last_error().decode()}) "
+                      f"src={[(d.src[i].C, d.src[i].H, d.src[i].W) for i in range(d.nsrc)]} cin_total={d.cin_total}", file=sys.stderr)
             continue
         lib.falnet_conv2d(ref, st)  # second warm-up: caches / clocks settled before timing
         t = None
@@ -305,6 +312,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
             e1.synchronize()
             tt = e0.elapsed_time(e1)
             t = tt if t is None else min(t, tt)
+        if _AUTOTUNE_LOG:
+            print(f"[autotune] M={M} w_rows={w_rows} Cout={Cout} ntaps={d.ntaps} nsrc={d.nsrc} v{v} k{k}: {t / reps * 1e3:.1f} us", file=sys.stderr)
         if best_t is None or t < best_t:
             best, best_t = (v, k), t
     return best
@@ -330,8 +339,9 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
     dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
     big = _wgrad_big(dtype, dense, pc.cin_pad, pad_c(gC))
+    co2 = not big and _wgrad_co2(dtype, dense, pc.cin_pad, pad_c(gC))
     if dense:
-        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 1)
+        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
         npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
         nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
     else:
@@ -341,7 +351,7 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     d.nsplit = nsplit
     d.partial = ws.data_ptr()
     d.dtype = L.dtype_code(dtype)
-    d.variant = 2 if big else 0
+    d.variant = 2 if big else 3 if co2 else 0
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
     c0_real, c0_pad = pc.group_channels()
@@ -379,6 +389,12 @@ def _wgrad_big(dtype, dense, cin_pad, cout_pad):
             and os.environ.get("FALNET_WGRAD_BIG", "0") == "1")
 
 
+def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
+    """32 (cin) x 64 (cout) channels per workgroup (falnet_wgrad variant 3): one gout fragment pair feeds twice the MFMAs.
+    Measured -17 % on 64 -> 64 channel layers, within noise for wider ones (left on the 32 x 32 form)."""
+    return dense and dtype == torch.bfloat16 and cin_pad <= 64 and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
+
+
 class WgradBatch:
     """All weight / bias gradients of one backward pass: per-layer split-K wgrad launches (each with its OWN slab
     region, so they can run back to back) followed by ONE batched slab reduce and ONE batched bias-gradient launch
@@ -408,15 +424,16 @@ class WgradBatch:
         slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
         dense = len(taps) == 9 and stride_in == 1 and TW >= 16
         big = _wgrad_big(self.dtype, dense, pc.cin_pad, pad_c(gC))
+        co2 = not big and _wgrad_co2(self.dtype, dense, pc.cin_pad, pad_c(gC))
         if dense:
-            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 1)
+            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
             npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
             nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
         else:
             tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
             nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
         nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
-        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (2 if big else 0)
+        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (2 if big else 3 if co2 else 0)
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
         dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
@@ -429,7 +446,7 @@ class WgradBatch:
         if grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
-        sym = ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi1EEv14falnet_wgrad_tiiii") \
+        sym = ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
             if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 

@@ -51,8 +51,10 @@ else:
     c = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W,
                         pc, gw, None, ws)
     run = lambda: c(0)
-    if os.environ.get("WGRAD_VARIANT"):  # diagnostic builds (-DFALNET_WGRAD_DIAG): 3 = no MFMA work, 4 = no DMA
+    if os.environ.get("WGRAD_VARIANT"):  # 2: 64x64 LDS-DMA, 3: 32(cin) x 64(cout), 4: 64 x 32 channels per workgroup
         c.desc.variant = int(os.environ["WGRAD_VARIANT"])
+        if os.environ.get("WGRAD_NSPLIT"):  # must stay within the 24 MiB workspace allocated above
+            c.desc.nsplit = min(int(os.environ["WGRAD_NSPLIT"]), (24 << 20) * 4 // (9 * pc.cout_pad * pc.cin_pad * 4))
 for _ in range(10):
     run()
 torch.cuda.synchronize()
