@@ -633,7 +633,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_multi_kernel(const fa
 // split-K epilogue: ws[m][n] (f32 sums) -> bias / residual / activation / activation-gradient -> NHWC output
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_t p) {
-    const int segs = p.Cout / 8;
+    // Reads the f32 sums the split-K workgroups accumulated with atomics, applies the epilogue, and ZEROES what it read:
+    // the workspace is all-zero between launches (contract of falnet_conv_t::splitk_ws), so no memset dispatch is needed
+    // in front of the next split-K launch (~40 per training step, each a ~5 us hole on the critical stream).
+    const int segs = p.w_rows / 8;  // every column a workgroup may have touched, not only the Cout that are stored
     const int64_t M = (int64_t)p.B * p.TH * p.TW;
     const int64_t total = M * segs;
     const T* addend = reinterpret_cast<const T*>(p.addend);
@@ -642,12 +645,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int seg = (int)(i % segs);
         const int64_t m = i / segs;
+        const int n = seg * 8;
+        float* wsp = p.splitk_ws + m * p.w_rows + n;
+        const float4 x0 = *reinterpret_cast<const float4*>(wsp);
+        const float4 x1 = *reinterpret_cast<const float4*>(wsp + 4);
+        *reinterpret_cast<float4*>(wsp) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(wsp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         const int tx = (int)(m % p.TW), ty = (int)((m / p.TW) % p.TH), b = (int)(m / ((int64_t)p.TW * p.TH));
         const int oy = ty * p.osy + p.ooy, ox = tx * p.osx + p.oox;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int n = seg * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(p.splitk_ws + m * p.w_rows + n);
-        const float4 x1 = *reinterpret_cast<const float4*>(p.splitk_ws + m * p.w_rows + n + 4);
+        if (oy >= p.OH || ox >= p.OW || n >= p.Cout) continue;
         float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
         const int64_t off = (((int64_t)b * p.OH + oy) * p.OW + ox) * p.out_cstride + n;
         Vec8<T> t;
@@ -1558,6 +1564,31 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
         i_col[u] = (short)(pix % WP_PW);
     }
 
+    // Interior patches (the vast majority) take a fast path: every slot's element offset relative to the patch origin is
+    // loop-invariant (also through an exact 2x nearest upsampling: origins are even), so a load is one 64-bit add -- the
+    // general path costs ~25 VALU per load, i.e. ~8 VALU per MFMA of this kernel (PMC), as much issue time as the MFMAs.
+    int g_off[G_SLOTS], i_off[I_SLOTS];
+    bool fast_ok = true;  // every tile's source is at the launch size or exactly half of it
+#pragma unroll
+    for (int t = 0; t < CIT; ++t)
+        fast_ok = fast_ok && (t_H[t] == p.IH || 2 * t_H[t] == p.IH) && (t_W[t] == p.IW || 2 * t_W[t] == p.IW) &&
+                  (int64_t)p.B * t_sb[t] < (1ll << 31);
+    fast_ok = fast_ok && (int64_t)p.B * p.TH * p.TW * p.gC < (1ll << 31) && co0 + 32 * COT <= p.gC && ci0 + 32 * CIT <= p.cin_total;
+#pragma unroll
+    for (int u = 0; u < G_SLOTS; ++u) {
+        const int idx = tid + u * WP_THREADS;
+        const int seg = idx % (SEGS * COT), pix = idx / (SEGS * COT);
+        g_off[u] = ((pix / WP_TW) * p.TW + pix % WP_TW) * p.gC + seg * EPS;
+    }
+#pragma unroll
+    for (int u = 0; u < I_SLOTS; ++u) {
+        const int idx = tid + u * WP_THREADS;
+        const int seg8 = idx % (SEGS * CIT), seg = seg8 % SEGS;
+        const bool t1 = CIT > 1 && seg8 >= SEGS;
+        const int hs = (t1 ? t_H[CIT - 1] : t_H[0]) != p.IH ? 1 : 0, ws = (t1 ? t_W[CIT - 1] : t_W[0]) != p.IW ? 1 : 0;
+        const int ry = (i_row[u] - 1) >> hs, rx = (i_col[u] - 1) >> ws;  // arithmetic shifts: -1 stays -1
+        i_off[u] = (int)(ry * (t1 ? t_sy[CIT - 1] : t_sy[0]) + rx * (t1 ? t_sx[CIT - 1] : t_sx[0])) + seg * EPS;
+    }
     struct Regs { uint4 g[G_SLOTS]; uint4 i[I_SLOTS]; };
     auto gload = [&](int patch, Regs& R) {
         int q = patch;
@@ -1567,6 +1598,30 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
         const int b = q / tiles_y;
         const int y0 = tiy * WP_TH, x0 = tix * WP_TW;
         const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC + co0;
+        if (fast_ok && y0 >= 1 && x0 >= 1 && y0 + WP_TH + 1 <= p.IH && x0 + WP_TW + 1 <= p.IW && y0 + WP_TH <= p.TH && x0 + WP_TW <= p.TW) {
+            const T* gb = gbase + ((int64_t)y0 * p.TW + x0) * p.gC;
+#pragma unroll
+            for (int u = 0; u < G_SLOTS; ++u) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (tid + u * WP_THREADS < G_LOADS) v = *reinterpret_cast<const uint4*>(gb + g_off[u]);
+                R.g[u] = v;
+            }
+            const T* ib[CIT];
+#pragma unroll
+            for (int t = 0; t < CIT; ++t) {
+                const int hs = t_H[t] != p.IH ? 1 : 0, ws = t_W[t] != p.IW ? 1 : 0;
+                ib[t] = t_ptr[t] + (int64_t)b * t_sb[t] + (int64_t)(y0 >> hs) * t_sy[t] + (int64_t)(x0 >> ws) * t_sx[t];
+            }
+#pragma unroll
+            for (int u = 0; u < I_SLOTS; ++u) {
+                const int idx = tid + u * WP_THREADS;
+                const bool t1 = CIT > 1 && idx % (SEGS * CIT) >= SEGS;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (idx < I_LOADS) v = *reinterpret_cast<const uint4*>((t1 ? ib[CIT - 1] : ib[0]) + i_off[u]);
+                R.i[u] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < G_SLOTS; ++u) {
             const int idx = tid + u * WP_THREADS;
@@ -2370,8 +2425,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     if (ksplit > 1) {
         FALNET_CHECK_ARG(!planar && p.splitk_ws && p.Cout % 8 == 0, "conv2d: split-K needs an NHWC output and a workspace");
         FALNET_CHECK_ARG(M * p.w_rows * 4 <= p.splitk_ws_bytes, "conv2d: split-K workspace too small (%lld needed)", (long long)(M * p.w_rows * 4));
-        hipError_t e = hipMemsetAsync(p.splitk_ws, 0, (size_t)(M * p.w_rows * 4), st);
-        if (e != hipSuccess) return (int)e;
+        // no memset: the workspace is zero on entry by contract (the epilogue kernel below re-zeroes what it consumes)
     }
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn), (unsigned)ksplit);
     if (p.dtype == FALNET_BF16) {
@@ -2382,7 +2436,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         else launch_conv<float, false>(p, bn, grid, st);
     }
     if (ksplit > 1) {
-        const int64_t total = M * (p.Cout / 8);
+        const int64_t total = M * (p.w_rows / 8);
         const unsigned eg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         if (p.dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(eg), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(eg), dim3(256), 0, st, p);

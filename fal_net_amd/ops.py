@@ -240,7 +240,7 @@ def _splitk_workspace(device, owner=None, nbytes=32 << 20):
     stream-ordered, and different plans (backbone, each VGG plan instance) run concurrently on different streams."""
     key = (device.type, device.index, owner)
     if key not in _SPLITK_WS:
-        _SPLITK_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _SPLITK_WS[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)  # zero on entry by contract; launches leave it zero
     return _SPLITK_WS[key]
 
 

@@ -89,7 +89,7 @@ typedef struct {
     int32_t dtype;
     int32_t ksplit;            /* gather kernel only: > 1 splits the K loop over blockIdx.z (f32 atomics into
                                   splitk_ws [B*TH*TW][w_rows], then an epilogue launch); for small-M layers */
-    float* splitk_ws;
+    float* splitk_ws;          /* must be ALL-ZERO on entry; the split-K epilogue leaves it all-zero again (no memset per launch) */
     int64_t splitk_ws_bytes;
     int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
