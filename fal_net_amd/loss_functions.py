@@ -125,7 +125,8 @@ class _VggFunction(torch.autograd.Function):
         for c in plan.fwd:
             c()
         ctx.plan, ctx.owner = plan, owner
-        return tuple(o.clone().permute(0, 3, 1, 2) for o in plan.outs)
+        # no clone: the plan (and its output buffers) stays reserved for this call until its backward has run
+        return tuple(o.permute(0, 3, 1, 2) for o in plan.outs)
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -188,7 +189,9 @@ class Vgg19_pc(nn.Module):
         pool.append(p)
         return p
 
-    def forward(self, x, full=False):
+    def forward(self, x, full=False, borrow=False):
+        """borrow=True (no-grad calls): return views of the plan's output buffers instead of copies -- valid until the next
+        no-grad call with the same input shape (the trainer's per-step label features, Train_Stage1_K.py:241-244)."""
         if full:
             raise NotImplementedError("slice4 (relu4_4) is never used on the FAL_net hot path (loss_functions.py:40-42)")
         if not x.is_cuda:
@@ -206,7 +209,7 @@ class Vgg19_pc(nn.Module):
             plan.x_in.copy_(xs)
             for c in plan.fwd:
                 c()
-            return tuple(o.clone().permute(0, 3, 1, 2) for o in plan.outs)
+            return tuple((o if borrow else o.clone()).permute(0, 3, 1, 2) for o in plan.outs)
 
 
 _DEFAULT_DTYPE = [torch.float32]
@@ -232,8 +235,8 @@ class _LazyVgg:
             self._m = Vgg19_pc()
         return self._m
 
-    def __call__(self, x, full=False):
-        return self._get()(x, full)
+    def __call__(self, x, full=False, **kw):
+        return self._get()(x, full, **kw)
 
     def __getattr__(self, name):
         return getattr(self._get(), name)

@@ -95,13 +95,13 @@ def vgg_label_async(label):
     """VGG features of a label image on an auxiliary HIP stream: independent of the network forward, so it runs
     concurrently with it and fills the CUs the small backbone layers leave idle.  Returns (features, join)."""
     if ops.TIMER is not None:  # instrumented pass (bench.py roofline): serial launches so per-kernel times are uncontended
-        feats_serial = vgg(label)
+        feats_serial = vgg(label, borrow=True)
         return lambda: feats_serial
     main = torch.cuda.current_stream()
     aux = _aux_stream(label.device)
     aux.wait_stream(main)
     with torch.cuda.stream(aux):
-        feats = vgg(label)
+        feats = vgg(label, borrow=True)  # consumed by this step's perceptual loss only
 
     def join():
         main.wait_stream(aux)
