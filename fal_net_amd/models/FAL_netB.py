@@ -198,7 +198,7 @@ class FalnetPlan:
             else:
                 self.bwd_body.extend(singles)
 
-    def _wgrad(self, pc, srcs, IH, IW, gout, name=""):
+    def _wgrad(self, pc, srcs, IH, IW, gout, name="", on_main=False):
         OH, OW = gout.shape[1], gout.shape[2]
         self._buckets_seen = getattr(self, "_buckets_seen", set()) | {self._bucket}
         gw = self.model._grad_view(pc.weight)
@@ -206,7 +206,10 @@ class FalnetPlan:
         call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
                                pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
                                bucket=self._bucket)
-        self._side_call(call)
+        if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
+            self.bwd_body.append(call)
+        else:
+            self._side_call(call)
 
     def _side_call(self, call):
         """Weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill the
@@ -313,7 +316,7 @@ class FalnetPlan:
                                    name="falnet_med_head_bwd", nbytes=(N + 7) * H * W * 4 * B + B * H * W * pad_c(N) * G0.element_size())
         self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
         # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
-        # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: encoder levels 0-3.  After a bucket's
+        # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: levels 1-3, 3: level 0.  After a bucket's
         # last wgrad its slab reduce / bias-gradient launches run and model._bucket_ready(i) lets the trainer start that
         # bucket's share of the step's all-reduce while backward continues.
         self._bucket = 0
@@ -365,7 +368,10 @@ class FalnetPlan:
         for i in range(6, -1, -1):
             if i == 3:
                 self._finish.append((1, len(self.bwd_body)))
-            self._bucket = 1 if i >= 4 else 2
+            if i == 0:
+                self._finish.append((2, len(self.bwd_body)))
+            self._bucket = 1 if i >= 4 else (2 if i >= 1 else 3)
+            tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
             cname, rname, ch = _ENC[i]
             hh, ww = sizes[i]
             gz = gc[i]
@@ -373,14 +379,14 @@ class FalnetPlan:
             self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2")
             g_h = self._act(f"g_h{i}", hh, ww, ch)
             self._dgrad(pr2, 0, gz, g_h, hh, ww, actout=h_[i], name=rname + ".conv2")
-            self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1")
+            self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1", on_main=tail)
             g_a = self._act(f"g_a{i}", hh, ww, ch)
             self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
             srcs, ih, iw = self._enc_srcs[i]
-            self._wgrad(pcc, srcs, ih, iw, g_a, name=cname)
+            self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
             if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                 self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
-        self._finish.append((2, len(self.bwd_body)))
+        self._finish.append((3, len(self.bwd_body)))
         # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
         # trainer's hook (asynchronous all-reduce of that range of the flat gradient buffer)
         finals = self.wbatch.finalize()
@@ -391,6 +397,14 @@ class FalnetPlan:
             pos = at
             if bucket in finals:
                 red, bias = finals[bucket]
+
+                if bucket == 3 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1":
+                    # last bucket: the bias gradients only need the data gradients -> main stream (idle by now), beside the
+                    # side stream's last weight gradients and slab reduce; run_backward fires the bucket hook after the join
+                    self.bwd_body.append(bias)
+                    self._side_call(red)
+                    self._deferred_ready = bucket
+                    continue
 
                 def finish(red=red, bias=bias, bucket=bucket):
                     red()
@@ -442,6 +456,8 @@ class FalnetPlan:
             call()
         if self._side_stream is not None:
             main.wait_stream(self._side_stream)
+        if getattr(self, "_deferred_ready", None) is not None:
+            self.model._bucket_ready(self._deferred_ready)
         self.model._end_grad_accumulation()
 
 
@@ -533,8 +549,10 @@ class FAL_net(nn.Module):
                 first.setdefault("dec", off)
             if n.startswith("backbone.conv4."):
                 first.setdefault("enc4", off)
+            if n.startswith("backbone.conv1."):
+                first.setdefault("enc1", off)
         total = self._flat.numel()
-        return [(first["dec"], total), (first["enc4"], first["dec"]), (0, first["enc4"])]
+        return [(first["dec"], total), (first["enc4"], first["dec"]), (first["enc1"], first["enc4"]), (0, first["enc1"])]
 
     def _bucket_ready(self, bucket):
         hook = getattr(self, "bucket_hook", None)
