@@ -421,7 +421,7 @@ class FalnetPlan:
         b["min_disp"].copy_(min_disp.reshape(-1))
         b["max_disp"].copy_(max_disp.reshape(-1))
         b["flow"][:, 0] = (b["max_disp"] / 100.0).to(self.dtype)  # FAL_netB.py:208-209
-        if repack:
+        if repack and not self.model._packed_is_fresh():
             for call in self.pack:
                 call()
         for call in self.fwd:
@@ -539,6 +539,31 @@ class FAL_net(nn.Module):
         self._gviews = {id(p): self._flat_grad[off:off + p.numel()].view(p.shape) for (n, p), off in zip(named, self._offsets)}
         self._plans = {}
         self._build_packed()
+
+    def _packed_is_fresh(self):
+        """True when the packed compute-dtype weight copies already match the f32 masters: FlatAdam re-packs right behind its
+        update (`repack_after_optimizer`), and nothing has written the flat buffer in place since (shared version counter of
+        the parameter views; writes through `.data` / raw pointers by other code are not tracked -> call `mark_weights_changed`)."""
+        return (getattr(self, "_packed_version", None) is not None and self._flat is not None
+                and self._packed_version == self._weights_version() and not torch.cuda.is_current_stream_capturing())
+
+    def _weights_version(self):
+        # in-place writes bump the version counter of the tensor they go through: the flat buffer's or a parameter's own
+        return self._flat._version + sum(p._version for _, p in self._trainable_named())
+
+    def mark_weights_changed(self):
+        self._packed_version = None
+
+    def repack_after_optimizer(self):
+        """Re-pack the weights NOW (current stream, behind the optimizer's kernel) instead of at the start of the next forward:
+        the ~0.1 ms launch then runs while the host is still issuing the next step's prologue."""
+        plan = next(iter(self._plans.values()), None)
+        if plan is None or torch.cuda.is_current_stream_capturing():
+            self._packed_version = None
+            return
+        for call in plan.pack:
+            call()
+        self._packed_version = self._weights_version()
 
     def gradient_buckets(self):
         """Contiguous element ranges of the flat gradient buffer, in the order backward finalises them."""

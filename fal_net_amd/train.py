@@ -49,6 +49,10 @@ class FlatAdam:
         b1, b2 = self.betas
         L.check(L.lib().falnet_adam_step_dev(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
                                              b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
+        if _os.environ.get("FALNET_PACK_AFTER_ADAM", "1") == "1":
+            self.model.repack_after_optimizer()  # the raw-pointer update is invisible to autograd's version counters
+        else:
+            self.model.mark_weights_changed()
 
 
 def enable_overlapped_allreduce(model):
