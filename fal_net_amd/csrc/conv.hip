@@ -2051,22 +2051,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_
     const int cp0 = (rel % chunks) * 64, co = rel / chunks;
     const int s0 = (int)((int64_t)d.nsplit * grp / d.groups), s1 = (int)((int64_t)d.nsplit * (grp + 1) / d.groups);
     const int64_t slab = (int64_t)d.ntaps * d.w_rows * d.cin_total;
-    for (int e = threadIdx.x; e < d.ntaps * 64; e += blockDim.x) {
-        const int t = e / 64, cl = e % 64;
-        float s = 0.f;
-        if (cp0 + cl < d.cin_total) {
-            const float* src = d.partial + ((int64_t)t * d.w_rows + co) * d.cin_total + cp0 + cl;
+    // one float4 (four packed input channels) per thread and slab, eight slabs in flight; the per-element summation
+    // order over the slabs stays sequential
+    for (int e = threadIdx.x; e < d.ntaps * 16; e += blockDim.x) {
+        const int t = e / 16, c4 = (e % 16) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cp0 + c4 < d.cin_total) {  // cin_total is a multiple of 32
+            const float* src = d.partial + ((int64_t)t * d.w_rows + co) * d.cin_total + cp0 + c4;
             int k = s0;
-            for (; k + 8 <= s1; k += 8) {  // eight slab loads in flight; the summation order stays sequential
-                float v[8];
+            for (; k + 8 <= s1; k += 8) {
+                float4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(k + j) * slab];
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(src + (k + j) * slab);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[j];
+                for (int j = 0; j < 8; ++j) {
+                    s.x += v[j].x;
+                    s.y += v[j].y;
+                    s.z += v[j].z;
+                    s.w += v[j].w;
+                }
             }
-            for (; k < s1; ++k) s += src[k * slab];
+            for (; k < s1; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(src + k * slab);
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
         }
-        tile[cl * d.ntaps + t] = s;
+        tile[(c4 + 0) * d.ntaps + t] = s.x;
+        tile[(c4 + 1) * d.ntaps + t] = s.y;
+        tile[(c4 + 2) * d.ntaps + t] = s.z;
+        tile[(c4 + 3) * d.ntaps + t] = s.w;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < d.ntaps * 64; e += blockDim.x) {
@@ -2098,14 +2114,13 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int64_t pix = (int64_t)bx * rows + rr;
         const int64_t stride = (int64_t)nbx * rows;
-        for (; pix + 3 * stride < d.npix; pix += 4 * stride) {  // four independent 16-B loads in flight
-            Vec8<T> v0, v1, v2, v3;
-            v0.load(g + pix * d.gC + seg * 8);
-            v1.load(g + (pix + stride) * d.gC + seg * 8);
-            v2.load(g + (pix + 2 * stride) * d.gC + seg * 8);
-            v3.load(g + (pix + 3 * stride) * d.gC + seg * 8);
+        for (; pix + 7 * stride < d.npix; pix += 8 * stride) {  // eight independent 16-B loads in flight
+            Vec8<T> v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += (v0.get(i) + v1.get(i)) + (v2.get(i) + v3.get(i));
+            for (int j = 0; j < 8; ++j) v[j].load(g + (pix + j * stride) * d.gC + seg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                acc[i] += ((v[0].get(i) + v[1].get(i)) + (v[2].get(i) + v[3].get(i))) + ((v[4].get(i) + v[5].get(i)) + (v[6].get(i) + v[7].get(i)));
         }
         for (; pix < d.npix; pix += stride) {
             Vec8<T> v;
