@@ -328,7 +328,19 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
                 tile_load<T>(actout, o, cbase, h, p.Cout, a);
                 actgrad16(v, a, p.actout_kind);
             }
-            if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
+            if (p.out_layout == FALNET_OUT_PLANAR_F32) {
+                // planar f32 [B][Cout][OH][OW] (the MED logits): o = offset of channel 0 of this lane's pixel, channel stride
+                // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
+                float* po = reinterpret_cast<float*>(p.out);
+                const int64_t cs = (int64_t)p.OH * p.OW;
+                if (o >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
+                        if (c < p.Cout) po[o + c * cs] = v[j];
+                    }
+                }
+            } else if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
             if constexpr (POOL) {
                 if (pooling) {
                     float m[16];
@@ -1022,9 +1034,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         load_bias16<NT>(p, n0 + wn * WTN, h, bias);
         const int cstride = p.out_cstride;
         const int x = tx0 + r;
+        const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
         auto pixoff = [&](int mt) -> int64_t {
             const int y = ty0 + wm * MT + mt;
-            return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
+            if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+            return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
         };
         if constexpr (MT % 2 == 0) {
             // fused 2x2 reduction (p.pool_out): block rows start even and every wave owns an even number of rows
@@ -1219,9 +1233,11 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
         const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int ty0 = tiy * TH, x = tix * PT_TW + r;
         const int cstride = p.out_cstride;
+        const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
         auto pixoff = [&](int mt) -> int64_t {
             const int y = ty0 + wm * MT + mt;
-            return (y < p.OH && x < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + x) * cstride : (int64_t)-1;
+            if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+            return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
         };
         auto pooloff = [&](int mt) -> int64_t {
             const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
@@ -2269,7 +2285,8 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     int ctot = 0;
     for (int s = 0; s < p.nsrc; ++s) ctot += p.src[s].C;
-    bool dense3x3 = !planar && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
+    // (a planar f32 output is fine for the halo-patch / weight-stationary kernels: their epilogue has the pixels on the lanes)
+    bool dense3x3 = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
                     p.TH == p.OH && p.TW == p.OW && p.TH == p.IH && p.TW == p.IW && p.TW >= 16;
     // the patch kernels walk taps in spatial order with weight tap t (forward) or 8-t (stride-1 dgrad)
     int flip = -1;

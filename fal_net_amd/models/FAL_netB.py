@@ -234,9 +234,19 @@ class FalnetPlan:
         lib = L.lib()
         code = L.dtype_code(dt)
         pcs = m._packed
-        for pc in pcs.values():
+        compose = getattr(m, "_compose_logits", False)
+        if compose:
+            w1_2d = m.conv0.weight.detach().view(m.conv0.weight.shape[0], -1)
+            w3_2d = m.backbone.iconv1.weight.detach().view(m.backbone.iconv1.weight.shape[0], -1)
+            wc_2d = m._wc.view(m._wc.shape[0], -1)
+
+            def compose_call():
+                torch.mm(w1_2d, w3_2d, out=wc_2d)
+            self.pack.append(compose_call)  # before the re-pack below: the composed f32 master changes with every update
+        packed_now = [pc for k, pc in pcs.items() if not (compose and k in ("iconv1", "conv0_1x1"))]
+        for pc in packed_now:
             pc.alloc(dt, dev)
-        self.pack.append(ops.pack_all_call(list(pcs.values()), dt, dev))
+        self.pack.append(ops.pack_all_call(packed_now, dt, dev))
         self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)
@@ -286,15 +296,23 @@ class FalnetPlan:
             if lvl > 1:
                 ic[lvl] = self._act(f"i{lvl}", hh, ww, ich)
                 self._conv_fwd(pcs[iname], [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, ic[lvl], L.ACT_ELU, name=iname)
+            elif compose:
+                logits_srcs = [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)]
             else:
                 dlog = self._act("dlog", hh, ww, pad_c(N))
                 self._conv_fwd(pcs[iname], [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, dlog, L.ACT_NONE, name=iname)
-        # ---- 1x1 conv0 -> planar f32 logits, MED head ----
+        # ---- logits: planar f32 [B][N][H][W] for the MED head ----
         pc0 = pcs["conv0_1x1"]
         dlog0 = self._f32("dlog0", B, N, H, W)
-        self.fwd.append(self._conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
-                                      1, B, H, W, dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pc0.bias,
-                                      name="fwd conv0(1x1)", flops=2 * B * H * W * N * N))
+        if compose:
+            pcl = pcs["logits"]
+            self.fwd.append(self._conv_call(dt, logits_srcs, H, W, pcl.wf, pcl.cin_pad, ops.fwd_taps(3), 9, pcl.cout_pad, 1, B, H, W,
+                                            dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pcl.bias, name="fwd logits(iconv1*conv0)",
+                                            flops=2 * B * H * W * N * pcl.cin * 9))
+        else:
+            self.fwd.append(self._conv_call(dt, [ops.nhwc_src(dlog)], H, W, pc0.wf, pc0.cin_pad, ops.fwd_taps(1), 1, pc0.cout_pad,
+                                            1, B, H, W, dlog0, H, W, N, 0, out_layout=L.OUT_PLANAR_F32, bias=pc0.bias,
+                                            name="fwd conv0(1x1)", flops=2 * B * H * W * N * N))
         disp, pan, stats = self._f32("disp", B, 1, H, W), self._f32("p_im0", B, 3, H, W), self._f32("stats", B, 4, H, W)
         maskL, maskR = self._f32("maskL", B, 1, H, W), self._f32("maskR", B, 1, H, W)
         self.head_disp_only = ops.simple_call("falnet_med_head_fwd", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx),
@@ -322,9 +340,12 @@ class FalnetPlan:
         self._bucket = 0
         self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
         self._side_call(self._x0_convert)
-        self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
-        g_dlog = self._act("g_dlog", H, W, pad_c(N))
-        self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
+        if compose:
+            g_dlog = G0  # the composed conv's output gradient IS the head's gradient
+        else:
+            self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
+            g_dlog = self._act("g_dlog", H, W, pad_c(N))
+            self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
 
         gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], _ENC[i][2]) for i in range(7)}
         # decoder, top (level 1) to bottom (level 6)
@@ -335,6 +356,9 @@ class FalnetPlan:
             below = ic[lvl + 1]
             bh, bw = below.shape[1], below.shape[2]
             pci, pcd = pcs[iname], pcs[dname]
+            if compose and lvl == 1:
+                pci = pcs["logits"]  # weight gradient lands in model._gwc and is split back after the bucket's slab reduce
+                iname = "logits"
             skip = c[lvl - 1]
             gi = g_ipre[lvl]
             self._wgrad(pci, [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, gi, name=iname)
@@ -409,9 +433,19 @@ class FalnetPlan:
                 def finish(red=red, bias=bias, bucket=bucket):
                     red()
                     bias()
+                    if bucket == 0 and getattr(self.model, "_compose_logits", False):
+                        self._split_logits_grad()
                     self.model._bucket_ready(bucket)
                 self._side_call(finish)
         self.bwd_body.extend(body[pos:])
+
+    def _split_logits_grad(self):
+        """dWc (composed 3x3 logits conv) -> dW3x3 = W1x1^T dWc and dW1x1 = dWc W3x3^T, added into the flat gradient buffer."""
+        m = self.model
+        w1, w3 = m.conv0.weight.detach(), m.backbone.iconv1.weight.detach()
+        g = m._gwc.view(w1.shape[0], -1)
+        m._grad_view(m.backbone.iconv1.weight).view(w3.shape[0], -1).addmm_(w1.view(w1.shape[0], -1).t(), g)
+        m._grad_view(m.conv0.weight).view(w1.shape[0], -1).addmm_(g, w3.view(w3.shape[0], -1).t())
 
     # ---- execution ----
     def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
@@ -443,6 +477,8 @@ class FalnetPlan:
         self._accumulate = self.model._begin_grad_accumulation()
         if not self._accumulate:
             self.model._flat_grad.zero_()  # the batched reduce / bias kernels ADD into the flat gradient buffer
+        if getattr(self.model, "_compose_logits", False):
+            self.model._gwc.zero_()  # per-backward scratch: its content is split into the two real gradients
         main = torch.cuda.current_stream()
         if self.use_side_stream and ops.TIMER is None:
             if self._side is None:
@@ -634,6 +670,18 @@ class FAL_net(nn.Module):
         add("deconv1", bb.deconv1.conv1, [64])
         add("iconv1", bb.iconv1, [64, 32])
         add("conv0_1x1", self.conv0, [self.no_levels])
+        # iconv1 (3x3, no bias, no activation; FAL_netB.py:127,174) followed by the 1x1 conv0 (FAL_netB.py:190,215) is ONE linear
+        # map: the plans run a single 3x3 convolution with the composed weights Wc = W1x1 . W3x3 straight into the planar f32
+        # logits (no NHWC intermediate, no 1x1 launches in forward / dgrad / wgrad); the weight gradients are split back by
+        # two small matrix products (dW3x3 = W1x1^T dWc, dW1x1 = dWc W3x3^T).  FALNET_COMPOSE_LOGITS=0 keeps the two launches.
+        self._compose_logits = os.environ.get("FALNET_COMPOSE_LOGITS", "1") == "1"
+        if self._compose_logits:
+            w3, w1 = bb.iconv1.weight, self.conv0.weight
+            dev = w3.device
+            self._wc = torch.zeros(w1.shape[0], w3.shape[1], 3, 3, dtype=torch.float32, device=dev)
+            self._gwc = torch.zeros_like(self._wc)
+            self._gviews[id(self._wc)] = self._gwc
+            P["logits"] = PackedConv("logits", self._wc, self.conv0.bias, [64, 32], 1)
         self._packed = P
 
     def _plan(self, B, H, W, device):

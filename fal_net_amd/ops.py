@@ -216,7 +216,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout)
-    if AUTOTUNE and autotune and out_layout == L.OUT_NHWC and dev_t.is_cuda:
+    if AUTOTUNE and autotune and dev_t.is_cuda:
         d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
     if pool_out is not None and lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:
         raise ValueError("no fused-pool kernel applies to this launch")  # the caller falls back to falnet_maxpool2_fwd

@@ -107,3 +107,21 @@ def test_highres_n96_forward_vs_oracle():
         pan, disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV), ret_disp=True, ret_pan=True)
     assert rel(disp, ref[1]) < F32_TOL
     assert rel(pan, ref[0]) < F32_TOL
+
+
+def test_composed_logits_conv_matches_two_launch_form(monkeypatch):
+    """iconv1 (3x3, linear) followed by the 1x1 conv0 runs as ONE 3x3 convolution with composed weights (FAL_netB.py:127,174,
+    190,215); outputs and the gradients of BOTH original weight tensors (split back from the composed weight gradient) must
+    equal the two-launch form."""
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 96, seed=11)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FALNET_COMPOSE_LOGITS", flag)
+        m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(7)}, 7).to(DEV).train()
+        pan, disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV), ret_disp=True, ret_pan=True)
+        g = torch.Generator().manual_seed(3)
+        ((pan * torch.randn(pan.shape, generator=g).to(DEV)).sum() + (disp * torch.randn(disp.shape, generator=g).to(DEV)).sum() * 0.01).backward()
+        res[flag] = (disp.detach().clone(), pan.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert rel(res["1"][0], res["0"][0]) < 1e-5 and rel(res["1"][1], res["0"][1]) < 1e-5
+    for k in ("backbone.iconv1.weight", "conv0.weight", "conv0.bias", "backbone.deconv1.conv1.weight", "backbone.conv0.0.weight"):
+        assert rel(res["1"][2][k], res["0"][2][k]) < 1e-4, k
