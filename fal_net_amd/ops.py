@@ -390,9 +390,11 @@ def _wgrad_big(dtype, dense, cin_pad, cout_pad):
 
 
 def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
-    """32 (cin) x 64 (cout) channels per workgroup (falnet_wgrad variant 3): one gout fragment pair feeds twice the MFMAs.
-    Measured -17 % on 64 -> 64 channel layers, within noise for wider ones (left on the 32 x 32 form)."""
-    return dense and dtype == torch.bfloat16 and cin_pad <= 64 and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
+    """32 (cin) x 64 (cout) channels per workgroup (falnet_wgrad variant 3): one gout fragment pair feeds twice the MFMAs
+    (1.7 instead of 2.7 transposed LDS reads per MFMA).  In isolation -17 % on 64 -> 64 channel layers and -4 % on 128 -> 128;
+    in the step (weight gradients are the longest chain of backward) +2.1 % pairs/s with the cut at 128 input channels, a little
+    less with no cut (same-box A/B)."""
+    return dense and dtype == torch.bfloat16 and cin_pad <= int(os.environ.get("FALNET_WGRAD_CO2_MAXCIN", "128")) and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
 
 
 class WgradBatch:
