@@ -52,3 +52,28 @@ def test_single_process_is_identity():
     m = _FlatModel(8)
     m.g.fill_(3.0)
     assert train.allreduce_gradients(m) == 1.0 and float(m.g.sum()) == 24.0
+
+
+def _worker_buckets(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    m = _FlatModel(n)
+    m.g.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+    train.enable_overlapped_allreduce(m)
+    assert m.bucket_hook is not None
+    # backward finalises contiguous ranges of the flat buffer back to front (FAL_net.gradient_buckets): one async all-reduce each
+    for i, (lo, hi) in enumerate([(700, n), (300, 700), (10, 300), (0, 10)]):
+        m.bucket_hook(i, m.g[lo:hi])
+    scale = train.allreduce_gradients(m)  # waits for the pending bucket reductions; no second collective
+    if rank == 0:
+        torch.save({"g": m.g.clone(), "scale": scale, "pending": len(m._pending_reduces)}, out)
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_covers_the_flat_buffer_once(tmp_path):
+    world, out = 2, str(tmp_path / "r0b.pt")
+    mp.spawn(_worker_buckets, args=(world, 29534, out), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["scale"] == 0.5 and got["pending"] == 0
+    assert torch.equal(got["g"], torch.arange(1000, dtype=torch.float32) * 3)  # rank0 (x1) + rank1 (x2), every element exactly once
