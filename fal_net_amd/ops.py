@@ -343,7 +343,7 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     if dense:
         tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
         npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-        nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
+        nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
     else:
         tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
         nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
@@ -378,6 +378,9 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
         t_reduce(accumulate)
     call.desc = d
     return call
+
+
+_WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
 
 
 def _wgrad_big(dtype, dense, cin_pad, cout_pad):
@@ -430,7 +433,7 @@ class WgradBatch:
         if dense:
             tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
             npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-            nsplit = max(1, min(((512 if big else 768) + tiles - 1) // tiles, npatch))
+            nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
         else:
             tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
             nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
