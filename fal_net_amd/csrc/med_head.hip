@@ -391,6 +391,152 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_kernel(
     }
 }
 
+// Backward, LDS-staged form (NHWC output; W <= 256*PPT).  The kernel above reads every logit three times per (n, x) with
+// 4-byte lane loads (x-1, x, x+1) and stores 16 B per lane at a cpad stride: ~2.6x its HBM time.  Here the workgroup streams
+// CH plane rows of its image row into LDS with coalesced 16-byte loads (each logit leaves L2 once), the three taps become LDS
+// reads, and every thread keeps its pixels' constants in registers across the chunks; a chunk = 8 planes = one 16-B bf16
+// (32-B f32) store per pixel.
+template <typename OUT, int PPT>
+__global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
+    const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
+    const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,
+    OUT* __restrict__ gdlog0, int N, int H, int W, int cpad) {
+    static_assert(CH == 8, "one chunk = one 8-channel store");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    const int WP = W + 3;
+    float* rowU = reinterpret_cast<float*>(smem + sizeof(PlaneTab));  // [3][WP]
+    float* rowV = rowU + 3 * WP;
+    float* rowM = rowV + WP;
+    const int PP = (W + 11) & ~3;  // plane-row pitch in floats: x lives at index x+4 (16-B aligned fills), zeros at 3 and >= W+4
+    float* prow = reinterpret_cast<float*>(smem + (sizeof(PlaneTab) + (size_t)5 * WP * sizeof(float) + 15) / 16 * 16);  // [CH][PP]
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t rowoff = (int64_t)y * W;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    const bool has_pan = gpan != nullptr, has_disp = gdisp != nullptr;
+    const float* st = stats + (int64_t)b * 4 * HW + rowoff;
+    if (has_pan) {
+        for (int i = threadIdx.x; i < WP; i += blockDim.x) {
+            const int x = i - 1;
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f, v = 0.f, m = 0.f;
+            if (x >= 0 && x < W) {
+                const float rz = 1.f / st[3 * HW + x];
+                const float g0 = gpan[((int64_t)b * 3 + 0) * HW + rowoff + x];
+                const float g1 = gpan[((int64_t)b * 3 + 1) * HW + rowoff + x];
+                const float g2 = gpan[((int64_t)b * 3 + 2) * HW + rowoff + x];
+                const float q = g0 * p_im0[((int64_t)b * 3 + 0) * HW + rowoff + x] +
+                                g1 * p_im0[((int64_t)b * 3 + 1) * HW + rowoff + x] +
+                                g2 * p_im0[((int64_t)b * 3 + 2) * HW + rowoff + x];
+                u0 = g0 * rz;
+                u1 = g1 * rz;
+                u2 = g2 * rz;
+                v = q * rz;
+                m = st[2 * HW + x];
+            }
+            rowU[i] = u0;
+            rowU[WP + i] = u1;
+            rowU[2 * WP + i] = u2;
+            rowV[i] = v;
+            rowM[i] = m;
+        }
+    }
+    for (int i = threadIdx.x; i < CH * PP; i += blockDim.x) {
+        const int c = i % PP;
+        if (c < 4 || c >= W + 4) prow[i] = 0.f;  // out-of-row taps read 0 (the logit of a pixel outside the image)
+    }
+    const float* Lrow = dlog0 + (int64_t)b * N * HW + rowoff;
+    OUT* Grow = gdlog0 + ((int64_t)b * HW + rowoff) * cpad;
+    const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(Lrow) & 15) == 0) && ((HW & 3) == 0);
+
+    // per-pixel constants across planes
+    float lm[PPT][3], lc[PPT][3], lp[PPT][3], m0[PPT], rz0[PPT], gd[PPT], dsp[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int x = threadIdx.x + q * HEAD_THREADS;
+        m0[q] = rz0[q] = gd[q] = dsp[q] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lm[q][c] = lc[q][c] = lp[q][c] = 0.f;
+        if (x < W) {
+            if (has_pan) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* lr = left + ((int64_t)b * 3 + c) * HW + rowoff;
+                    lm[q][c] = x > 0 ? lr[x - 1] : 0.f;
+                    lc[q][c] = lr[x];
+                    lp[q][c] = x + 1 < W ? lr[x + 1] : 0.f;
+                }
+            }
+            if (has_disp) {
+                m0[q] = st[x];
+                rz0[q] = 1.f / st[HW + x];
+                gd[q] = gdisp[(int64_t)b * HW + rowoff + x];
+                dsp[q] = disp[(int64_t)b * HW + rowoff + x];
+            }
+        }
+    }
+    for (int n0 = 0; n0 < cpad; n0 += CH) {
+        __syncthreads();  // previous chunk fully consumed (and tab / rows ready)
+        if (n0 < N) {
+            if (vec4) {
+                const int w4 = W >> 2;
+                for (int i = threadIdx.x; i < CH * w4; i += blockDim.x) {
+                    const int j = i / w4, q4 = i % w4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q4];
+                    *reinterpret_cast<float4*>(prow + j * PP + 4 + 4 * q4) = v;
+                }
+            } else {
+                for (int i = threadIdx.x; i < CH * W; i += blockDim.x) {
+                    const int j = i / W, x = i % W;
+                    prow[j * PP + 4 + x] = n0 + j < N ? Lrow[(int64_t)(n0 + j) * HW + x] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int x = threadIdx.x + q * HEAD_THREADS;
+            if (x >= W) continue;
+            float gv[8];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int n = n0 + j;
+                float g = 0.f;
+                if (n < N) {
+                    const float* pr = prow + j * PP + 4 + x;
+                    const float Lc = pr[0];
+                    if (has_pan) {
+                        const int k = tab.k[n];
+                        const float a = tab.a[n];
+                        const float Lm = pr[-1], Lp = pr[1];
+                        const int xa = x - k;  // source pixel whose first tap is x
+                        if (xa >= 0) {
+                            const float wl = (1.f - a) * Lc + a * Lp;
+                            const float G = rowU[xa + 1] * ((1.f - a) * lc[q][0] + a * lp[q][0]) +
+                                            rowU[WP + xa + 1] * ((1.f - a) * lc[q][1] + a * lp[q][1]) +
+                                            rowU[2 * WP + xa + 1] * ((1.f - a) * lc[q][2] + a * lp[q][2]);
+                            g += (1.f - a) * __expf(wl - rowM[xa + 1]) * (G - rowV[xa + 1]);
+                        }
+                        const int xb = xa - 1;  // source pixel whose second tap is x
+                        if (xb >= 0) {
+                            const float wl = (1.f - a) * Lm + a * Lc;
+                            const float G = rowU[xb + 1] * ((1.f - a) * lm[q][0] + a * lc[q][0]) +
+                                            rowU[WP + xb + 1] * ((1.f - a) * lm[q][1] + a * lc[q][1]) +
+                                            rowU[2 * WP + xb + 1] * ((1.f - a) * lm[q][2] + a * lc[q][2]);
+                            g += a * __expf(wl - rowM[xb + 1]) * (G - rowV[xb + 1]);
+                        }
+                    }
+                    if (has_disp) g += gd[q] * __expf(Lc - m0[q]) * rz0[q] * (tab.d[n] - dsp[q]);
+                }
+                gv[j] = g;
+            }
+            store8(Grow + (int64_t)x * cpad + n0, gv);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- masks
 // maskR(x) = min(1, sum_n (1-a) sm_n(x+k) + a sm_n(x+k+1)),   sm = softmax(dlog0)        (FAL_netB.py:266-267)
 // maskL(x) = min(1, sum_n a Dprob_n(x-k-1) + (1-a) Dprob_n(x-k))  (shift by -s_n)         (FAL_netB.py:270-273)
@@ -512,6 +658,21 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     FALNET_CHECK_ARG(cpad >= N && cpad % 8 == 0, "med_head_bwd_nhwc: cpad=%d must be a multiple of 8 >= N", cpad);
     FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16, "med_head_bwd_nhwc: bad dtype %d", dtype);
     const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
+    static const bool v1 = [] { const char* e = getenv("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
+    if (!v1 && W <= 4 * HEAD_THREADS) {  // LDS-staged plane rows
+        const size_t lds2 = (lds + 15) / 16 * 16 + (size_t)CH * ((W + 11) & ~3) * sizeof(float);
+#define LAUNCH_BWD_LDS(T, P)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_lds_kernel<T, P>), dim3(B * H), dim3(HEAD_THREADS), lds2, (hipStream_t)stream, dlog0, left, \
+                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (T*)grad_dlog0_nhwc, N, H, W, cpad)
+        const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
+        if (dtype == FALNET_BF16) {
+            if (ppt <= 1) LAUNCH_BWD_LDS(bf16_t, 1); else if (ppt == 2) LAUNCH_BWD_LDS(bf16_t, 2); else LAUNCH_BWD_LDS(bf16_t, 4);
+        } else {
+            if (ppt <= 1) LAUNCH_BWD_LDS(float, 1); else if (ppt == 2) LAUNCH_BWD_LDS(float, 2); else LAUNCH_BWD_LDS(float, 4);
+        }
+#undef LAUNCH_BWD_LDS
+        FALNET_RETURN_LAUNCH();
+    }
     if (dtype == FALNET_BF16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<bf16_t, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
                            min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (bf16_t*)grad_dlog0_nhwc, N, H, W, cpad);

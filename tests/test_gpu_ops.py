@@ -428,14 +428,15 @@ def test_med_head(B, N, H, W, maxd):
     L.check(lib.falnet_med_head_bwd(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
                                     L.ptr(gd_d), L.ptr(gp_d), L.ptr(gl), B, N, H, W, L.stream_ptr()))
     assert rel(gl, dlog0.grad) < F32_TOL
-    # the same gradient written pixel-major (what the 1x1 logits conv's gradient launches consume): f32 identical to
-    # the planar one, bf16 = its rounding; padding channels zero
+    # the same gradient written pixel-major (what the logits conv's gradient launches consume); padding channels zero
     for dt in (torch.float32, torch.bfloat16):
         cp = ops.pad_c(N)
         gn = torch.full((B, H, W, cp), float("nan"), dtype=dt, device=DEV)
         L.check(lib.falnet_med_head_bwd_nhwc(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
                                              L.ptr(gd_d), L.ptr(gp_d), L.ptr(gn), cp, L.dtype_code(dt), B, N, H, W, L.stream_ptr()))
-        assert torch.equal(gn[..., :N].float(), gl.permute(0, 2, 3, 1).to(dt).float())
+        # (the NHWC form is a different kernel -- LDS-staged plane rows -- so equal up to contraction order, not bitwise)
+        assert rel(gn[..., :N].float(), gl.permute(0, 2, 3, 1).float()) < (2e-6 if dt == torch.float32 else 1e-2)
+        assert rel(gn[..., :N].float().permute(0, 3, 1, 2), dlog0.grad) < (F32_TOL if dt == torch.float32 else 1e-2)
         assert cp == N or float(gn[..., N:].float().abs().max()) == 0.0
     # disparity-only backward
     dlog0.grad = None
