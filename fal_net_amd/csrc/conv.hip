@@ -1779,6 +1779,171 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
     }
 }
 
+// Stride-2 3x3 weight gradient (encoder convs conv1..conv6, FAL_netB.py:101-111), bf16: the same wave-per-tap-row scheme
+// as the dense kernel on a 4x32 block of OUTPUT positions; the (2*4+1)x(2*32+1) input region is loaded as whole contiguous
+// rows and de-interleaved by row / column parity into four LDS planes (even/odd rows x even/odd columns), so that the
+// pixels tap (ky,kx) needs for 16 consecutive outputs (2x+kx-1: stride 2 in the image) are 16 CONSECUTIVE rows of one
+// plane -- the transposed reads and their conflict-free 64-B pitch are exactly those of the dense kernel.
+//   tap ky: rows 2y+ky-1 -> ky=1: odd region rows (index y), ky=0 / 2: even region rows (index y / y+1); columns alike.
+// (The per-tap gather kernel it replaces ran these layers at 65-130 TFLOP/s on the longest chain of the backward pass.)
+#define WS2_RH (2 * WP_TH + 1)   // region rows
+#define WS2_RW (2 * WP_TW + 1)   // region columns
+template <int COT>
+__global__ __launch_bounds__(WP_THREADS) void wgrad3x3_s2_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+                                                                 int patches_per_split) {
+    typedef bf16_t T;
+    constexpr int EPS = 8, SEGS = 4, PITCH = 64;
+    constexpr int NE_R = WP_TH + 1, NO_R = WP_TH, NE_C = WP_TW + 1, NO_C = WP_TW;  // even / odd region rows and columns
+    // plane (row parity, column parity) -> pixel offset of its first pixel; E = even region index
+    constexpr int P_EE = 0, P_EO = P_EE + NE_R * NE_C, P_OE = P_EO + NE_R * NO_C, P_OO = P_OE + NO_R * NE_C, I_PIX = P_OO + NO_R * NO_C;
+    static_assert(I_PIX == WS2_RH * WS2_RW, "the four planes tile the region");
+    constexpr int G_PLANE = WP_TH * WP_TW * PITCH;
+    constexpr int G_BYTES = COT * G_PLANE, I_BYTES = I_PIX * PITCH;
+    constexpr int G_LOADS = WP_TH * WP_TW * SEGS * COT, I_LOADS = I_PIX * SEGS;
+    constexpr int G_SLOTS = (G_LOADS + WP_THREADS - 1) / WP_THREADS, I_SLOTS = (I_LOADS + WP_THREADS - 1) / WP_THREADS;
+    // ONE LDS buffer (54 KB with COT = 2) + register prefetch of the next block: two workgroups per CU overlap each other
+    __shared__ __attribute__((aligned(16))) char lds[G_BYTES + I_BYTES];
+    auto Gbuf = [&](int) -> char* { return lds; };
+    auto Ibuf = [&](int) -> char* { return lds + G_BYTES; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32 * COT, split = blockIdx.z;
+    const int c_first = p.src[0].C;
+    const bool second = ci0 >= c_first;
+    const T* s_ptr = reinterpret_cast<const T*>(second ? p.src[1].ptr : p.src[0].ptr) + (second ? ci0 - c_first : ci0);
+    const int64_t s_sb = second ? p.src[1].sb : p.src[0].sb, s_sy = second ? p.src[1].sy : p.src[0].sy, s_sx = second ? p.src[1].sx : p.src[0].sx;
+    const int npatch = p.B * tiles_x * tiles_y;
+    const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
+
+    // region slots: (row, column, 16-B segment) -> LDS offset inside the parity plane (loop-invariant)
+    short i_row[I_SLOTS], i_col[I_SLOTS];
+    int i_lds[I_SLOTS];
+#pragma unroll
+    for (int u = 0; u < I_SLOTS; ++u) {
+        const int idx = tid + u * WP_THREADS;
+        const int seg = idx % SEGS, pix = idx / SEGS;
+        const int r = pix / WS2_RW, c = pix % WS2_RW;
+        i_row[u] = (short)r;
+        i_col[u] = (short)c;
+        const int base = (r & 1) ? ((c & 1) ? P_OO : P_OE) : ((c & 1) ? P_EO : P_EE);
+        const int pw = (c & 1) ? NO_C : NE_C;
+        i_lds[u] = idx < I_LOADS ? (base + (r >> 1) * pw + (c >> 1)) * PITCH + seg * 16 : -1;
+    }
+    struct Regs { uint4 g[G_SLOTS]; uint4 i[I_SLOTS]; };
+    auto gload = [&](int patch, Regs& R) {
+        int q = patch;
+        const int tix = q % tiles_x;
+        q /= tiles_x;
+        const int tiy = q % tiles_y;
+        const int b = q / tiles_y;
+        const int y0 = tiy * WP_TH, x0 = tix * WP_TW;
+        const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC + co0;
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            const int seg = idx % (SEGS * COT), pix = idx / (SEGS * COT);
+            const int y = y0 + pix / WP_TW, x = x0 + pix % WP_TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < G_LOADS && y < p.TH && x < p.TW && co0 + seg * EPS < p.gC)
+                v = *reinterpret_cast<const uint4*>(gbase + ((int64_t)y * p.TW + x) * p.gC + seg * EPS);
+            R.g[u] = v;
+        }
+        const T* ibase = s_ptr + (int64_t)b * s_sb;
+#pragma unroll
+        for (int u = 0; u < I_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int vy = 2 * y0 - 1 + i_row[u], vx = 2 * x0 - 1 + i_col[u];
+            if (idx < I_LOADS && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW)
+                v = *reinterpret_cast<const uint4*>(ibase + (int64_t)vy * s_sy + (int64_t)vx * s_sx + (idx % SEGS) * EPS);
+            R.i[u] = v;
+        }
+    };
+    auto lstore = [&](int buf, const Regs& R) {
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WP_THREADS;
+            const int seg8 = idx % (SEGS * COT), pix = idx / (SEGS * COT);
+            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + (seg8 / SEGS) * G_PLANE + (pix * SEGS + seg8 % SEGS) * 16) = R.g[u];
+        }
+#pragma unroll
+        for (int u = 0; u < I_SLOTS; ++u)
+            if (i_lds[u] >= 0) *reinterpret_cast<uint4*>(Ibuf(buf) + i_lds[u]) = R.i[u];
+    };
+
+    f32x16 acc[3][COT];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 0; c < COT; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][c][j] = 0.f;
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q4 = i16 >> 2, pc = i16 & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    const int lane_off = (kh * 8 + q4) * PITCH + (cb * 16 + pc * 4) * 2;
+    // wave = ky: region-row parity and row shift inside the plane
+    const bool odd_rows = wave == 1;
+    const int row_shift = wave == 2 ? 1 : 0;
+
+    auto compute = [&](int cur) {
+        const char* gl = Gbuf(cur) + lane_off;
+        const char* il = Ibuf(cur) + lane_off;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {  // K = 128 output positions: block row ks>>1, 16-position half ks&1
+            const int goff = ks * 16 * PITCH;
+            bf16x8 av[COT];
+#pragma unroll
+            for (int c = 0; c < COT; ++c) {
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
+                av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            const int prow = (ks >> 1) + row_shift;  // row inside the parity plane
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                // column parity odd for kx = 1; even columns start at lx (kx = 0) or lx + 1 (kx = 2)
+                const int pw = kx == 1 ? NO_C : NE_C;
+                const int pbase = odd_rows ? (kx == 1 ? P_OO : P_OE) : (kx == 1 ? P_EO : P_EE);
+                const int ioff = (pbase + prow * pw + (ks & 1) * 16 + (kx == 2 ? 1 : 0)) * PITCH;
+                s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
+                s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int c = 0; c < COT; ++c) acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[kx][c], 0, 0, 0);
+            }
+        }
+    };
+
+    Regs R0;
+    if (pbeg < pend) {
+        gload(pbeg, R0);
+        lstore(0, R0);
+    }
+    __syncthreads();
+    for (int patch = pbeg; patch < pend; ++patch) {
+        if (patch + 1 < pend) gload(patch + 1, R0);
+        compute(0);
+        __syncthreads();  // every wave is done reading this block
+        if (patch + 1 < pend) lstore(0, R0);
+        __syncthreads();
+    }
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + r;
+    if (ci < p.cin_total) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + kx) * w_rows) * p.cin_total;
+#pragma unroll
+            for (int c = 0; c < COT; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = co0 + 32 * c + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[kx][c][j];
+                }
+        }
+    }
+}
+
 // 64 x 64 channels per workgroup, staged by LDS-DMA (bf16).  The 2x2-tile form above needs 192 accumulator registers per
 // wave, so one workgroup fits a CU and nothing overlaps the global-load issue of the next patch.  Here a patch (16 KB gout +
 // 26 KB halo) arrives as 42 global_load_lds_dwordx4 pieces (16 pixels x 64 B of one channel plane = 1 KiB, written
@@ -2561,6 +2726,23 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
     bool dense = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
     for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;  // canonical forward order
+    if (p.variant == 5) {  // stride-2 3x3 (bf16): parity-plane halo kernel
+        bool ok = p.dtype == FALNET_BF16 && p.ntaps == 9 && p.isy == 2 && p.isx == 2 && p.TW >= 16 && p.TH == (p.IH + 1) / 2 && p.TW == (p.IW + 1) / 2;
+        for (int t = 0; t < p.ntaps && ok; ++t) ok = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;
+        for (int s = 0; s < p.nsrc && ok; ++s) ok = p.src[s].C % 32 == 0 && ((p.src[s].H == p.IH && p.src[s].W == p.IW) || (p.src[s].sy == 0 && p.src[s].sx == 0));
+        FALNET_CHECK_ARG(ok, "wgrad: variant 5 needs a bf16 3x3 stride-2 pad-1 launch with sources at the input size");
+        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
+        const int npatch = p.B * tiles_x * tiles_y;
+        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
+        if (w_rows % 64 == 0) {
+            const dim3 grid(p.cin_total / 32, w_rows / 64, p.nsplit);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<2>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+        } else {
+            const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+        }
+        FALNET_RETURN_LAUNCH();
+    }
     if (dense) {
         const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
         const int npatch = p.B * tiles_x * tiles_y;

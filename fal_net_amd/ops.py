@@ -340,7 +340,12 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
     big = _wgrad_big(dtype, dense, pc.cin_pad, pad_c(gC))
     co2 = not big and _wgrad_co2(dtype, dense, pc.cin_pad, pad_c(gC))
-    if dense:
+    s2 = _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs)
+    if s2:
+        tiles = (pc.cin_pad // 32) * (pad_c(gC) // (64 if pad_c(gC) % 64 == 0 else 32))
+        npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+        nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
+    elif dense:
         tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
         npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
         nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
@@ -351,7 +356,7 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     d.nsplit = nsplit
     d.partial = ws.data_ptr()
     d.dtype = L.dtype_code(dtype)
-    d.variant = 2 if big else 3 if co2 else 0
+    d.variant = 5 if s2 else 2 if big else 3 if co2 else 0
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
     c0_real, c0_pad = pc.group_channels()
@@ -392,6 +397,14 @@ def _wgrad_big(dtype, dense, cin_pad, cout_pad):
             and os.environ.get("FALNET_WGRAD_BIG", "0") == "1")
 
 
+def _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
+    """Parity-plane halo kernel for 3x3 stride-2 weight gradients (falnet_wgrad variant 5): bf16, canonical taps, sources at
+    the input size (or per-sample constants)."""
+    return (dtype == torch.bfloat16 and len(taps) == 9 and stride_in == 2 and TW >= 32 and TH == (IH + 1) // 2 and TW == (IW + 1) // 2
+            and all((s.H == IH and s.W == IW) or (s.sy == 0 and s.sx == 0) for s in srcs)
+            and os.environ.get("FALNET_WGRAD_S2", "1") == "1")
+
+
 def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
     """32 (cin) x 64 (cout) channels per workgroup (falnet_wgrad variant 3): one gout fragment pair feeds twice the MFMAs
     (1.7 instead of 2.7 transposed LDS reads per MFMA).  In isolation -17 % on 64 -> 64 channel layers and -4 % on 128 -> 128;
@@ -430,7 +443,12 @@ class WgradBatch:
         dense = len(taps) == 9 and stride_in == 1 and TW >= 16
         big = _wgrad_big(self.dtype, dense, pc.cin_pad, pad_c(gC))
         co2 = not big and _wgrad_co2(self.dtype, dense, pc.cin_pad, pad_c(gC))
-        if dense:
+        s2 = _wgrad_s2(self.dtype, taps, stride_in, TH, TW, IH, IW, srcs)
+        if s2:
+            tiles = (pc.cin_pad // 32) * (pad_c(gC) // (64 if pad_c(gC) % 64 == 0 else 32))
+            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+            nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
+        elif dense:
             tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
             npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
             nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
@@ -438,7 +456,7 @@ class WgradBatch:
             tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
             nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
         nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
-        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (2 if big else 3 if co2 else 0)
+        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (5 if s2 else 2 if big else 3 if co2 else 0)
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
         dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
@@ -451,7 +469,7 @@ class WgradBatch:
         if grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
-        sym = ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
+        sym = f"_Z18wgrad3x3_s2_kernelILi{2 if pad_c(gC) % 64 == 0 else 1}EEv14falnet_wgrad_tiiii" if s2 else ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
             if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 

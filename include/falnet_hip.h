@@ -143,7 +143,7 @@ typedef struct {
     int32_t variant;           /* 0 heuristic (halo-patch kernel, 32x32 channels per workgroup, when dense 3x3 stride 1),
                                   1 force the per-tap kernel, 2 halo-patch with 64x64 channels per workgroup (bf16, channel
                                   counts multiples of 64, LDS-DMA staged), 3 / 4 halo-patch with 32x64 / 64x32 (cin x cout)
-                                  channels per workgroup (bf16) */
+                                  channels per workgroup (bf16), 5 parity-plane halo kernel for 3x3 stride-2 launches (bf16) */
 } falnet_wgrad_t;
 int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p);
 int falnet_wgrad(const falnet_wgrad_t* p, void* stream);

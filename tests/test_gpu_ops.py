@@ -64,6 +64,9 @@ CONV_CASES = [
     (1, [128, 256], 256, 4, 8, 1, 3, True, L.ACT_ELU, False),   # bottleneck-like, M < tile
     (2, [64], 64, 8, 8, 1, 3, True, L.ACT_RELU, False),         # VGG style
     (1, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False),        # 1x1
+    (2, [32, 32], 64, 24, 71, 2, 3, True, L.ACT_ELU, False),    # stride 2, output wide enough for the parity-plane wgrad (odd W)
+    (1, [64], 128, 16, 64, 2, 3, True, L.ACT_ELU, False),       # stride 2, even sizes, Cout 128
+    (1, [128], 96, 9, 66, 2, 3, False, L.ACT_ELU, False),       # stride 2, odd H, Cout 96 (32-wide cout tiles)
 ]
 # W >= 32, dense 3x3 stride 1 -> the halo-patch kernel (conv.hip: conv3x3_patch_kernel), every instantiation
 PATCH_CASES = [
@@ -292,7 +295,7 @@ def test_conv_fused_upsample(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", CONV_CASES[:7] + PATCH_CASES[:5] + PATCH_CASES[7:])
+@pytest.mark.parametrize("case", CONV_CASES[:7] + CONV_CASES[8:] + PATCH_CASES[:5] + PATCH_CASES[7:])
 def test_conv_backward(case, dtype):
     """dgrad (per concat group, stride 1 and the 4 stride-2 parity launches) and wgrad/bias-grad vs autograd."""
     B, groups, Cout, H, W, stride, k, bias, act, res = case
