@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
 // as they are, no packing), two bf16 MFMAs (sixteen f32 ones) per 32x32 output tile: purely output-write bound.
 #define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, next patch prefetched behind the epilogue
 template <typename T, int NT>
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                                   const falnet_conv_t p, int groups_x, int tiles_y) {
     constexpr int PH = PT_TH + 2, PW = PT_PW, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
     __shared__ __attribute__((aligned(16))) float patch[NEL];                       // [3][PH][PW] f32
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #define WS2_RH (2 * WP_TH + 1)   // region rows
 #define WS2_RW (2 * WP_TW + 1)   // region columns
 template <int COT>
-__global__ __launch_bounds__(WP_THREADS) void wgrad3x3_s2_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+__global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
                                                                  int patches_per_split) {
     typedef bf16_t T;
     constexpr int EPS = 8, SEGS = 4, PITCH = 64;
