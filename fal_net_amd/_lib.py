@@ -44,7 +44,7 @@ class Wgrad(C.Structure):
                 ("gout", C.c_void_p), ("gC", C.c_int32), ("ntaps", C.c_int32),
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("isy", C.c_int32), ("isx", C.c_int32),
                 ("B", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("cin_total", C.c_int32),
-                ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32)]
+                ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32), ("bias_grad", C.c_void_p)]
 
 
 class ReduceDesc(C.Structure):

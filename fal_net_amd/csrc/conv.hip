@@ -1524,6 +1524,47 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_
 
 #define WP_THREADS 192  // three waves: wave w owns the tap row dy = w-1 (taps 3w..3w+2)
 
+// Bias gradient from the gout tile a weight-gradient workgroup has in LDS ([plane][pixel][32 channels], zero-filled outside the
+// image): every thread owns one 16-B channel segment and strides over the tile's pixels, accumulating in registers across
+// all patches of the workgroup; bias_grad_flush sums the pixel groups through LDS and issues one atomic per channel.
+template <typename T, int COT, int NTHR>
+__device__ __forceinline__ void bias_grad_accumulate(const char* G, int tid, float (&bsum)[16 / (int)sizeof(T)]) {
+    constexpr int EPS = 16 / (int)sizeof(T), SEGS = 32 / EPS, NSEG = SEGS * COT, PSTEP = NTHR / NSEG;
+    static_assert(NTHR % NSEG == 0, "threads map evenly onto channel segments");
+    constexpr int NPIXT = WP_TH * WP_TW, G_PLANE = NPIXT * 32 * (int)sizeof(T);
+    const int sg = tid % NSEG, pg = tid / NSEG;
+    const char* base = G + (sg / SEGS) * G_PLANE + (sg % SEGS) * 16;
+    for (int px = pg; px < NPIXT; px += PSTEP) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + px * 32 * (int)sizeof(T));
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned w = (&v.x)[i];
+                bsum[2 * i] += __uint_as_float(w << 16);
+                bsum[2 * i + 1] += __uint_as_float(w & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bsum[i] += __uint_as_float((&v.x)[i]);
+        }
+    }
+}
+template <typename T, int COT, int NTHR>
+__device__ __forceinline__ void bias_grad_flush(float* lds_f /* >= NTHR * EPS floats, all waves past their last LDS use */, int tid,
+                                                const float (&bsum)[16 / (int)sizeof(T)], float* db, int co0, int gC) {
+    constexpr int EPS = 16 / (int)sizeof(T), SEGS = 32 / EPS, NSEG = SEGS * COT, PSTEP = NTHR / NSEG;
+#pragma unroll
+    for (int i = 0; i < EPS; ++i) lds_f[tid * EPS + i] = bsum[i];
+    __syncthreads();
+    if (tid < NSEG * EPS) {
+        const int sg = tid / EPS, i = tid % EPS;
+        float t = 0.f;
+        for (int pg = 0; pg < PSTEP; ++pg) t += lds_f[(pg * NSEG + sg) * EPS + i];
+        const int co = co0 + (sg / SEGS) * 32 + (sg % SEGS) * EPS + i;
+        if (co < gC) atomicAdd(db + co, t);
+    }
+}
+
 // CIT x COT = 32-channel tiles per workgroup along cin / cout (1x1, or 2x2 for bf16 layers with >= 64 channels on both
 // sides): every wave then owns 3 taps x CIT x COT accumulator tiles, and one A (gout) fragment feeds 3*CIT MFMAs, one B
 // (input) fragment COT of them -- half the LDS reads and half the global bytes per MFMA of the 1x1 form, whose ~2.7
@@ -1751,13 +1792,19 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
         lstore(0, R0);
     }
     __syncthreads();
+    const bool do_bias = p.bias_grad != nullptr && blockIdx.x == 0;  // one cin tile per cout slice sums the bias gradient
+    float bsum[EPS];
+#pragma unroll
+    for (int i = 0; i < EPS; ++i) bsum[i] = 0.f;
     for (int patch = pbeg; patch < pend; ++patch) {
         const int cur = (patch - pbeg) & 1;
         if (patch + 1 < pend) gload(patch + 1, R0);
         compute(cur);
+        if (do_bias) bias_grad_accumulate<T, COT, WP_THREADS>(Gbuf(cur), tid, bsum);
         if (patch + 1 < pend) lstore(cur ^ 1, R0);
         __syncthreads();
     }
+    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.gC);
     // every wave owns its three taps: no cross-wave reduction
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -1920,13 +1967,19 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
         lstore(0, R0);
     }
     __syncthreads();
+    const bool do_bias = p.bias_grad != nullptr && blockIdx.x == 0;
+    float bsum[EPS];
+#pragma unroll
+    for (int i = 0; i < EPS; ++i) bsum[i] = 0.f;
     for (int patch = pbeg; patch < pend; ++patch) {
         if (patch + 1 < pend) gload(patch + 1, R0);
         compute(0);
+        if (do_bias) bias_grad_accumulate<T, COT, WP_THREADS>(Gbuf(0), tid, bsum);
         __syncthreads();  // every wave is done reading this block
         if (patch + 1 < pend) lstore(0, R0);
         __syncthreads();
     }
+    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.gC);
     const int r = lane & 31, h = lane >> 5;
     const int ci = ci0 + r;
     if (ci < p.cin_total) {

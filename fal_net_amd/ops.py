@@ -369,22 +369,29 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     def k_wgrad(accumulate=0, _keep=keep):
         L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
 
+    fused_bias = grad_b is not None and (s2 or (dense and not big)) and _FUSED_BIAS
+    if fused_bias:
+        d.bias_grad = grad_b.data_ptr()
+
     def k_reduce(accumulate=0):
         st = L.stream_ptr()
         L.check(lib.falnet_wgrad_reduce(*red_args, int(accumulate), st), name + " reduce")
-        if grad_b is not None:
+        if grad_b is not None and not fused_bias:
             L.check(lib.falnet_bias_grad(L.ptr(gout), npix, gC, pc.cout, L.ptr(grad_b), int(accumulate),
                                          L.dtype_code(dtype), st), name + " bias")
     t_wgrad = _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, k_wgrad)
     t_reduce = _timed("wgrad_reduce+bias_grad", 0, 0, k_reduce)
 
     def call(accumulate=0):
+        if fused_bias and not accumulate:
+            grad_b.zero_()  # the fused bias gradient ADDS (atomics), like the batched plan path into its pre-zeroed buffer
         t_wgrad(accumulate)
         t_reduce(accumulate)
     call.desc = d
     return call
 
 
+_FUSED_BIAS = os.environ.get("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients inside the halo weight-gradient kernels
 _WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
 
 
@@ -466,7 +473,10 @@ class WgradBatch:
         c0_real, c0_pad = pc.group_channels()
         self.items.append(dict(bucket=bucket, d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
-        if grad_b is not None:
+        fused_bias = grad_b is not None and (s2 or (dense and not big)) and _FUSED_BIAS
+        if fused_bias:
+            d.bias_grad = grad_b.data_ptr()  # summed from the gout tiles the halo kernel stages anyway
+        elif grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
         sym = f"_Z18wgrad3x3_s2_kernelILi{2 if pad_c(gC) % 64 == 0 else 1}EEv14falnet_wgrad_tiiii" if s2 else ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
