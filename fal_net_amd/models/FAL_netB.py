@@ -284,6 +284,11 @@ class FalnetPlan:
             self._conv_fwd(pcs[rname + ".conv1"], [ops.nhwc_src(a[i])], hh, ww, h_[i], L.ACT_ELU, name=rname + ".conv1")
             self._conv_fwd(pcs[rname + ".conv2"], [ops.nhwc_src(h_[i])], hh, ww, c[i], L.ACT_ELU, addend=a[i],
                            name=rname + ".conv2")
+            if i == int(os.environ.get("FALNET_MID_HOOK_LEVEL", "2")):
+                # from here on (levels 3-6 of the encoder, 6-3 of the decoder) the launches are small and leave most CUs
+                # idle: the trainer's mid-forward hook starts independent heavy work (the label's VGG features) HERE, on
+                # another stream, instead of beside the chip-filling level-0..2 layers
+                self._mid_index = len(self.fwd)
         # ---- decoder ----
         d, ic = {}, {7: c[6]}
         for lvl in range(6, 0, -1):
@@ -458,7 +463,11 @@ class FalnetPlan:
         if repack and not self.model._packed_is_fresh():
             for call in self.pack:
                 call()
-        for call in self.fwd:
+        hook, mid = getattr(self.model, "_mid_forward_hook", None), getattr(self, "_mid_index", -1)
+        for i, call in enumerate(self.fwd):
+            if hook is not None and i == mid:
+                self.model._mid_forward_hook = None  # one shot
+                hook()
             call()
         if ret_pan or ret_subocc:
             self.head_full()

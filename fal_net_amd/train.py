@@ -124,9 +124,19 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
     enable_overlapped_allreduce(model)
     W = left.shape[3]
     min_disp = max_disp * min_disp_arg / max_disp_arg  # :237
-    join_vgg = vgg_label_async(right) if a_p > 0 else None  # :241-244, overlapped with the model forward
+    # :241-244 label features, overlapped with the model forward: started from the plan's mid-forward hook, i.e. when the
+    # main stream reaches the small deep layers (beside the chip-filling shallow ones the overlap would only time-slice)
+    joins = []
+    if a_p > 0:
+        if _os.environ.get("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
+            model._mid_forward_hook = lambda: joins.append(vgg_label_async(right))
+        else:
+            joins.append(vgg_label_async(right))
     rpan, ldisp = model(left, min_disp, max_disp, ret_disp=True, ret_pan=True, ret_subocc=False)  # :238
-    vgg_right = join_vgg() if join_vgg else None
+    if a_p > 0 and not joins:  # the plan did not reach the hook (no plan replay on this path): start it now
+        model._mid_forward_hook = None
+        joins.append(vgg_label_async(right))
+    vgg_right = joins[0]() if joins else None
     rec_loss = rec_loss_fnc(1, rpan, right, vgg_right, a_p)  # :248
     sm_loss = 0
     if a_sm > 0:
