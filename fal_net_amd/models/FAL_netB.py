@@ -207,7 +207,8 @@ class FalnetPlan:
                                pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
                                bucket=self._bucket)
         if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
-            self.bwd_body.append(call)
+            self._main_tail = getattr(self, "_main_tail", [])
+            self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)
         else:
             self._side_call(call)
 
@@ -415,6 +416,7 @@ class FalnetPlan:
             self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
             if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                 self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
+        self.bwd_body.extend(getattr(self, "_main_tail", []))
         self._finish.append((3, len(self.bwd_body)))
         # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
         # trainer's hook (asynchronous all-reduce of that range of the flat gradient buffer)
