@@ -58,26 +58,81 @@ __global__ __launch_bounds__(RED_THREADS) void l1_bwd_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ perceptual MSE on NHWC (loss_functions.py:61-65)
-template <typename T>
+__device__ __forceinline__ void diff8(const bf16_t* a, const bf16_t* b, float (&d)[8]) {
+    const uint4 x = *reinterpret_cast<const uint4*>(a), y = *reinterpret_cast<const uint4*>(b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = (&x.x)[i], v = (&y.x)[i];
+        d[2 * i] = __uint_as_float(u << 16) - __uint_as_float(v << 16);
+        d[2 * i + 1] = __uint_as_float(u & 0xffff0000u) - __uint_as_float(v & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void diff8(const float* a, const float* b, float (&d)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4 x = reinterpret_cast<const float4*>(a)[h], y = reinterpret_cast<const float4*>(b)[h];
+        d[4 * h] = x.x - y.x;
+        d[4 * h + 1] = x.y - y.y;
+        d[4 * h + 2] = x.z - y.z;
+        d[4 * h + 3] = x.w - y.w;
+    }
+}
+__device__ __forceinline__ void put8(bf16_t* p, const float (&v)[8]) {
+    uint4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
+        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = q;
+}
+__device__ __forceinline__ void put8(float* p, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// 8 elements (16 B bf16 / 32 B f32) per thread and iteration when `total` and the pointers allow (VEC), else one
+template <typename T, bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                               int64_t total, float scale, float* out) {
     __shared__ float red[16];
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const float d = to_f32(a[i]) - to_f32(b[i]);
-        acc += d * d;
+    if constexpr (VEC) {
+        const int64_t n8 = total >> 3;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+            float d[8];
+            diff8(a + 8 * i, b + 8 * i, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += d[j] * d[j];
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const float d = to_f32(a[i]) - to_f32(b[i]);
+            acc += d * d;
+        }
     }
     const float s = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(out, s * scale);
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void mse_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                               int64_t total, float scale,
                                                               const float* __restrict__ gscale, T* __restrict__ ga) {
     const float gs = 2.f * scale * (gscale ? gscale[0] : 1.f);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        ga[i] = from_f32<T>(gs * (to_f32(a[i]) - to_f32(b[i])));
+    if constexpr (VEC) {
+        const int64_t n8 = total >> 3;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+            float d[8];
+            diff8(a + 8 * i, b + 8 * i, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] *= gs;
+            put8(ga + 8 * i, d);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+            ga[i] = from_f32<T>(gs * (to_f32(a[i]) - to_f32(b[i])));
+    }
 }
 
 // ------------------------------------------------------------------ edge-aware smoothness (loss_functions.py:70-101)
@@ -277,12 +332,12 @@ extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cp
     FALNET_CHECK_ARG(a && b && out && npix > 0 && Cpad > 0, "mse_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = npix * Cpad;
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(mse_fwd_kernel<bf16_t>, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)a, (const bf16_t*)b, total, scale, out);
-    else
-        hipLaunchKernelGGL(mse_fwd_kernel<float>, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                           (const float*)a, (const float*)b, total, scale, out);
+    const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 31) == 0);
+    const int grid = red_grid(vec ? total / 8 : total);
+#define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out)
+    if (dtype == FALNET_BF16) { if (vec) MSE_FWD(bf16_t, true); else MSE_FWD(bf16_t, false); }
+    else { if (vec) MSE_FWD(float, true); else MSE_FWD(float, false); }
+#undef MSE_FWD
     FALNET_RETURN_LAUNCH();
 }
 
@@ -290,12 +345,12 @@ extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cp
                               void* ga, int dtype, void* stream) {
     FALNET_CHECK_ARG(a && b && ga && npix > 0 && Cpad > 0, "mse_bwd: bad argument");
     const int64_t total = npix * Cpad;
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(mse_bwd_kernel<bf16_t>, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)a, (const bf16_t*)b, total, scale, gscale, (bf16_t*)ga);
-    else
-        hipLaunchKernelGGL(mse_bwd_kernel<float>, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream,
-                           (const float*)a, (const float*)b, total, scale, gscale, (float*)ga);
+    const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
+    const int grid = red_grid(vec ? total / 8 : total) * 4;
+#define MSE_BWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_bwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, gscale, (T*)ga)
+    if (dtype == FALNET_BF16) { if (vec) MSE_BWD(bf16_t, true); else MSE_BWD(bf16_t, false); }
+    else { if (vec) MSE_BWD(float, true); else MSE_BWD(float, false); }
+#undef MSE_BWD
     FALNET_RETURN_LAUNCH();
 }
 
