@@ -164,15 +164,31 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_lds_kernel(
         m0[q] = mw[q] = -INFINITY;
         z0[q] = dacc[q] = zw[q] = p0[q] = p1[q] = p2[q] = 0.f;
     }
+    // register prefetch of the next chunk's plane rows (vec4 path): the global round trip of chunk n0+CH overlaps the
+    // softmax arithmetic of chunk n0 instead of sitting between two barriers
+    constexpr int PF = (CH * PPT + 3) / 4;  // float4 per thread: CH rows of W <= 256*PPT floats over 256 threads
+    float4 pf[PF];
+    const int w4 = W >> 2;
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = threadIdx.x + u * HEAD_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < CH * w4) {
+                const int j = i / w4, q = i % w4;
+                if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q];
+            }
+            pf[u] = v;
+        }
+    };
+    if (vec4) fetch(0);
     for (int n0 = 0; n0 < N; n0 += CH) {
         __syncthreads();                                              // previous chunk fully consumed (and tab/lrow ready)
         if (vec4) {
-            const int w4 = W >> 2;
-            for (int i = threadIdx.x; i < CH * w4; i += blockDim.x) {
-                const int j = i / w4, q = i % w4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q];
-                *reinterpret_cast<float4*>(prow + j * WP + 4 * q) = v;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int i = threadIdx.x + u * HEAD_THREADS;
+                if (i < CH * w4) *reinterpret_cast<float4*>(prow + (i / w4) * WP + 4 * (i % w4)) = pf[u];
             }
         } else {
             for (int i = threadIdx.x; i < CH * W; i += blockDim.x) {
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_fwd_lds_kernel(
             }
         }
         __syncthreads();
+        if (vec4 && n0 + CH < N) fetch(n0 + CH);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int x = threadIdx.x + q * HEAD_THREADS;
@@ -476,16 +493,31 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
             }
         }
     }
+    // register prefetch of the next chunk's plane rows (vec4 path): its global round trip overlaps this chunk's arithmetic
+    constexpr int PF = (CH * PPT + 3) / 4;
+    float4 pf[PF];
+    const int w4 = W >> 2;
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = threadIdx.x + u * HEAD_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < CH * w4) {
+                const int j = i / w4, q4 = i % w4;
+                if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q4];
+            }
+            pf[u] = v;
+        }
+    };
+    if (vec4) fetch(0);
     for (int n0 = 0; n0 < cpad; n0 += CH) {
         __syncthreads();  // previous chunk fully consumed (and tab / rows ready)
         if (n0 < N) {
             if (vec4) {
-                const int w4 = W >> 2;
-                for (int i = threadIdx.x; i < CH * w4; i += blockDim.x) {
-                    const int j = i / w4, q4 = i % w4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (n0 + j < N) v = reinterpret_cast<const float4*>(Lrow + (int64_t)(n0 + j) * HW)[q4];
-                    *reinterpret_cast<float4*>(prow + j * PP + 4 + 4 * q4) = v;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int i = threadIdx.x + u * HEAD_THREADS;
+                    if (i < CH * w4) *reinterpret_cast<float4*>(prow + (i / w4) * PP + 4 + 4 * (i % w4)) = pf[u];
                 }
             } else {
                 for (int i = threadIdx.x; i < CH * W; i += blockDim.x) {
@@ -495,6 +527,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
             }
         }
         __syncthreads();
+        if (vec4 && n0 + CH < N) fetch(n0 + CH);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int x = threadIdx.x + q * HEAD_THREADS;
