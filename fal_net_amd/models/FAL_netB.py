@@ -345,7 +345,14 @@ class FalnetPlan:
         # bucket's share of the step's all-reduce while backward continues.
         self._bucket = 0
         self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
-        self._side_call(self._x0_convert)
+        # NHWC copy of the image for conv0's weight gradient: converted on the side stream; that weight gradient runs on the MAIN
+        # stream at the tail (tail balancing), so it waits for this event
+        self._x0_event = torch.cuda.Event()
+
+        def x0_convert_and_mark():
+            self._x0_convert()
+            self._x0_event.record()  # on the stream the conversion was launched on
+        self._side_call(x0_convert_and_mark)
         if compose:
             g_dlog = G0  # the composed conv's output gradient IS the head's gradient
         else:
@@ -413,6 +420,9 @@ class FalnetPlan:
             g_a = self._act(f"g_a{i}", hh, ww, ch)
             self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
             srcs, ih, iw = self._enc_srcs[i]
+            if tail:
+                self._main_tail = getattr(self, "_main_tail", [])
+                self._main_tail.append(lambda: torch.cuda.current_stream().wait_event(self._x0_event))
             self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
             if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                 self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
