@@ -90,14 +90,12 @@ class _VggPlan:
             else:
                 pc, x, y, h, w = entry
                 if x is x0:
-                    # first conv: data gradient wrt the 3-channel image
-                    gin = torch.empty(B, h, w, ops.pad_c(3), dtype=dtype, device=device)
-                    self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
-                                                  ops.pad_c(3), 1, B, h, w, gin, h, w, ops.pad_c(3), ops.pad_c(3), name="vgg dgrad0",
-                                                  flops=2 * B * h * w * pc.cout * pc.cin * 9))
+                    # first conv: data gradient wrt the 3-channel image, written straight into the planar f32 gradient the
+                    # caller gets (the halo kernels' epilogue has the pixels on the lanes: no NHWC intermediate, no conversion)
                     self.g_in = torch.empty(B, 3, H, W, dtype=torch.float32, device=device)
-                    self.bwd.append(ops.simple_call("falnet_nhwc_to_nchw", L.ptr(gin), L.ptr(self.g_in), B, 3, H, W, ops.pad_c(3), code))
-                    self.keep.append(gin)
+                    self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
+                                          ops.pad_c(3), 1, B, h, w, self.g_in, h, w, 3, 0, out_layout=L.OUT_PLANAR_F32, name="vgg dgrad0",
+                                          flops=2 * B * h * w * pc.cout * pc.cin * 9))
                 else:
                     # x is the ReLU output of the previous conv (or a pooled map: relu' = 1 where > 0 holds there too,
                     # but a pooled map's gradient must NOT be masked -> only mask when x came from a conv)
