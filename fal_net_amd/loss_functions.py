@@ -25,6 +25,9 @@ _MEAN = (0.411, 0.432, 0.45)
 _SLICES = ((0, 2), (5, 7), (10, 12, 14, 16))
 
 
+_GOUT_OF = {}  # data_ptr of a grad-plan's output map -> that plan's gradient buffer for it
+
+
 class _VggPlan:
     """Static launch plan of VGG19 features[0:19] forward + data-gradient for one (B,H,W,dtype)."""
 
@@ -52,7 +55,8 @@ class _VggPlan:
                 args = (dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, h, w)
                 fused = False
                 if cur is x0:
-                    self.fwd.append(ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)"))
+                    self.c3_call = ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)")
+                    self.fwd.append(self.c3_call)
                 elif last and os.environ.get("FALNET_FUSED_POOL", "1") == "1":
                     try:  # 2x2 max pool in the conv epilogue: the full-resolution map is not re-read (nor written at all for labels)
                         self.fwd.append(_conv(*args, y, h, w, pc.cout, pc.cout, pool_out=pooled, **kw))
@@ -74,6 +78,8 @@ class _VggPlan:
             return
         # ---- backward: gradients of the three pooled outputs -> gradient of the planar f32 input ----
         self.gouts = [torch.empty_like(o) for o in self.outs]
+        for o, g in zip(self.outs, self.gouts):
+            _GOUT_OF[o.data_ptr()] = g  # lets the perceptual loss write d loss / d feature straight into the plan
         g_next = None  # gradient wrt `cur` of the step being undone (post-pool tensor of the slice below)
         slice_i = len(self.outs) - 1
         for entry in reversed(acts):
@@ -119,7 +125,7 @@ def _axpy_call(dst, src):
 class _VggFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, plan, x):
-        plan.x_in.copy_(x)
+        plan.c3_call.set_input(x)  # the first conv reads the caller's image in place (it is only read during this forward)
         for c in plan.fwd:
             c()
         ctx.plan, ctx.owner = plan, owner
@@ -132,7 +138,7 @@ class _VggFunction(torch.autograd.Function):
         for buf, g in zip(plan.gouts, gouts):
             if g is None:
                 buf.zero_()
-            else:
+            elif g.data_ptr() != buf.data_ptr():  # _PerceptualMse writes its gradient straight into this buffer
                 buf.copy_(g.permute(0, 2, 3, 1))
         for c in plan.bwd:
             c()
@@ -204,7 +210,7 @@ class Vgg19_pc(nn.Module):
         if need_grad:
             return _VggFunction.apply(self, plan, xs)
         with torch.no_grad():
-            plan.x_in.copy_(xs)
+            plan.c3_call.set_input(xs)
             for c in plan.fwd:
                 c()
             return tuple((o if borrow else o.clone()).permute(0, 3, 1, 2) for o in plan.outs)
@@ -319,7 +325,9 @@ class _PerceptualMse(torch.autograd.Function):
         grads = []
         for i in range(ctx.n):
             an, bn = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
-            ga = torch.empty_like(an)
+            ga = _GOUT_OF.get(an.data_ptr())  # `an` is a VGG plan's output: write into the plan's own gradient buffer
+            if ga is None or ga.shape != an.shape or ga.dtype != an.dtype:
+                ga = torch.empty_like(an)
             B, H, W, Cc = an.shape
             L.check(L.lib().falnet_mse_bwd(L.ptr(an), L.ptr(bn), B * H * W, Cc, ctx.scales[i], L.ptr(gs), L.ptr(ga),
                                            L.dtype_code(an.dtype), L.stream_ptr()), "mse_bwd")

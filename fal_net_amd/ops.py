@@ -115,16 +115,24 @@ class PackedConv:
 
 
 def conv_c3_call(dtype, x_planar, pc, out, act, name="conv0(c3)"):
-    """First-layer launch (falnet_conv3x3_c3): planar f32 image + f32 OIHW master weights -> NHWC activation."""
+    """First-layer launch (falnet_conv3x3_c3): planar f32 image + f32 OIHW master weights -> NHWC activation.
+    `call.set_input(t)` re-points the launch at another contiguous f32 image of the same shape (no staging copy)."""
     lib = L.lib()
     B, C, H, W = x_planar.shape
     assert C == 3 and pc.cin == 3 and pc.cout in (32, 64) and out.shape == (B, H, W, pc.cout)
-    args = (L.ptr(x_planar), L.ptr(pc.weight), L.ptr(pc.bias), L.ptr(out), B, H, W, pc.cout, act, L.dtype_code(dtype))
+    tail = (L.ptr(pc.weight), L.ptr(pc.bias), L.ptr(out), B, H, W, pc.cout, act, L.dtype_code(dtype))
     tn, nt = ("DF16b" if dtype == torch.bfloat16 else "f"), pc.cout // 32
+    cur = [x_planar]
 
-    def launch(_keep=(x_planar, pc, out)):
-        L.check(lib.falnet_conv3x3_c3(*args, L.stream_ptr()), name)
-    return _timed(f"_Z17conv3x3_c3_kernelI{tn}Li{nt}EEvPKfS1_13falnet_conv_tii", 2 * B * H * W * pc.cout * 27, 0, launch, name)
+    def launch(_keep=(pc, out)):
+        L.check(lib.falnet_conv3x3_c3(L.ptr(cur[0]), *tail, L.stream_ptr()), name)
+    call = _timed(f"_Z17conv3x3_c3_kernelI{tn}Li{nt}EEvPKfS1_13falnet_conv_tii", 2 * B * H * W * pc.cout * 27, 0, launch, name)
+
+    def set_input(t):
+        assert t.shape == x_planar.shape and t.dtype == torch.float32 and t.is_contiguous() and t.device == x_planar.device
+        cur[0] = t
+    call.set_input = set_input
+    return call
 
 
 def pack_all_call(pcs, dtype, device):
