@@ -1997,6 +1997,133 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
     }
 }
 
+// First layer (Cin = 3) weight gradient, bf16 gout: dW[co][c][tap] = sum_p gout[p][co] * x[c][p + tap] straight from the PLANAR f32
+// image (variant 6) -- the generic kernels need an NHWC copy of the image padded to 32 channels (a 67 MB conversion per step
+// for 3 real channels).  GEMM view: D[co 32][k 32] += A[co][p] B[p][k], k = c*9 + tap (27 used): A fragments are the dense
+// kernel's transposed gout reads, B fragments eight consecutive image columns (f32 -> bf16) of the lane's (c, tap) row in
+// the LDS patch.  Four waves split the eight 16-position K steps of a 4x32 block; partial sums are reduced through LDS and
+// written as a standard [tap][co][cin_pad] slab (the batched reduce un-pads it).
+#define WC3_THREADS 256
+__global__ __launch_bounds__(WC3_THREADS) void wgrad3x3_c3_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
+                                                                  int patches_per_split) {
+    typedef bf16_t T;
+    constexpr int PITCH = 64, SEGS = 4;
+    constexpr int G_BYTES = WP_TH * WP_TW * PITCH, X_FLOATS = 3 * (WP_TH + 2) * WP_PW;
+    constexpr int G_LOADS = WP_TH * WP_TW * SEGS, G_SLOTS = (G_LOADS + WC3_THREADS - 1) / WC3_THREADS;
+    constexpr int X_SLOTS = (X_FLOATS + WC3_THREADS - 1) / WC3_THREADS;
+    constexpr int BUF_BYTES = G_BYTES + ((X_FLOATS * 4 + 15) / 16) * 16;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF_BYTES > 4 * 32 * 33 * 4 ? 2 * BUF_BYTES : 4 * 32 * 33 * 4];
+    auto Gbuf = [&](int b) -> char* { return lds + b * BUF_BYTES; };
+    auto Xbuf = [&](int b) -> float* { return reinterpret_cast<float*>(lds + b * BUF_BYTES + G_BYTES); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.z;
+    const float* x = reinterpret_cast<const float*>(p.src[0].ptr);
+    const int64_t HW = (int64_t)p.IH * p.IW;
+    const int npatch = p.B * tiles_x * tiles_y;
+    const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
+
+    struct Regs { uint4 g[G_SLOTS]; float xv[X_SLOTS]; };
+    auto gload = [&](int patch, Regs& R) {
+        int q = patch;
+        const int tix = q % tiles_x;
+        q /= tiles_x;
+        const int tiy = q % tiles_y;
+        const int b = q / tiles_y;
+        const int y0 = tiy * WP_TH, x0 = tix * WP_TW;
+        const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC;
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WC3_THREADS;
+            const int seg = idx % SEGS, pix = idx / SEGS;
+            const int y = y0 + pix / WP_TW, xx = x0 + pix % WP_TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < G_LOADS && y < p.TH && xx < p.TW) v = *reinterpret_cast<const uint4*>(gbase + ((int64_t)y * p.TW + xx) * p.gC + seg * 8);
+            R.g[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < X_SLOTS; ++u) {
+            const int idx = tid + u * WC3_THREADS;
+            const int c = idx / ((WP_TH + 2) * WP_PW), rem = idx % ((WP_TH + 2) * WP_PW);
+            const int vy = y0 - 1 + rem / WP_PW, vx = x0 - 1 + rem % WP_PW;
+            R.xv[u] = (idx < X_FLOATS && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) ? x[((int64_t)b * 3 + c) * HW + (int64_t)vy * p.IW + vx] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf, const Regs& R) {
+#pragma unroll
+        for (int u = 0; u < G_SLOTS; ++u) {
+            const int idx = tid + u * WC3_THREADS;
+            if (idx < G_LOADS) *reinterpret_cast<uint4*>(Gbuf(buf) + idx * 16) = R.g[u];
+        }
+#pragma unroll
+        for (int u = 0; u < X_SLOTS; ++u) {
+            const int idx = tid + u * WC3_THREADS;
+            if (idx < X_FLOATS) Xbuf(buf)[idx] = R.xv[u];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q4 = i16 >> 2, pc = i16 & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+    const int lane_off = (kh * 8 + q4) * PITCH + (cb * 16 + pc * 4) * 2;
+    const int r = lane & 31, h = lane >> 5;
+    const bool kvalid = r < 27;
+    const int kc = r / 9, kt = r % 9;
+    const int koff = (kc * (WP_TH + 2) + kt / 3) * WP_PW + kt % 3;  // patch offset of this lane's (channel, tap)
+
+    const bool do_bias = p.bias_grad != nullptr;
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+    Regs R0;
+    if (pbeg < pend) {
+        gload(pbeg, R0);
+        lstore(0, R0);
+    }
+    __syncthreads();
+    for (int patch = pbeg; patch < pend; ++patch) {
+        const int cur = (patch - pbeg) & 1;
+        if (patch + 1 < pend) gload(patch + 1, R0);
+        const char* gl = Gbuf(cur) + lane_off;
+        const float* X = Xbuf(cur);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ks = wave * 2 + kk;  // 16-position K step: block row ks>>1, half ks&1
+            s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + ks * 16 * PITCH));
+            s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + ks * 16 * PITCH + 4 * PITCH));
+            const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            bf16x8 bv;
+            const float* xr = X + koff + (ks >> 1) * WP_PW + (ks & 1) * 16 + h * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = (bf16_t)(kvalid ? xr[j] : 0.f);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+        }
+        if (do_bias) bias_grad_accumulate<T, 1, WC3_THREADS>(Gbuf(cur), tid, bsum);
+        if (patch + 1 < pend) lstore(cur ^ 1, R0);
+        __syncthreads();
+    }
+    if (do_bias) {
+        bias_grad_flush<T, 1, WC3_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, 0, p.gC);
+        __syncthreads();
+    }
+    // sum the four waves' partial tiles through LDS ([wave][co][k], pitch 33), then one thread per (co, k)
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int co = (j & 3) + 8 * (j >> 2) + 4 * h;
+        red[(wave * 32 + co) * 33 + r] = acc[j];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 27; e += WC3_THREADS) {
+        const int co = e / 27, k = e % 27;
+        const float v = red[(0 * 32 + co) * 33 + k] + red[(1 * 32 + co) * 33 + k] + red[(2 * 32 + co) * 33 + k] + red[(3 * 32 + co) * 33 + k];
+        const int c = k / 9, t = k % 9;
+        if (co < w_rows) p.partial[(((int64_t)split * 9 + t) * w_rows + co) * p.cin_total + c] = v;
+    }
+}
+
 // 64 x 64 channels per workgroup, staged by LDS-DMA (bf16).  The 2x2-tile form above needs 192 accumulator registers per
 // wave, so one workgroup fits a CU and nothing overlaps the global-load issue of the next patch.  Here a patch (16 KB gout +
 // 26 KB halo) arrives as 42 global_load_lds_dwordx4 pieces (16 pixels x 64 B of one channel plane = 1 KiB, written
@@ -2768,17 +2895,31 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16, "wgrad: bad dtype %d", p.dtype);
     FALNET_CHECK_ARG(p.nsrc == 1 || p.nsrc == 2, "wgrad: nsrc=%d", p.nsrc);
     int ctot = 0;
-    for (int s = 0; s < p.nsrc; ++s) {
-        if (int r = check_src(p.src[s], 32, "wgrad")) return r;
-        ctot += p.src[s].C;
+    if (p.variant != 6) {  // (variant 6 reads a planar f32 3-channel image: its own checks below)
+        for (int s = 0; s < p.nsrc; ++s) {
+            if (int r = check_src(p.src[s], 32, "wgrad")) return r;
+            ctot += p.src[s].C;
+        }
+        FALNET_CHECK_ARG(ctot == p.cin_total, "wgrad: sources carry %d channels, cin_total=%d", ctot, p.cin_total);
+    } else {
+        FALNET_CHECK_ARG(p.src[0].ptr && p.src[0].C == 3, "wgrad: variant 6 needs a 3-channel planar f32 source");
     }
-    FALNET_CHECK_ARG(ctot == p.cin_total, "wgrad: sources carry %d channels, cin_total=%d", ctot, p.cin_total);
     FALNET_CHECK_ARG(p.gout && p.partial && p.gC > 0 && p.gC % 32 == 0 && p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= 9, "wgrad: bad argument");
     FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0, "wgrad: empty shape");
     const int w_rows = round32(p.gC);
     // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
     bool dense = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
     for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;  // canonical forward order
+    if (p.variant == 6) {  // first layer: planar f32 3-channel source (src[0].ptr = [B][3][IH][IW] f32), bf16 gout, Cout 32
+        bool ok = p.dtype == FALNET_BF16 && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.gC == 32 && w_rows == 32 && p.cin_total == 32 && p.nsrc == 1;
+        for (int t = 0; t < p.ntaps && ok; ++t) ok = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;
+        FALNET_CHECK_ARG(ok, "wgrad: variant 6 is the Cin=3 / Cout=32 first layer in bf16 (dense 3x3, cin_total 32)");
+        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
+        const int npatch = p.B * tiles_x * tiles_y;
+        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
+        hipLaunchKernelGGL(wgrad3x3_c3_kernel, dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+        FALNET_RETURN_LAUNCH();
+    }
     if (p.variant == 5) {  // stride-2 3x3 (bf16): parity-plane halo kernel
         bool ok = p.dtype == FALNET_BF16 && p.ntaps == 9 && p.isy == 2 && p.isx == 2 && p.TW >= 16 && p.TH == (p.IH + 1) / 2 && p.TW == (p.IW + 1) / 2;
         for (int t = 0; t < p.ntaps && ok; ++t) ok = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;

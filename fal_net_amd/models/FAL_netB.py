@@ -269,7 +269,9 @@ class FalnetPlan:
             hh, ww = sizes[i]
             a[i], h_[i], c[i] = self._act(f"a{i}", hh, ww, ch), self._act(f"h{i}", hh, ww, ch), self._act(f"c{i}", hh, ww, ch)
             if i == 0:
-                srcs, ih, iw = [ops.nhwc_src(x0)], H, W
+                # bf16: conv0's weight gradient reads the planar f32 image itself (falnet_wgrad variant 6): no NHWC copy of the image
+                self._c3_wgrad = dt == torch.bfloat16 and W >= 16 and os.environ.get("FALNET_WGRAD_C3", "1") == "1"
+                srcs, ih, iw = [ops.planar_src(left) if self._c3_wgrad else ops.nhwc_src(x0)], H, W
             elif i == 1:
                 ih, iw = sizes[0]
                 srcs = [ops.nhwc_src(c[0]), ops.bcast_src(flow, ih, iw)]
@@ -350,7 +352,8 @@ class FalnetPlan:
         self._x0_event = torch.cuda.Event()
 
         def x0_convert_and_mark():
-            self._x0_convert()
+            if not self._c3_wgrad:
+                self._x0_convert()
             self._x0_event.record()  # on the stream the conversion was launched on
         self._side_call(x0_convert_and_mark)
         if compose:

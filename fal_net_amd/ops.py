@@ -57,6 +57,16 @@ def nhwc_src(t, C_used=None):
     return s
 
 
+def planar_src(t):
+    """Planar f32 [B][3][H][W] image as the source of the first-layer weight gradient (falnet_wgrad variant 6)."""
+    B, Cc, H, W = t.shape
+    assert Cc == 3 and t.dtype == torch.float32 and t.is_contiguous()
+    s = L.Src()
+    s.ptr, s.C, s.H, s.W = t.data_ptr(), 3, H, W
+    s.sb, s.sy, s.sx = 3 * H * W, W, 1
+    return s
+
+
 def bcast_src(t, H, W):
     """Per-sample constant (B,C) presented as an HxW image (pixel strides 0): the `flow` plane."""
     B, Ct = t.shape
@@ -459,7 +469,13 @@ class WgradBatch:
         big = _wgrad_big(self.dtype, dense, pc.cin_pad, pad_c(gC))
         co2 = not big and _wgrad_co2(self.dtype, dense, pc.cin_pad, pad_c(gC))
         s2 = _wgrad_s2(self.dtype, taps, stride_in, TH, TW, IH, IW, srcs)
-        if s2:
+        c3 = len(srcs) == 1 and srcs[0].C == 3  # planar f32 image source (ops.planar_src): first-layer kernel, variant 6
+        if c3:
+            assert self.dtype == torch.bfloat16 and dense and gC == 32 and pc.cin_pad == 32, "variant 6: bf16 first layer, Cout 32"
+            big = co2 = False
+            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+            nsplit = max(1, min(_WGRAD_WGS, npatch))
+        elif s2:
             tiles = (pc.cin_pad // 32) * (pad_c(gC) // (64 if pad_c(gC) % 64 == 0 else 32))
             npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
             nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
@@ -471,7 +487,7 @@ class WgradBatch:
             tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
             nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
         nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
-        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (5 if s2 else 2 if big else 3 if co2 else 0)
+        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (6 if c3 else 5 if s2 else 2 if big else 3 if co2 else 0)
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
         dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
@@ -487,7 +503,7 @@ class WgradBatch:
         elif grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
         tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
-        sym = f"_Z18wgrad3x3_s2_kernelILi{2 if pad_c(gC) % 64 == 0 else 1}EEv14falnet_wgrad_tiiii" if s2 else ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
+        sym = "_Z18wgrad3x3_c3_kernel14falnet_wgrad_tiiii" if c3 else f"_Z18wgrad3x3_s2_kernelILi{2 if pad_c(gC) % 64 == 0 else 1}EEv14falnet_wgrad_tiiii" if s2 else ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
             if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 

@@ -143,7 +143,9 @@ typedef struct {
     int32_t variant;           /* 0 heuristic (halo-patch kernel, 32x32 channels per workgroup, when dense 3x3 stride 1),
                                   1 force the per-tap kernel, 2 halo-patch with 64x64 channels per workgroup (bf16, channel
                                   counts multiples of 64, LDS-DMA staged), 3 / 4 halo-patch with 32x64 / 64x32 (cin x cout)
-                                  channels per workgroup (bf16), 5 parity-plane halo kernel for 3x3 stride-2 launches (bf16) */
+                                  channels per workgroup (bf16), 5 parity-plane halo kernel for 3x3 stride-2 launches (bf16),
+                                  6 first layer: src[0].ptr = planar f32 [B][3][IH][IW] image (src[0].C = 3), bf16 gout with 32
+                                  channels, cin_total 32 (slab layout) */
     float* bias_grad;          /* optional, halo kernels (dense 3x3 stride 1, variant 5): db[co] += sum over positions of gout[.,co]
                                   (f32 atomics, [gC]) from the gout tiles the kernel stages anyway -- replaces a falnet_bias_grad
                                   pass over the same tensor; ignored by the per-tap kernel and variant 2 */

@@ -367,6 +367,30 @@ def test_wgrad_big_tiles(case, monkeypatch):
     assert rel(gw, wp.grad) < BF16_TOL
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (1, 75, 250)])
+def test_wgrad_first_layer_planar(B, H, W):
+    """falnet_wgrad variant 6: conv0's weight (+ fused bias) gradient straight from the planar f32 image (no NHWC copy), through
+    the batched path the plans use (slab reduce un-pads the 3 real input channels)."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = (torch.randn(32, generator=g) * 0.1).requires_grad_(True)
+    go = torch.randn(B, 32, H, W, generator=g)
+    (F.conv2d(x, w, b, padding=1) * go).sum().backward()
+    pc = packed(w.detach(), b.detach(), [3], 1, dtype)
+    xd, g_t = x.to(DEV).contiguous(), to_nhwc(go, dtype)
+    gw, gb = torch.zeros(32, 3, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+    wb = ops.WgradBatch(dtype, torch.device(DEV))
+    call = wb.add([ops.planar_src(xd)], H, W, g_t, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W, pc, gw, gb, name="wgrad conv0")
+    fin = wb.finalize()
+    call()
+    for c in fin[0]:
+        c()
+    assert rel(gw, w.grad) < BF16_TOL
+    assert rel(gb, b.grad) < BF16_TOL
+
+
 def test_upsample_bwd_and_pool():
     g = torch.Generator().manual_seed(9)
     for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
