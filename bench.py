@@ -87,6 +87,33 @@ def cpu_baseline(height, width, levels, sample_batch=8):
                       f"fp32 torch-CPU oracle, {torch.get_num_threads()} threads, {dt:.1f} s"}
 
 
+def parity_vs_oracle(height, width, levels, dev):
+    """SURVEY 8(d) `abs_rel vs ref`: one seeded pair through the CPU oracle (fixture-pinned restatement of the reference) and
+    through the HIP path in f32 (gate 1e-4) and bf16 (reported); depth = f*b/disp, abs_rel = mean(|d_ref - d_hip| / d_ref)
+    (myUtils.py:225).  Part of the cpu_baseline leg: the only place bench.py touches oracle/."""
+    import numpy as np
+    from fal_net_amd import synthetic
+    from fal_net_amd.models import FAL_netB
+    from oracle import falnet_oracle as O
+    left, right, mn, mx = synthetic.synthetic_pair(1, height, width, seed=4321)
+    sd = synthetic.seeded_falnetb_state_dict(levels)
+    with torch.no_grad():
+        ref = O.falnet_forward(sd, left, mn, mx)
+    d_ref = O.disp_to_depth(ref.numpy())
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        m = FAL_netB({"state_dict": sd}, no_levels=levels, compute_dtype=dt).to(dev).eval()
+        with torch.no_grad():
+            disp = m(left.to(dev), mn.to(dev), mx.to(dev)).float().cpu()
+        d = O.disp_to_depth(disp.numpy())
+        out[name] = {"abs_rel_depth": float(np.mean(np.abs(d_ref - d) / d_ref)),
+                     "disp_max_rel": float((disp - ref).abs().max() / ref.abs().max())}
+        del m
+    out["gate_f32"] = 1e-4
+    out["sample"] = f"1 pair, {height}x{width}, N={levels}, seeded weights, forward (disp) vs CPU oracle"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +246,7 @@ def main():
         result["kernel_breakdown_ms_per_step"] = {t: round(a["ms"] / 3, 4) for t, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.height, args.width, args.levels)
+        result["abs_rel_vs_ref"] = parity_vs_oracle(args.height, args.width, args.levels, dev)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
