@@ -64,7 +64,7 @@ class BiasGradDesc(C.Structure):
                 ("blocks", C.c_int32), ("block_begin", C.c_int32)]
 
 
-_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/falnet_hip.h one to one
 SIGNATURES = {
     "falnet_version": [],
@@ -103,6 +103,8 @@ SIGNATURES = {
     "falnet_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "falnet_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
     "falnet_hflip": [_P, _P, _L, _I, _P],
+    "falnet_resample_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "falnet_augment_normalize": [_P, _I, _I, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _F, _F, _F, _P, _P],
     "falnet_rowmax": [_P, _P, _I, _L, _P],
 }
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}

@@ -274,6 +274,20 @@ int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stre
 /* per-sample max of planar f32 [B][n] -> out[B]  (F.max_pool2d(kernel=(H,W)), Train_Stage2_K.py:319) */
 int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream);
 
+/* ---- training-data augmentation (data_transforms.py:46-157, Train_Stage1_K.py:116-128) ---- */
+/* One pass of Pillow's 8-bit bicubic resampling (Image.resize(size, BICUBIC), data_transforms.py:68) over an interleaved uint8
+ * image [H][W][C]: along x (horizontal != 0: dst [H][out_size][C]) or along y (dst [out_size][W][C]).  bounds [out_size][2] =
+ * (first source index, tap count), kk [out_size][ksize] = 22-bit fixed-point coefficients (host side:
+ * fal_net_amd.data_transforms.resample_coeffs, the precompute_coeffs of Pillow's Resample.c).  Bit-exact with Pillow. */
+int falnet_resample_u8(const uint8_t* src, uint8_t* dst, int H, int W, int C, int out_size, int horizontal,
+                       const int32_t* bounds, const int32_t* kk, int ksize, void* stream);
+/* crop [y1,y1+th) x [x1,x1+tw) of a uint8 [H][W][3] image, optional np.fliplr, RandomGamma / RandomBrightness /
+ * RandomCBrightness with the given factors (<= 0: not applied; float64 arithmetic as numpy), ArrayToTensor, Normalize(0,255),
+ * Normalize(mean,1) -> planar f32 [3][th][tw] */
+int falnet_augment_normalize(const uint8_t* src, int H, int W, int x1, int y1, int th, int tw, int flip, double gamma,
+                             double bright, double cb0, double cb1, double cb2, float mean0, float mean1, float mean2,
+                             float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

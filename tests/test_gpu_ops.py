@@ -565,3 +565,42 @@ def test_adam_matches_torch():
         gg[:n] = (gr * step).to(DEV)
         L.check(L.lib().falnet_adam_step(L.ptr(p), L.ptr(gg), L.ptr(m), L.ptr(v), n, 1e-4, 0.5, 0.999, 1e-8, step, 1.0, L.stream_ptr()))
     assert float((p[:n].cpu() - pt.detach()).abs().max()) < 1e-7
+
+
+def test_data_augmentation_vs_reference_goldens(golden_dir):
+    """GPU augmentation path (falnet_resample_u8 + falnet_augment_normalize behind fal_net_amd.data_transforms) against the
+    goldens recorded from the reference's data_transforms + Pillow: the resize is bit-exact, the augmented normalised views agree
+    to float32 rounding (device pow vs libm in RandomGamma)."""
+    import os
+    import random
+    from fal_net_amd import data_transforms as DT
+    g = np.load(os.path.join(golden_dir, "g8_data_aug.npz"))
+    for i in range(int(g["n_resize"])):
+        ow, oh = (int(v) for v in g[f"rs{i}_size"])
+        got = DT.resize_bicubic_u8(torch.from_numpy(g[f"rs{i}_in"]).to(DEV), ow, oh).cpu().numpy()
+        assert np.array_equal(got, g[f"rs{i}_out"]), i
+    H, W, TH, TW = (int(v) for v in g["aug_shape"])
+    aug = DT.StereoAugment(TH, TW)
+    for k, seed in enumerate(g["aug_seeds"]):
+        random.seed(int(seed))
+        np.random.seed(int(seed))
+        outs = aug([torch.from_numpy(g[f"aug{k}_left"]).to(DEV), torch.from_numpy(g[f"aug{k}_right"]).to(DEV)])
+        for j, o in enumerate(outs):
+            assert float((o.cpu() - torch.from_numpy(g[f"aug{k}_out{j}"])).abs().max()) <= 2e-6, (k, j)
+
+
+def test_data_resize_full_size_properties():
+    """Size-independent properties at KITTI size (375x1242 -> x1.3): constant images stay constant, output within the input range
+    up to the bicubic overshoot, identity when the size does not change, and agreement with the CPU oracle on a strip."""
+    from fal_net_amd import data_transforms as DT
+    from oracle import data_oracle as D
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (375, 1242, 3), generator=g, dtype=torch.uint8)
+    const = torch.full((375, 1242, 3), 77, dtype=torch.uint8)
+    ow, oh = int(1242 * 1.3), int(375 * 1.3)
+    assert int((DT.resize_bicubic_u8(const.to(DEV), ow, oh).cpu().int() - 77).abs().max()) == 0
+    assert torch.equal(DT.resize_bicubic_u8(img.to(DEV), 1242, 375).cpu(), img)
+    got = DT.resize_bicubic_u8(img.to(DEV), ow, oh).cpu().numpy()
+    ref = D.pil_bicubic_resize_u8(img[:40].numpy(), ow, 40)  # horizontal pass only on a strip (the oracle is slow)
+    hgot = DT.resize_bicubic_u8(img[:40].contiguous().to(DEV), ow, 40).cpu().numpy()
+    assert np.array_equal(hgot, ref) and got.shape == (oh, ow, 3)

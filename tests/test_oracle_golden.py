@@ -154,3 +154,23 @@ def test_g7_odd_size(golden_dir):
     with torch.no_grad():
         disp = O.falnet_forward(synthetic.seeded_falnetb_state_dict(49), left, mn, mx)
     assert rel(disp.numpy(), g["disp"]) < TOL
+
+
+def test_data_oracle_matches_reference_goldens(golden_dir):
+    """oracle/data_oracle.py (PIL-compatible bicubic resize + the reference's augmentation chain, every random draw replayed in
+    the reference's order) against tests/golden/g8_data_aug.npz recorded from the reference's data_transforms + Pillow."""
+    import random
+    from oracle import data_oracle as D
+    g = np.load(os.path.join(golden_dir, "g8_data_aug.npz"))
+    for i in range(int(g["n_resize"])):
+        ow, oh = (int(v) for v in g[f"rs{i}_size"])
+        assert np.array_equal(D.pil_bicubic_resize_u8(g[f"rs{i}_in"], ow, oh), g[f"rs{i}_out"]), i  # bit-exact
+    H, W, TH, TW = (int(v) for v in g["aug_shape"])
+    for k, seed in enumerate(g["aug_seeds"]):
+        random.seed(int(seed))
+        np.random.seed(int(seed))
+        prm = D.draw_params(H, W, TH, TW)
+        outs = D.co_transform([g[f"aug{k}_left"], g[f"aug{k}_right"]], TH, TW, prm)
+        for j, o in enumerate(outs):
+            got = D.input_transform(o)
+            assert np.abs(got - g[f"aug{k}_out{j}"]).max() <= 1e-6, (k, j)
