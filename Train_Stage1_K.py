@@ -50,6 +50,9 @@ parser.add_argument('--start-epoch', type=int, default=0)
 parser.add_argument('--pretrained', default=None, help='checkpoint.pth.tar in the reference format')
 # --- additions ---
 parser.add_argument('--synthetic', action='store_true', help='seeded random pairs instead of a dataset')
+parser.add_argument('--gpu-augment', action='store_true',
+                    help='synthetic mode: start from KITTI-sized uint8 "decoded" pairs and run the reference augmentation chain on '
+                         'the GPU every step (fal_net_amd.data_transforms.StereoAugment) instead of cycling pre-made float batches')
 parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype (f32 = exact-f32 MFMA parity path)')
 parser.add_argument('--save-path', default=None)
 
@@ -91,8 +94,8 @@ def main():
         return args.lr * (0.5 ** sum(1 for m in args.milestones if epoch >= m))
 
     if not args.synthetic:
-        raise SystemExit('only --synthetic input is wired in this build: the KITTI loaders/augmentations (Datasets/, '
-                         'data_transforms.py) are outside the hot path (SURVEY.md 8f-3).')
+        raise SystemExit('only --synthetic input is wired in this build: the KITTI file lists / image decoding (Datasets/) need the '
+                         'dataset; the augmentation chain itself runs on the GPU (--gpu-augment, SURVEY.md 8f-3).')
     steps_per_epoch = args.epoch_size or 100
     best = -1
     # synthetic mode: a small pool of seeded batches resident in HBM, cycled (generating 25 MB of noise on the CPU every
@@ -101,13 +104,28 @@ def main():
     for k in range(4):
         l_, r_, _, mx_ = synthetic.synthetic_pair(args.batch_size, args.crop_height, args.crop_width, seed=1234 + rank + 977 * k, max_disp=args.max_disp)
         pool.append((l_.to(dev), r_.to(dev), mx_.to(dev)))
+    raw, augment = None, None
+    if args.gpu_augment:
+        from fal_net_amd import data_transforms as DT
+        import torch as _t
+        g = _t.Generator().manual_seed(4321 + rank)
+        raw = [[_t.randint(0, 256, (375, 1242, 3), generator=g, dtype=_t.uint8).to(dev) for _ in range(2)] for _ in range(2 * args.batch_size)]
+        augment = DT.StereoAugment(args.crop_height, args.crop_width)  # down=0.75, up=1.5, gamma / brightness ranges of :117-122
+        mx_aug = _t.full((args.batch_size, 1, 1), float(args.max_disp), device=dev)
+
+    def next_batch(i):
+        if augment is None:
+            return pool[i % len(pool)]
+        import torch as _t
+        views = [augment(raw[(i * args.batch_size + b) % len(raw)]) for b in range(args.batch_size)]
+        return _t.stack([v[0] for v in views]), _t.stack([v[1] for v in views]), mx_aug
     for epoch in range(args.start_epoch, args.epochs):
         opt.param_groups[0]['lr'] = lr_at(epoch)
         m_model.train()
         losses, rec_losses = utils.AverageMeter(), utils.AverageMeter()
         end = time.time()
         for i in range(steps_per_epoch):
-            left, right, mx = pool[i % len(pool)]
+            left, right, mx = next_batch(i)
             out = train.stage1_step(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
                                     min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
             if i % args.print_freq == 0:

@@ -53,6 +53,7 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
 @pytest.mark.parametrize("cmd", [
     ["Test_KITTI.py", "--height", "96", "--width", "320", "--iters", "2", "--dtype", "f32"],
     ["Train_Stage1_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
+    ["Train_Stage1_K.py", "--synthetic", "--gpu-augment", "--epochs", "1", "--epoch_size", "2", "-b", "2", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage2_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
 ])
 def test_entry_scripts_synthetic(cmd, tmp_path):
