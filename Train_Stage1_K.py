@@ -57,7 +57,7 @@ parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='co
 parser.add_argument('--save-path', default=None)
 
 
-def main():
+def main(step='stage1_step'):
     import torch
     import torch.distributed as dist
     from fal_net_amd import loss_functions as LF
@@ -126,8 +126,8 @@ def main():
         end = time.time()
         for i in range(steps_per_epoch):
             left, right, mx = next_batch(i)
-            out = train.stage1_step(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
-                                    min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
+            out = getattr(train, step)(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
+                                       min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
             if i % args.print_freq == 0:
                 losses.update(float(out['loss']), args.batch_size)
                 rec_losses.update(float(out['rec']), args.batch_size)

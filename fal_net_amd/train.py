@@ -95,17 +95,18 @@ def _aux_stream(device):
     return _AUX_STREAMS[key]
 
 
-def vgg_label_async(label):
+def vgg_label_async(label, borrow=True):
     """VGG features of a label image on an auxiliary HIP stream: independent of the network forward, so it runs
-    concurrently with it and fills the CUs the small backbone layers leave idle.  Returns (features, join)."""
+    concurrently with it and fills the CUs the small backbone layers leave idle.  Returns join() -> features.
+    `borrow`: the features alias the label plan's buffers (valid until the next label pass of that shape)."""
     if ops.TIMER is not None:  # instrumented pass (bench.py roofline): serial launches so per-kernel times are uncontended
-        feats_serial = vgg(label, borrow=True)
+        feats_serial = vgg(label, borrow=borrow)
         return lambda: feats_serial
     main = torch.cuda.current_stream()
     aux = _aux_stream(label.device)
     aux.wait_stream(main)
     with torch.cuda.stream(aux):
-        feats = vgg(label, borrow=True)  # consumed by this step's perceptual loss only
+        feats = vgg(label, borrow=borrow)  # consumed by this step's perceptual loss only
 
     def join():
         main.wait_stream(aux)
@@ -149,6 +150,33 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
     if optimize:
         opt.step(allreduce_gradients(model))
     return out
+
+
+def stage1_slow_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0,
+                     max_disp_arg=300.0):
+    """One iteration of Train_Stage1_Kslow.py:236-284: both views in one 2B batch (left | flip(right)), the second
+    half of the outputs flipped back, reconstruction and smoothness averaged over the two views."""
+    opt.zero_grad()
+    enable_overlapped_allreduce(model)
+    B, C, H, W = left.shape
+    min_disp = max_disp * min_disp_arg / max_disp_arg  # :244
+    mn2, mx2 = torch.cat((min_disp, min_disp), 0), torch.cat((max_disp, max_disp), 0)
+    joins = [vgg_label_async(right, borrow=False), vgg_label_async(left)] if a_p > 0 else []  # :259-264
+    pan, disp = model(torch.cat((left, hflip(right)), 0), mn2, mx2, ret_disp=True, ret_pan=True, ret_subocc=False)  # :245-248
+    rpan, lpan = pan[0:B], flip(pan[B:])  # :249-256
+    ldisp, rdisp = disp[0:B], flip(disp[B:])
+    vgg_right, vgg_left = (joins[0](), joins[1]()) if joins else (None, None)
+    rec_loss = (rec_loss_fnc(1, rpan, right, vgg_right, a_p) + rec_loss_fnc(1, lpan, left, vgg_left, a_p)) / 2  # :268-269
+    sm_loss = 0
+    if a_sm > 0:  # :274-278
+        c2, c8 = int(0.20 * W), int(0.80 * W)
+        sm_loss = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
+                   smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
+    loss = rec_loss + a_sm * sm_loss  # :281
+    loss.backward()
+    opt.step(allreduce_gradients(model))
+    return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
+            "rpan": rpan, "lpan": lpan, "ldisp": ldisp, "rdisp": rdisp}
 
 
 class GraphedStage1Step:

@@ -259,6 +259,28 @@ def hflip(x):
     return torch.flip(x, [3])
 
 
+def stage1_slow_losses(params, vsd, left, right, min_disp, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512):
+    """Loss part of one iteration of the two-view Stage-1 variant, Train_Stage1_Kslow.py:243-281:
+    the batch is (left | flip(right)); the second half of every output is flipped back."""
+    B, C, H, W = left.shape
+    mn2, mx2 = torch.cat((min_disp, min_disp), 0), torch.cat((max_disp, max_disp), 0)
+    pan, disp = falnet_forward(params, torch.cat((left, hflip(right)), 0), mn2, mx2,
+                               ret_disp=True, ret_pan=True)  # :245-248
+    rpan, lpan = pan[0:B], hflip(pan[B:])  # :249-256
+    ldisp, rdisp = disp[0:B], hflip(disp[B:])
+    with torch.no_grad():
+        vgg_right, vgg_left = (vgg_forward(vsd, right), vgg_forward(vsd, left)) if a_p > 0 else (None, None)  # :259-264
+    rec = (rec_loss_fnc(vsd, 1, rpan, right, vgg_right, a_p) +
+           rec_loss_fnc(vsd, 1, lpan, left, vgg_left, a_p)) / 2  # :268-269
+    c2, c8 = int(0.20 * W), int(0.80 * W)
+    sm = 0
+    if a_sm > 0:  # :274-278
+        sm = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
+              smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
+    loss = rec + a_sm * sm  # :281
+    return {"loss": loss, "rec": rec, "sm": sm, "rpan": rpan, "lpan": lpan, "ldisp": ldisp, "rdisp": rdisp}
+
+
 def stage2_losses(params, teacher_sd, vsd, left, right, min_disp, max_disp,
                   a_p=0.01, a_sm=0.4 * 2 / 512, a_mr=1.0):
     """Loss part of one Stage-2 iteration, Train_Stage2_K.py:247-329."""

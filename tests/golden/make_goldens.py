@@ -78,7 +78,15 @@ def np32(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None, help="write only this fixture (e.g. g9); earlier ones are recomputed but not saved")
     args = ap.parse_args()
+    if args.only:
+        _savez = np.savez
+
+        def savez_only(path, **kw):
+            if os.path.basename(path).startswith(args.only):
+                _savez(path, **kw)
+        np.savez = savez_only
     install_shims()
     sys.path.insert(0, args.ref)
     import models as ref_models  # noqa
@@ -188,6 +196,50 @@ def main():
     out = stage2(ref_model(7).train(), ref_model(7).eval(), left, right, mx)
     np.savez(os.path.join(HERE, "g3_stage2_step.npz"), seed=31, max_disp=np32(mx), **out)
     print("G3", out["loss"], out["rec"], out["sm"], out["mirror"])
+
+    # ---- G9: one two-view Stage-1 step (Train_Stage1_Kslow.py:236-284), B=2 64x128 N=49 ----
+    def stage1_slow(m, left, right, mx, a_p=0.01, a_sm=0.2 * 2 / 512, lr=1e-4):
+        opt = torch.optim.Adam([{"params": m.bias_parameters(), "weight_decay": 0.0},
+                                {"params": m.weight_parameters(), "weight_decay": 0.0}], lr=lr, betas=(0.5, 0.999))
+        m.train()
+        opt.zero_grad()
+        B, C, H, W = left.shape
+        mn = mx * 2 / 300
+        th = torch.zeros(B, 2, 3)
+        th[:, 0, 0] = 1
+        th[:, 1, 1] = 1
+        fg = F.affine_grid(th, [B, C, H, W], align_corners=True).clone()
+        fg[:, :, :, 0] = -fg[:, :, :, 0]
+        gs = lambda t: F.grid_sample(t, fg, align_corners=True)
+        pan, disp = m(torch.cat((left, gs(right)), 0), torch.cat((mn, mn), 0), torch.cat((mx, mx), 0),
+                      ret_disp=True, ret_pan=True, ret_subocc=False)
+        rpan, lpan = pan[0:B], gs(pan[B::])
+        ldisp, rdisp = disp[0:B], gs(disp[B::])
+        vgg_right, vgg_left = ref_loss.vgg(right), ref_loss.vgg(left)
+        rec = (ref_loss.rec_loss_fnc(1, rpan, right, vgg_right, a_p) +
+               ref_loss.rec_loss_fnc(1, lpan, left, vgg_left, a_p)) / 2
+        sm = (ref_loss.smoothness(left[:, :, :, int(0.20 * W)::], ldisp[:, :, :, int(0.20 * W)::], gamma=2) +
+              ref_loss.smoothness(right[:, :, :, 0:int(0.80 * W)], rdisp[:, :, :, 0:int(0.80 * W)], gamma=2)) / 2
+        loss = rec + a_sm * sm
+        loss.backward()
+        out = {"loss": float(loss), "rec": float(rec), "sm": float(sm), "ldisp": np32(ldisp), "rdisp": np32(rdisp),
+               "rpan": np32(rpan)[:, :, ::2, ::2], "lpan": np32(lpan)[:, :, ::2, ::2]}
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                g = p.grad.reshape(-1)
+                out["gnorm:" + k] = float(g.norm())
+                out["gsamp:" + k] = np32(g[sample_idx(k, g.numel())])
+        opt.step()
+        for k, p in m.named_parameters():
+            out["after:" + k] = np32(p.reshape(-1)[sample_idx(k, p.numel())])
+        return out
+
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=91, distinct=True)
+    out = stage1_slow(ref_model(49), left, right, mx)
+    np.savez(os.path.join(HERE, "g9_stage1_slow_step.npz"), seed=91, max_disp=np32(mx), **out)
+    print("G9", out["loss"], out["rec"], out["sm"])
+    if args.only == "g9":
+        return
 
     # ---- G4: config shape 256x512 N=49 B=1: strided outputs + Stage-1 scalars ----
     left, right, mn, mx = synthetic.synthetic_pair(1, 256, 512, seed=1234)

@@ -54,10 +54,11 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     ["Test_KITTI.py", "--height", "96", "--width", "320", "--iters", "2", "--dtype", "f32"],
     ["Train_Stage1_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage1_K.py", "--synthetic", "--gpu-augment", "--epochs", "1", "--epoch_size", "2", "-b", "2", "-ch", "64", "-cw", "128", "-p", "1"],
+    ["Train_Stage1_Kslow.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage2_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
 ])
 def test_entry_scripts_synthetic(cmd, tmp_path):
-    extra = ["--save-path", str(tmp_path)] if cmd[0] == "Train_Stage1_K.py" else []
+    extra = ["--save-path", str(tmp_path)] if cmd[0].startswith("Train_Stage1_K") else []
     r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "{" in r.stdout

@@ -135,6 +135,31 @@ def test_stage2_step_vs_golden(golden_dir):
             assert abs(float(p.grad.norm()) - gn) / gn < 1e-3, k
 
 
+def test_stage1_slow_step_vs_golden(golden_dir):
+    """Two-view Stage-1 variant (Train_Stage1_Kslow.py:236-284) against the reference-made golden: losses, both
+    disparities, both synthesised views, gradients and the weights after Adam."""
+    g = np.load(os.path.join(golden_dir, "g9_stage1_slow_step.npz"))
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    m = build(49).train()
+    opt = train.FlatAdam(m)
+    out = train.stage1_slow_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, (k, float(out[k]), float(g[k]))
+    for k in ("ldisp", "rdisp"):
+        assert rel(out[k], g[k]) < TOL, k
+    for k in ("rpan", "lpan"):
+        assert rel(out[k][:, :, ::2, ::2], g[k]) < 2e-4, k
+    for k, p in m.named_parameters():
+        if ("gnorm:" + k) not in g.files:
+            continue
+        gn = float(g["gnorm:" + k])
+        gr = p.grad.reshape(-1)
+        assert abs(float(gr.norm()) - gn) / gn < 1e-3, k
+        assert np.abs(gr[sample_idx(k, gr.numel())].cpu().numpy() - g["gsamp:" + k]).max() <= 1e-3 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
+        assert np.abs(after - g["after:" + k]).max() < 2e-5, k
+
+
 def test_bf16_step_runs_and_tracks_f32():
     """bf16 throughput path: same step, deviation reported (no 1e-4 gate; the reference is f32-only)."""
     left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=21, distinct=True)

@@ -98,6 +98,34 @@ def test_g3_stage2_losses(golden_dir):
             assert abs(float(p.grad.norm()) - gn) / gn < 2e-4, k
 
 
+def test_g9_stage1_slow_step(golden_dir):
+    g = load(golden_dir, "g9_stage1_slow_step.npz")
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    params = O.leaf_params(synthetic.seeded_falnetb_state_dict(49))
+    vsd = synthetic.seeded_vgg19_state_dict()
+    opt = O.OracleAdam(params)
+    opt.zero_grad()
+    out = O.stage1_slow_losses(params, vsd, left, right, mn, mx)
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < 2e-5, k
+    for k in ("ldisp", "rdisp"):
+        assert rel(out[k].detach().numpy(), g[k]) < 2e-5, k
+    for k in ("rpan", "lpan"):
+        assert rel(out[k].detach().numpy()[:, :, ::2, ::2], g[k]) < WARP_TOL, k
+    out["loss"].backward()
+    grads = {k: p.grad.detach().clone() for k, p in params.items() if p.grad is not None}
+    opt.step()
+    for k, p in params.items():
+        if ("gnorm:" + k) not in g.files:
+            assert k not in grads
+            continue
+        gr, gn = grads[k].reshape(-1), float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - gn) / gn < 2e-4, k
+        assert np.abs(gr[sample_idx(k, gr.numel())].numpy() - g["gsamp:" + k]).max() <= 2e-4 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].numpy()
+        assert np.abs(after - g["after:" + k]).max() < 2e-5, k
+
+
 def test_g4_config_shape(golden_dir):
     g = load(golden_dir, "g4_config_256x512.npz")
     params, out = _stage1(int(g["seed"]), 1, 256, 512, 49, False)
