@@ -12,7 +12,7 @@ parser = argparse.ArgumentParser(description='FAL_net inference on MI355X', form
 parser.add_argument('-maxd', '--max_disp', type=float, default=300)
 parser.add_argument('-mind', '--min_disp', type=float, default=2)
 parser.add_argument('-relbase', '--rel_baselne', type=float, default=1)
-parser.add_argument('-mm', '--m_model', default='FAL_netB', choices=['FAL_netB'])
+parser.add_argument('-mm', '--m_model', default='FAL_netB', choices=['FAL_netA', 'FAL_netB', 'FAL_netC'])
 parser.add_argument('-no_levels', '--no_levels', type=int, default=49)
 parser.add_argument('--model', dest='model_dir', default=None, help='checkpoint (reference format); seeded weights if absent')
 parser.add_argument('-fpp', '--f_post_process', action='store_true', help='flip post-processing (Test_KITTI.py:200-203)')

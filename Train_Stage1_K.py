@@ -26,7 +26,7 @@ parser.add_argument('-relbase_test', '--rel_baset', type=float, default=1)
 parser.add_argument('-maxd', '--max_disp', type=float, default=300)
 parser.add_argument('-mind', '--min_disp', type=float, default=2)
 parser.add_argument('-gpu_no', '--gpu_no', default='0')
-parser.add_argument('-mm', '--m_model', default='FAL_netB', choices=['FAL_netB'])
+parser.add_argument('-mm', '--m_model', default='FAL_netB', choices=['FAL_netA', 'FAL_netB', 'FAL_netC'])
 parser.add_argument('-no_levels', '--no_levels', type=int, default=49)
 parser.add_argument('-perc', '--a_p', type=float, default=0.01)
 parser.add_argument('-smooth', '--a_sm', type=float, default=0.2 * 2 / 512)

@@ -93,6 +93,7 @@ SIGNATURES = {
     "falnet_med_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_head_bwd_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_med_masks_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "falnet_med_maskr_acfalse_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_l1_fwd": [_P, _P, _P, _I, _I, _L, _F, _P, _I, _P],
     "falnet_l1_bwd": [_P, _P, _P, _I, _I, _L, _F, _P, _P, _I, _P],
     "falnet_mse_fwd": [_P, _P, _L, _I, _F, _P, _I, _I, _P],

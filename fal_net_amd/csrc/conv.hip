@@ -2532,7 +2532,7 @@ __device__ __forceinline__ void pack_tile(const falnet_pack_t& d, int rel, float
 
 // One block = one 32(cout) x 32(packed cin) tile of one layer, all taps, staged through LDS: the OIHW reads are
 // runs of taps*32 contiguous floats, the wf rows ([co][tap][32 cin]) and wd rows ([cin][tap][32 cout]) are written as
-// 32 contiguous elements.  taps is 9 or 1 (compile-time divisions).
+// 32 contiguous elements.  taps is 9, 3 or 1 (compile-time divisions).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_pack_t* __restrict__ descs, int n) {
     __shared__ float tile[32][32 * 9 + 1];
@@ -2541,11 +2541,12 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
     const falnet_pack_t d = descs[li];
     const int rel = blockIdx.x - d.block_begin;
     if (d.taps == 9) pack_tile<T, 9>(d, rel, tile);
+    else if (d.taps == 3) pack_tile<T, 3>(d, rel, tile);  // 3x1 / 1x3 (FAL_netA.py:73-76)
     else pack_tile<T, 1>(d, rel, tile);
 }
 
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
-    FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9 or 1, n <= 64)");
+    FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9, 3 or 1, n <= 64)");
     if (dtype == FALNET_BF16)
         hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
     else

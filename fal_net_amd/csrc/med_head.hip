@@ -622,6 +622,50 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_masks_kernel(
     }
 }
 
+// FAL_netA's right mask (FAL_netA.py:264): softmax(dlog0)_n sampled by grid_sample with its DEFAULT align_corners=False on a grid
+// that was built for align_corners=True (:231,:241-242).  Pixel (x, y) therefore reads the bilinear sample (zero padding) at
+//   ix = ((xn + 1) W - 1) / 2,  xn = 2x/(W-1) - 1 + 2 d_n / W      iy = ((yn + 1) H - 1) / 2,  yn = 2y/(H-1) - 1
+// i.e. a slightly magnified, half-pixel-shifted image: two rows and two columns per plane.  maskR = min(1, sum_n sample_n).
+__global__ __launch_bounds__(HEAD_THREADS) void med_maskr_acfalse_kernel(
+    const float* __restrict__ dlog0, const float* __restrict__ min_disp, const float* __restrict__ max_disp,
+    const float* __restrict__ stats, float* __restrict__ maskR, int N, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
+    const int b = blockIdx.x / H, y = blockIdx.x % H;
+    const int64_t HW = (int64_t)H * W;
+    build_plane_tab(tab, min_disp[b], max_disp[b], N, W);
+    __syncthreads();
+    const float yn = H > 1 ? 2.f * (float)y / (float)(H - 1) - 1.f : 0.f;
+    const float iy = ((yn + 1.f) * (float)H - 1.f) * 0.5f;
+    const float y0f = floorf(iy);
+    const int y0 = (int)y0f;
+    const float wy1 = iy - y0f, wy0 = 1.f - wy1;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const float* st = stats + (int64_t)b * 4 * HW;
+    const float* Lb = dlog0 + (int64_t)b * N * HW;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const float xb = W > 1 ? 2.f * (float)x / (float)(W - 1) - 1.f : 0.f;
+        float mr = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float xn = xb + 2.f * tab.d[n] / (float)W;
+            const float ix = ((xn + 1.f) * (float)W - 1.f) * 0.5f;
+            const float x0f = floorf(ix);
+            if (x0f >= (float)W) continue;  // both columns right of the image
+            const int x0 = (int)x0f;
+            const float wx1 = ix - x0f, wx0 = 1.f - wx1;
+            const float* Ln = Lb + (int64_t)n * HW;
+            auto tap = [&](int yy, int xx) -> float {
+                if (xx < 0 || xx >= W) return 0.f;
+                const int64_t o = (int64_t)yy * W + xx;
+                return __expf(Ln[o] - st[o]) / st[HW + o];
+            };
+            if (vy0) mr += wy0 * (wx0 * tap(y0, x0) + wx1 * tap(y0, x0 + 1));
+            if (vy1) mr += wy1 * (wx0 * tap(y0 + 1, x0) + wx1 * tap(y0 + 1, x0 + 1));
+        }
+        maskR[(int64_t)b * HW + (int64_t)y * W + x] = fminf(mr, 1.f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------- C-ABI
 #include <stdlib.h>
 // FALNET_HEAD_V1=1: first forward kernel (per-lane global taps) instead of the LDS-staged one (A/B, tests)
@@ -723,5 +767,14 @@ extern "C" int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, c
     const size_t lds = sizeof(PlaneTab) + (size_t)4 * (W + 3) * sizeof(float);
     hipLaunchKernelGGL(med_masks_kernel, dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, min_disp,
                        max_disp, stats, maskL, maskR, N, H, W);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_med_maskr_acfalse_fwd(const float* dlog0, const float* min_disp, const float* max_disp,
+                                            const float* stats, float* maskR, int B, int N, int H, int W, void* stream) {
+    if (int r = check_head(B, N, H, W)) return r;
+    FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && maskR, "med_maskr_acfalse_fwd: null input");
+    hipLaunchKernelGGL(med_maskr_acfalse_kernel, dim3(B * H), dim3(HEAD_THREADS), sizeof(PlaneTab), (hipStream_t)stream, dlog0,
+                       min_disp, max_disp, stats, maskR, N, H, W);
     FALNET_RETURN_LAUNCH();
 }

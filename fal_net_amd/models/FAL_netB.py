@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ..arch import ARCHS
 from .. import ops
 from ..ops import PackedConv, pad_c
 
@@ -28,7 +29,11 @@ __all__ = ["FAL_netB"]
 
 def FAL_netB(data=None, no_levels=49, compute_dtype=None):
     """Factory with the reference's signature (models/FAL_netB.py:28-32)."""
-    model = FAL_net(batchNorm=False, no_levels=no_levels, compute_dtype=compute_dtype)
+    return _make("B", data, no_levels, compute_dtype)
+
+
+def _make(arch, data, no_levels, compute_dtype):
+    model = FAL_net(batchNorm=False, no_levels=no_levels, compute_dtype=compute_dtype, arch=arch)
     if data is not None:
         model.load_state_dict(data["state_dict"])
     return model
@@ -47,10 +52,14 @@ class deconv(nn.Module):
 
 
 class residual_block(nn.Module):
-    def __init__(self, in_planes):
+    def __init__(self, in_planes, separable=False):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
-        self.conv2 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
+        if separable:  # FAL_netA.py:73-76: a 3x1 then a 1x3 convolution
+            self.conv1 = nn.Conv2d(in_planes, in_planes, (3, 1), padding=(1, 0), bias=False)
+            self.conv2 = nn.Conv2d(in_planes, in_planes, (1, 3), padding=(0, 1), bias=False)
+        else:
+            self.conv1 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
+            self.conv2 = nn.Conv2d(in_planes, in_planes, 3, padding=1, bias=False)
 
 
 def predict_amask(in_planes, out_planes):
@@ -60,37 +69,27 @@ def predict_amask(in_planes, out_planes):
 
 
 class BackBone(nn.Module):
-    """Parameter tree of the reference BackBone (FAL_netB.py:92-138); compute lives in FalnetPlan."""
+    """Parameter tree of the reference BackBone (FAL_netB.py:92-138, FAL_netA.py:92-135, FAL_netC.py:96-137), built in the
+    reference's registration order from the variant's layer table (fal_net_amd/arch.py); compute lives in FalnetPlan."""
 
-    def __init__(self, batchNorm=False, no_in=3, no_flow=1, no_out=64):
+    def __init__(self, batchNorm=False, no_in=3, no_flow=1, no_out=64, arch="B"):
         super().__init__()
-        self.conv0 = conv_elu(batchNorm, no_in, 32)
-        self.conv0_1 = residual_block(32)
-        self.conv1 = conv_elu(batchNorm, 32 + no_flow, 64, stride=2)
-        self.conv1_1 = residual_block(64)
-        self.conv2 = conv_elu(batchNorm, 64, 128, stride=2)
-        self.conv2_1 = residual_block(128)
-        self.conv3 = conv_elu(batchNorm, 128, 256, stride=2)
-        self.conv3_1 = residual_block(256)
-        self.conv4 = conv_elu(batchNorm, 256, 256, stride=2)
-        self.conv4_1 = residual_block(256)
-        self.conv5 = conv_elu(batchNorm, 256, 256, stride=2)
-        self.conv5_1 = residual_block(256)
-        self.conv6 = conv_elu(batchNorm, 256, 512, stride=2)
-        self.conv6_1 = residual_block(512)
-        self.deconv6 = deconv(512, 256)
-        self.iconv6 = conv_elu(batchNorm, 256 + 256, 256)
-        self.deconv5 = deconv(256, 128)
-        self.iconv5 = conv_elu(batchNorm, 128 + 256, 256)
-        self.deconv4 = deconv(256, 128)
-        self.iconv4 = conv_elu(batchNorm, 128 + 256, 256)
-        self.deconv3 = deconv(256, 128)
-        self.iconv3 = conv_elu(batchNorm, 128 + 128, 128)
-        self.deconv2 = deconv(128, 64)
-        self.iconv2 = conv_elu(batchNorm, 64 + 64, 64)
-        self.deconv1 = deconv(64, 64)
-        self.iconv1 = nn.Conv2d(32 + 64, no_out, 3, 1, 1, bias=False)
-        self.amask_conv = predict_amask(32 + 64, 1)
+        t = ARCHS[arch]
+        enc, dec = t["enc"], t["dec"]
+        for i, ch in enumerate(enc):
+            cin = no_in if i == 0 else enc[i - 1] + (no_flow if i == 1 else 0)
+            setattr(self, f"conv{i}", conv_elu(batchNorm, cin, ch, stride=1 if i == 0 else 2))
+            setattr(self, f"conv{i}_1", residual_block(ch, t["separable"]))
+        below = enc[6]
+        for lvl in range(6, 1, -1):
+            dch, ich = dec[lvl]
+            setattr(self, f"deconv{lvl}", deconv(below, dch))
+            setattr(self, f"iconv{lvl}", conv_elu(batchNorm, dch + enc[lvl - 1], ich))
+            below = ich
+        self.deconv1 = deconv(below, 64)
+        self.iconv1 = nn.Conv2d(enc[0] + 64, no_out, 3, 1, 1, bias=False)
+        if t["amask"]:
+            self.amask_conv = predict_amask(32 + 64, 1)
         for m in self.modules():  # FAL_netB.py:131-138
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight.data)
@@ -98,19 +97,17 @@ class BackBone(nn.Module):
                     m.bias.data.zero_()
 
 
-# encoder level i: (stride-2 conv name, residual block name, channels)
-_ENC = [("conv0", "conv0_1", 32), ("conv1", "conv1_1", 64), ("conv2", "conv2_1", 128), ("conv3", "conv3_1", 256),
-        ("conv4", "conv4_1", 256), ("conv5", "conv5_1", 256), ("conv6", "conv6_1", 512)]
-# decoder level i (6..1): (deconv name, deconv Cout, iconv name, iconv Cout)
-_DEC = {6: ("deconv6", 256, "iconv6", 256), 5: ("deconv5", 128, "iconv5", 256), 4: ("deconv4", 128, "iconv4", 256),
-        3: ("deconv3", 128, "iconv3", 128), 2: ("deconv2", 64, "iconv2", 64), 1: ("deconv1", 64, "iconv1", None)}
-
-
 class FalnetPlan:
     """Static launch plan of FAL_net.forward / backward for one (B, H, W, dtype, device)."""
 
     def __init__(self, model, B, H, W, dtype, device):
         self.model, self.B, self.H, self.W, self.dtype, self.device = model, B, H, W, dtype, device
+        t = ARCHS[model.arch]
+        # encoder level i: (stride-2 conv name, residual block name, channels)
+        self._enc = [(f"conv{i}", f"conv{i}_1", ch) for i, ch in enumerate(t["enc"])]
+        # decoder level i (6..1): (deconv name, deconv Cout, iconv name, iconv Cout)
+        self._dec = {lvl: (f"deconv{lvl}", dch, f"iconv{lvl}", ich) for lvl, (dch, ich) in t["dec"].items()}
+        self._dec[1] = ("deconv1", 64, "iconv1", None)
         self.N = model.no_levels
         self.generation = 0
         self.use_side_stream = True
@@ -238,7 +235,7 @@ class FalnetPlan:
         compose = getattr(m, "_compose_logits", False)
         if compose:
             w1_2d = m.conv0.weight.detach().view(m.conv0.weight.shape[0], -1)
-            w3_2d = m.backbone.iconv1.weight.detach().view(m.backbone.iconv1.weight.shape[0], -1)
+            w3_2d = m._bb.iconv1.weight.detach().view(m._bb.iconv1.weight.shape[0], -1)
             wc_2d = m._wc.view(m._wc.shape[0], -1)
 
             def compose_call():
@@ -265,7 +262,7 @@ class FalnetPlan:
         for _ in range(6):
             sizes.append(((sizes[-1][0] - 1) // 2 + 1, (sizes[-1][1] - 1) // 2 + 1))
         a, h_, c = {}, {}, {}
-        for i, (cname, rname, ch) in enumerate(_ENC):
+        for i, (cname, rname, ch) in enumerate(self._enc):
             hh, ww = sizes[i]
             a[i], h_[i], c[i] = self._act(f"a{i}", hh, ww, ch), self._act(f"h{i}", hh, ww, ch), self._act(f"c{i}", hh, ww, ch)
             if i == 0:
@@ -295,7 +292,7 @@ class FalnetPlan:
         # ---- decoder ----
         d, ic = {}, {7: c[6]}
         for lvl in range(6, 0, -1):
-            dname, dch, iname, ich = _DEC[lvl]
+            dname, dch, iname, ich = self._dec[lvl]
             hh, ww = sizes[lvl - 1]
             below = ic[lvl + 1]  # tensor being upsampled (c6, then iconv outputs)
             d[lvl] = self._act(f"d{lvl}", hh, ww, dch)
@@ -330,6 +327,15 @@ class FalnetPlan:
                                          nbytes=(N + 7) * H * W * 4 * B)
         self.head_masks = ops.simple_call("falnet_med_masks_fwd", L.ptr(dlog0), L.ptr(mn), L.ptr(mx), L.ptr(stats),
                                           L.ptr(maskL), L.ptr(maskR), B, N, H, W)
+        if not ARCHS[m.arch]["maskr_align_corners"]:  # FAL_netA.py:264: maskR sampled with align_corners=False
+            both = self.head_masks
+            fix_r = ops.simple_call("falnet_med_maskr_acfalse_fwd", L.ptr(dlog0), L.ptr(mn), L.ptr(mx), L.ptr(stats), L.ptr(maskR),
+                                    B, N, H, W)
+
+            def masks_a():
+                both()
+                fix_r()
+            self.head_masks = masks_a
 
         # =========================== backward plan ===========================
         g_disp, g_pan = self._f32("g_disp", B, 1, H, W), self._f32("g_pan", B, 3, H, W)
@@ -363,11 +369,11 @@ class FalnetPlan:
             g_dlog = self._act("g_dlog", H, W, pad_c(N))
             self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
 
-        gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], _ENC[i][2]) for i in range(7)}
+        gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], self._enc[i][2]) for i in range(7)}
         # decoder, top (level 1) to bottom (level 6)
         g_ipre = {1: g_dlog}  # gradient wrt the pre-activation of iconv{lvl} (iconv1 has no activation)
         for lvl in range(1, 7):
-            dname, dch, iname, ich = _DEC[lvl]
+            dname, dch, iname, ich = self._dec[lvl]
             hh, ww = sizes[lvl - 1]
             below = ic[lvl + 1]
             bh, bw = below.shape[1], below.shape[2]
@@ -412,7 +418,7 @@ class FalnetPlan:
                 self._finish.append((2, len(self.bwd_body)))
             self._bucket = 1 if i >= 4 else (2 if i >= 1 else 3)
             tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
-            cname, rname, ch = _ENC[i]
+            cname, rname, ch = self._enc[i]
             hh, ww = sizes[i]
             gz = gc[i]
             pr1, pr2, pcc = pcs[rname + ".conv1"], pcs[rname + ".conv2"], pcs[cname]
@@ -462,9 +468,9 @@ class FalnetPlan:
     def _split_logits_grad(self):
         """dWc (composed 3x3 logits conv) -> dW3x3 = W1x1^T dWc and dW1x1 = dWc W3x3^T, added into the flat gradient buffer."""
         m = self.model
-        w1, w3 = m.conv0.weight.detach(), m.backbone.iconv1.weight.detach()
+        w1, w3 = m.conv0.weight.detach(), m._bb.iconv1.weight.detach()
         g = m._gwc.view(w1.shape[0], -1)
-        m._grad_view(m.backbone.iconv1.weight).view(w3.shape[0], -1).addmm_(w1.view(w1.shape[0], -1).t(), g)
+        m._grad_view(m._bb.iconv1.weight).view(w3.shape[0], -1).addmm_(w1.view(w1.shape[0], -1).t(), g)
         m._grad_view(m.conv0.weight).view(w1.shape[0], -1).addmm_(g, w3.view(w3.shape[0], -1).t())
 
     # ---- execution ----
@@ -551,11 +557,13 @@ class _FalnetFunction(torch.autograd.Function):
 
 
 class FAL_net(nn.Module):
-    def __init__(self, batchNorm, no_levels, compute_dtype=None):
+    def __init__(self, batchNorm, no_levels, compute_dtype=None, arch="B"):
         super().__init__()
         self.no_levels = no_levels
         self.no_fac = 1
-        self.backbone = BackBone(batchNorm, no_in=3, no_flow=1, no_out=self.no_levels)
+        self.arch = arch
+        # the attribute name is part of the checkpoint keys: backbone (FAL_netB.py:184) / BackBone (FAL_netA.py:183) / synth (FAL_netC.py:185)
+        setattr(self, ARCHS[arch]["prefix"], BackBone(batchNorm, no_in=3, no_flow=1, no_out=self.no_levels, arch=arch))
         self.softmax = nn.Softmax(dim=1)
         self.elu = nn.ELU(inplace=True)
         self.sigmoid = nn.Sigmoid()
@@ -566,6 +574,10 @@ class FAL_net(nn.Module):
         self._plans = {}
         self._flat = self._flat_grad = None
         self._anchor = None
+
+    @property
+    def _bb(self):
+        return getattr(self, ARCHS[self.arch]["prefix"])
 
     def weight_parameters(self):
         return [param for name, param in self.named_parameters() if "weight" in name]
@@ -628,13 +640,14 @@ class FAL_net(nn.Module):
     def gradient_buckets(self):
         """Contiguous element ranges of the flat gradient buffer, in the order backward finalises them."""
         named = self._trainable_named()
+        pre = ARCHS[self.arch]["prefix"]
         first = {}
         for (n, p), off in zip(named, self._offsets):
-            if n.startswith("backbone.deconv6"):
+            if n.startswith(pre + ".deconv6"):
                 first.setdefault("dec", off)
-            if n.startswith("backbone.conv4."):
+            if n.startswith(pre + ".conv4."):
                 first.setdefault("enc4", off)
-            if n.startswith("backbone.conv1."):
+            if n.startswith(pre + ".conv1."):
                 first.setdefault("enc1", off)
         total = self._flat.numel()
         return [(first["dec"], total), (first["enc4"], first["dec"]), (first["enc1"], first["enc4"]), (0, first["enc1"])]
@@ -674,25 +687,28 @@ class FAL_net(nn.Module):
             p.grad = v
 
     def _build_packed(self):
-        bb = self.backbone
+        bb = self._bb
+        enc, dec = ARCHS[self.arch]["enc"], ARCHS[self.arch]["dec"]
         P = {}
 
         def add(key, conv, groups, stride=1):
             P[key] = PackedConv(key, conv.weight, conv.bias, groups, stride)
         add("conv0", bb.conv0[0], [3])
-        add("conv1", bb.conv1[0], [32, 1], 2)
-        for i, cin in zip(range(2, 7), (64, 128, 256, 256, 256)):
-            add(f"conv{i}", getattr(bb, f"conv{i}")[0], [cin], 2)
-        for i, ch in enumerate((32, 64, 128, 256, 256, 256, 512)):
+        add("conv1", bb.conv1[0], [enc[0], 1], 2)
+        for i in range(2, 7):
+            add(f"conv{i}", getattr(bb, f"conv{i}")[0], [enc[i - 1]], 2)
+        for i, ch in enumerate(enc):
             rb = getattr(bb, f"conv{i}_1")
             add(f"conv{i}_1.conv1", rb.conv1, [ch])
             add(f"conv{i}_1.conv2", rb.conv2, [ch])
-        for lvl, (dcin, g0, g1) in {6: (512, 256, 256), 5: (256, 128, 256), 4: (256, 128, 256), 3: (256, 128, 128),
-                                    2: (128, 64, 64)}.items():
-            add(f"deconv{lvl}", getattr(bb, f"deconv{lvl}").conv1, [dcin])
-            add(f"iconv{lvl}", getattr(bb, f"iconv{lvl}")[0], [g0, g1])
-        add("deconv1", bb.deconv1.conv1, [64])
-        add("iconv1", bb.iconv1, [64, 32])
+        below = enc[6]
+        for lvl in range(6, 1, -1):
+            dch, ich = dec[lvl]
+            add(f"deconv{lvl}", getattr(bb, f"deconv{lvl}").conv1, [below])
+            add(f"iconv{lvl}", getattr(bb, f"iconv{lvl}")[0], [dch, enc[lvl - 1]])
+            below = ich
+        add("deconv1", bb.deconv1.conv1, [below])
+        add("iconv1", bb.iconv1, [64, enc[0]])
         add("conv0_1x1", self.conv0, [self.no_levels])
         # iconv1 (3x3, no bias, no activation; FAL_netB.py:127,174) followed by the 1x1 conv0 (FAL_netB.py:190,215) is ONE linear
         # map: the plans run a single 3x3 convolution with the composed weights Wc = W1x1 . W3x3 straight into the planar f32
@@ -705,7 +721,7 @@ class FAL_net(nn.Module):
             self._wc = torch.zeros(w1.shape[0], w3.shape[1], 3, 3, dtype=torch.float32, device=dev)
             self._gwc = torch.zeros_like(self._wc)
             self._gviews[id(self._wc)] = self._gwc
-            P["logits"] = PackedConv("logits", self._wc, self.conv0.bias, [64, 32], 1)
+            P["logits"] = PackedConv("logits", self._wc, self.conv0.bias, [64, enc[0]], 1)
         self._packed = P
 
     def _plan(self, B, H, W, device):

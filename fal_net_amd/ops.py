@@ -88,7 +88,7 @@ class PackedConv:
         self.cout, self.cin, kh, kw = weight.shape
         assert sum(groups_real) == self.cin and len(groups_real) <= 2
         self.taps = kh * kw
-        self.ksize = kh
+        self.ksize = kh if kh == kw else (kh, kw)  # (3, 1) / (1, 3): FAL_netA's separable residual convs
         self.groups_real = list(groups_real)
         self.groups_pad = [pad_c(c) for c in groups_real]
         self.cin_pad = sum(self.groups_pad)
@@ -166,15 +166,15 @@ def pack_all_call(pcs, dtype, device):
 
 
 def fwd_taps(ksize):
+    """(dy, dx, packed-weight tap index) of a 'same'-padded kernel: 1, 3 (3x3) or (kh, kw) for the 3x1 / 1x3 convs."""
     if ksize == 1:
         return [(0, 0, 0)]
-    return [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    KH, KW = (3, 3) if ksize == 3 else ksize
+    return [(kh - KH // 2, kw - KW // 2, kh * KW + kw) for kh in range(KH) for kw in range(KW)]
 
 
 def dgrad_taps_s1(ksize):
-    if ksize == 1:
-        return [(0, 0, 0)]
-    return [(1 - kh, 1 - kw, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+    return [(-dy, -dx, t) for dy, dx, t in fwd_taps(ksize)]
 
 
 def dgrad_taps_s2(py, px):

@@ -54,6 +54,17 @@ def _seeded(key, shape, bias_std=0.05):
     return torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5  # Kaiming-normal (FAL_netB.py:133)
 
 
+def seeded_state_dict(arch="B", no_levels=None):
+    """Seeded weights of FAL_netA / B / C in the reference's checkpoint key order (models/FAL_net{A,B,C}.py)."""
+    from .arch import ARCHS, conv_shapes
+    sd = OrderedDict()
+    for key, shape, has_bias in conv_shapes(arch, no_levels or ARCHS[arch]["no_levels"]):
+        sd[key + ".weight"] = _seeded(key + ".weight", shape)
+        if has_bias:
+            sd[key + ".bias"] = _seeded(key + ".bias", (shape[0],))
+    return sd
+
+
 def seeded_falnetb_state_dict(no_levels=49):
     """Seeded FAL_netB weights in the reference's checkpoint key order."""
     # the module registers parameters in construction order (encoder interleaved as below)

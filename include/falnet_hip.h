@@ -175,7 +175,7 @@ typedef struct {
 } falnet_biasgrad_t;
 typedef struct {
     const float* w; void* wf; void* wd;
-    int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps <= 9 */
+    int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps 9, 3 or 1 */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream);
@@ -236,6 +236,11 @@ int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, const float*
  * maskL = min(1, sum_n shift_{-s_n}(Dprob_n)).  Dprob is rebuilt from the logits and `stats`. */
 int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp, const float* stats,
                          float* maskL, float* maskR, int B, int N, int H, int W, void* stream);
+/* FAL_netA's right mask (models/FAL_netA.py:264): the same sum, but each plane is sampled with grid_sample's default
+ * align_corners=False on the align_corners=True grid (:231,:241-242) -- bilinear in x AND y at
+ * (x W/(W-1) + d_n - 1/2, y H/(H-1) - 1/2), zero padding.  Overwrites maskR; `stats` from falnet_med_head_fwd. */
+int falnet_med_maskr_acfalse_fwd(const float* dlog0, const float* min_disp, const float* max_disp, const float* stats,
+                                 float* maskR, int B, int N, int H, int W, void* stream);
 
 /* ---- losses (loss_functions.py) ; all write/accumulate a scalar in `out` (f32, device) ---- */
 /* out[0] (+)= scale * sum(mask * |a - b|) ; mask NULL or [B][1][H][W] broadcast over C (loss_functions.py:53) */

@@ -34,30 +34,56 @@ def _elu(x):
     return F.elu(x)
 
 
+def backbone_prefix(sd):
+    """Attribute name of the backbone in the checkpoint keys: `backbone` (FAL_netB.py:184), `BackBone` (FAL_netA.py:183)
+    or `synth` (FAL_netC.py:185).  The three variants share BackBone.forward; channel counts and the residual-conv
+    kernel shapes (3x1 / 1x3 in FAL_netA.py:73-75) are read off the weights themselves."""
+    for k in sd:
+        if k.endswith(".conv0.0.weight"):
+            return k[:-len(".conv0.0.weight")]
+    raise KeyError("no <backbone>.conv0.0.weight in the state dict")
+
+
 def _conv(sd, key, x, stride=1):
-    """3x3 pad-1 conv, bias if present in the checkpoint (FAL_netB.py:44-47)."""
-    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=stride, padding=1)
+    """'same'-padded conv (3x3 everywhere; 3x1 / 1x3 in FAL_netA's residual blocks), bias if present in the checkpoint
+    (FAL_netB.py:44-47, FAL_netA.py:73-76)."""
+    w = sd[key + ".weight"]
+    return F.conv2d(x, w, sd.get(key + ".bias"), stride=stride, padding=(w.shape[2] // 2, w.shape[3] // 2))
 
 
 def _conv_elu(sd, name, x, stride):
     # conv_elu, batchNorm=False branch: FAL_netB.py:44-48
-    return _elu(_conv(sd, f"backbone.{name}.0", x, stride))
+    return _elu(_conv(sd, f"{name}.0", x, stride))
 
 
 def _res_block(sd, name, x):
     # residual_block.forward: FAL_netB.py:78-80
-    h = _elu(_conv(sd, f"backbone.{name}.conv1", x))
-    return _elu(_conv(sd, f"backbone.{name}.conv2", h) + x)
+    h = _elu(_conv(sd, f"{name}.conv1", x))
+    return _elu(_conv(sd, f"{name}.conv2", h) + x)
 
 
 def _deconv(sd, name, x, ref):
     # deconv.forward: nearest resize to the skip's size then conv+ELU, FAL_netB.py:57-60
     x = F.interpolate(x, size=(ref.size(2), ref.size(3)), mode="nearest")
-    return _elu(_conv(sd, f"backbone.{name}.conv1", x))
+    return _elu(_conv(sd, f"{name}.conv1", x))
+
+
+class _Prefixed:
+    """state-dict view that prepends the backbone prefix to every key."""
+
+    def __init__(self, sd, prefix):
+        self.sd, self.p = sd, prefix + "."
+
+    def __getitem__(self, k):
+        return self.sd[self.p + k]
+
+    def get(self, k, default=None):
+        return self.sd.get(self.p + k, default)
 
 
 def backbone_forward(sd, x, flow):
-    """BackBone.forward, FAL_netB.py:140-176 -> raw logits `dlog` (B,N,H,W)."""
+    """BackBone.forward, FAL_netB.py:140-176 (= FAL_netA.py:139-175, FAL_netC.py:141-177) -> raw logits `dlog` (B,N,H,W)."""
+    sd = _Prefixed(sd, backbone_prefix(sd))
     c0 = _res_block(sd, "conv0_1", _conv_elu(sd, "conv0", x, 1))
     c1 = _res_block(sd, "conv1_1", _conv_elu(sd, "conv1", torch.cat((c0, flow), 1), 2))
     c2 = _res_block(sd, "conv2_1", _conv_elu(sd, "conv2", c1, 2))
@@ -71,7 +97,7 @@ def backbone_forward(sd, x, flow):
     i3 = _conv_elu(sd, "iconv3", torch.cat((_deconv(sd, "deconv3", i4, c2), c2), 1), 1)
     i2 = _conv_elu(sd, "iconv2", torch.cat((_deconv(sd, "deconv2", i3, c1), c1), 1), 1)
     cat1 = torch.cat((_deconv(sd, "deconv1", i2, c0), c0), 1)
-    return F.conv2d(cat1, sd["backbone.iconv1.weight"], None, padding=1)  # FAL_netB.py:127,174
+    return F.conv2d(cat1, sd["iconv1.weight"], None, padding=1)  # FAL_netB.py:127,174
 
 
 # --------------------------------------------------------------------------- MED head
@@ -107,7 +133,24 @@ def shift_planes(t, s):
     return (1.0 - a) * tap(i0) + a * tap(i1)
 
 
-def med_head(dlog0, left, min_disp, max_disp, ret_disp=True, ret_subocc=False, ret_pan=False):
+def _maskr_align_corners_false(sm, d):
+    """FAL_netA.py:264 samples softmax(dlog0) for maskR with grid_sample's DEFAULT align_corners=False on a grid built
+    with align_corners=True (:231,:241-242): pixel (x, y) reads (x*W/(W-1) + d_n - 0.5, y*H/(H-1) - 0.5), bilinear in both
+    axes with zero padding.  Restated with torch's own grid_sample (torch is the oracle for that arithmetic)."""
+    B, N, H, W = sm.shape
+    th = torch.zeros(B, 2, 3)
+    th[:, 0, 0] = 1
+    th[:, 1, 1] = 1
+    grid = F.affine_grid(th, [B, 1, H, W], align_corners=True)
+    acc = 0
+    for n in range(N):
+        g = grid.clone()
+        g[:, :, :, 0] = g[:, :, :, 0] + (2 * d[:, n] / W).view(B, 1, 1)
+        acc = acc + F.grid_sample(sm[:, n:n + 1], g, align_corners=False)
+    return acc
+
+
+def med_head(dlog0, left, min_disp, max_disp, ret_disp=True, ret_subocc=False, ret_pan=False, maskr_align_corners=True):
     """FAL_net.forward after conv0 (FAL_netB.py:216-297) in closed form.
 
     Returns a dict with the requested tensors: disp, p_im0, maskL, maskR, Dprob.
@@ -131,7 +174,10 @@ def med_head(dlog0, left, min_disp, max_disp, ret_disp=True, ret_subocc=False, r
         out["p_im0"] = p
     if ret_subocc:  # :264-273,291-292 (no grad)
         with torch.no_grad():
-            out["maskR"] = shift_planes(sm.detach(), s).sum(1, keepdim=True).clamp(max=1.0)
+            if maskr_align_corners:
+                out["maskR"] = shift_planes(sm.detach(), s).sum(1, keepdim=True).clamp(max=1.0)
+            else:
+                out["maskR"] = _maskr_align_corners_false(sm.detach(), d).clamp(max=1.0)
             out["maskL"] = shift_planes(dprob.detach(), -s).sum(1, keepdim=True).clamp(max=1.0)
     return out
 
@@ -144,7 +190,8 @@ def falnet_forward(sd, left, min_disp, max_disp, ret_disp=True, ret_subocc=False
     flow = (max_disp.view(B, 1, 1, 1) / 100.0).expand(B, 1, H, W)  # :208-209
     dlog = backbone_forward(sd, left, flow)
     dlog0 = F.conv2d(dlog, sd["conv0.weight"], sd["conv0.bias"])  # :215
-    out = med_head(dlog0, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan)
+    out = med_head(dlog0, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan,
+                   maskr_align_corners=backbone_prefix(sd) != "BackBone")  # FAL_netA.py:264
     out["dlog0"] = dlog0
     if return_dict:
         return out

@@ -241,6 +241,20 @@ def main():
     if args.only == "g9":
         return
 
+    # ---- G10: FAL_netA / FAL_netC (models/FAL_netA.py, FAL_netC.py): forward incl. masks + one Stage-1 step, N=33 ----
+    for arch, seed in (("A", 101), ("C", 102)):
+        def ref_variant():
+            return getattr(ref_models, "FAL_net" + arch)({"state_dict": synthetic.seeded_state_dict(arch, 33)}, no_levels=33)
+        left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=seed, distinct=True)
+        with torch.no_grad():
+            pan, disp, maskL, maskR = ref_variant().eval()(left, mn, mx, ret_disp=True, ret_subocc=True, ret_pan=True)
+        rec_d, rpan, ldisp = stage1(ref_variant(), left, right, mx)
+        np.savez(os.path.join(HERE, f"g10_falnet{arch}.npz"), seed=seed, max_disp=np32(mx), disp=np32(disp), p_im0=np32(pan)[:, :, ::2, ::2],
+                 maskL=np32(maskL), maskR=np32(maskR), **rec_d)
+        print("G10", arch, float(disp.mean()), rec_d["loss"], rec_d["rec"], rec_d["sm"])
+    if args.only == "g10":
+        return
+
     # ---- G4: config shape 256x512 N=49 B=1: strided outputs + Stage-1 scalars ----
     left, right, mn, mx = synthetic.synthetic_pair(1, 256, 512, seed=1234)
     rec_d, rpan, ldisp = stage1(ref_model(49), left, right, mx)

@@ -67,7 +67,17 @@ CONV_CASES = [
     (2, [32, 32], 64, 24, 71, 2, 3, True, L.ACT_ELU, False),    # stride 2, output wide enough for the parity-plane wgrad (odd W)
     (1, [64], 128, 16, 64, 2, 3, True, L.ACT_ELU, False),       # stride 2, even sizes, Cout 128
     (1, [128], 96, 9, 66, 2, 3, False, L.ACT_ELU, False),       # stride 2, odd H, Cout 96 (32-wide cout tiles)
+    (2, [64], 64, 12, 40, 1, (3, 1), False, L.ACT_ELU, False),  # FAL_netA residual block, first conv: 3x1 (FAL_netA.py:73)
+    (1, [128], 128, 9, 21, 1, (1, 3), False, L.ACT_ELU, True),  # FAL_netA residual block, second conv: 1x3 + residual (:75,:79)
 ]
+
+
+def _khw(k):
+    return (k, k) if isinstance(k, int) else k
+
+
+def _pad(k):
+    return (_khw(k)[0] // 2, _khw(k)[1] // 2)
 # W >= 32, dense 3x3 stride 1 -> the halo-patch kernel (conv.hip: conv3x3_patch_kernel), every instantiation
 PATCH_CASES = [
     (2, [32], 32, 12, 40, 1, 3, True, L.ACT_ELU, True),         # mode S, BN=32, ragged tiles
@@ -87,14 +97,15 @@ def _conv_inputs(case, seed=0):
     g = torch.Generator().manual_seed(seed)
     xs = [torch.randn(B, c, H, W, generator=g) for c in groups]
     cin = sum(groups)
-    w = torch.randn(Cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    kh, kw = _khw(k)
+    w = torch.randn(Cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1 if bias else None
     return xs, w, b
 
 
 def _ref_conv(case, xs, w, b, addend=None):
     B, groups, Cout, H, W, stride, k, bias, act, res = case
-    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=k // 2)
+    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=_pad(k))
     if addend is not None:
         y = y + addend
     if act == L.ACT_ELU:
@@ -304,7 +315,7 @@ def test_conv_backward(case, dtype):
     w.requires_grad_(True)
     if b is not None:
         b.requires_grad_(True)
-    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=k // 2)
+    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=_pad(k))
     gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
     y.backward(gy)
     OH, OW = y.shape[2], y.shape[3]

@@ -160,6 +160,56 @@ def test_stage1_slow_step_vs_golden(golden_dir):
         assert np.abs(after - g["after:" + k]).max() < 2e-5, k
 
 
+@pytest.mark.parametrize("arch", ["A", "C"])
+def test_falnet_variants_vs_golden(golden_dir, arch):
+    """FAL_netA (3x1 / 1x3 residual convs, `BackBone.` keys, maskR with align_corners=False) and FAL_netC (wider bottleneck,
+    `synth.` keys) on the shared launch plan, against goldens recorded from models/FAL_netA.py / FAL_netC.py: forward with
+    masks, then one Stage-1 step (losses, every gradient, weights after Adam)."""
+    from fal_net_amd import models as M
+    g = np.load(os.path.join(golden_dir, f"g10_falnet{arch}.npz"))
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    LF.set_compute_dtype(torch.float32)
+    sd = synthetic.seeded_state_dict(arch, 33)
+    m = getattr(M, "FAL_net" + arch)({"state_dict": sd}, no_levels=33, compute_dtype=torch.float32).to(DEV)
+    assert list(m.state_dict().keys()) == list(sd.keys())  # the reference's checkpoint layout, in its order
+    with torch.no_grad():
+        pan, disp, maskL, maskR = m.eval()(left.to(DEV), mn.to(DEV), mx.to(DEV), ret_disp=True, ret_subocc=True, ret_pan=True)
+    assert rel(disp, g["disp"]) < TOL
+    assert rel(pan[:, :, ::2, ::2], g["p_im0"]) < 2e-4
+    assert rel(maskL, g["maskL"]) < 2e-4
+    assert rel(maskR, g["maskR"]) < 2e-4
+    m.train()
+    opt = train.FlatAdam(m, lr=1e-4, betas=(0.5, 0.999))
+    out = train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV))
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, (k, float(out[k]), float(g[k]))
+    for k, p in m.named_parameters():
+        if ("nograd:" + k) in g.files:
+            assert p.grad is None
+            continue
+        gr, gn = p.grad.reshape(-1), float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - gn) / gn < 5e-4, k
+        assert np.abs(gr[sample_idx(k, gr.numel())].cpu().numpy() - g["gsamp:" + k]).max() <= 5e-4 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
+        assert np.abs(after - g["after:" + k]).max() < 2.5e-5, k
+
+
+@pytest.mark.parametrize("arch", ["A", "C"])
+def test_falnet_variants_bf16_step_runs(arch):
+    """bf16 throughput path of the variants: runs, finite, loss close to the f32 path's."""
+    from fal_net_amd import models as M
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=7, distinct=True)
+    losses = {}
+    for dt in (torch.float32, torch.bfloat16):
+        LF.set_compute_dtype(dt)
+        m = getattr(M, "FAL_net" + arch)({"state_dict": synthetic.seeded_state_dict(arch, 33)}, no_levels=33, compute_dtype=dt).to(DEV).train()
+        out = train.stage1_step(m, train.FlatAdam(m), left.to(DEV), right.to(DEV), mx.to(DEV))
+        losses[dt] = float(out["loss"])
+        assert torch.isfinite(m.flat_gradients()).all()
+    LF.set_compute_dtype(torch.float32)
+    assert abs(losses[torch.bfloat16] - losses[torch.float32]) / losses[torch.float32] < 3e-2, losses
+
+
 def test_bf16_step_runs_and_tracks_f32():
     """bf16 throughput path: same step, deviation reported (no 1e-4 gate; the reference is f32-only)."""
     left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=21, distinct=True)

@@ -126,6 +126,34 @@ def test_g9_stage1_slow_step(golden_dir):
         assert np.abs(after - g["after:" + k]).max() < 2e-5, k
 
 
+@pytest.mark.parametrize("arch", ["A", "C"])
+def test_g10_falnet_variants(golden_dir, arch):
+    """FAL_netA (separable residual convs, no amask_conv, maskR with align_corners=False) and FAL_netC (channel table,
+    `synth.` keys) against goldens recorded from the reference modules."""
+    g = load(golden_dir, f"g10_falnet{arch}.npz")
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=int(g["seed"]), distinct=True)
+    sd = synthetic.seeded_state_dict(arch, 33)
+    with torch.no_grad():
+        pan, disp, maskL, maskR = O.falnet_forward(sd, left, mn, mx, ret_disp=True, ret_subocc=True, ret_pan=True)
+    assert rel(disp.numpy(), g["disp"]) < TOL
+    assert rel(pan.numpy()[:, :, ::2, ::2], g["p_im0"]) < WARP_TOL
+    assert rel(maskL.numpy(), g["maskL"]) < WARP_TOL
+    assert rel(maskR.numpy(), g["maskR"]) < WARP_TOL
+    params = O.leaf_params(sd)
+    out = O.stage1_step(params, O.OracleAdam(params), synthetic.seeded_vgg19_state_dict(), left, right, mn, mx)
+    for k in ("loss", "rec", "sm"):
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < TOL, k
+    for k, p in params.items():
+        if ("nograd:" + k) in g.files:
+            assert out["grads"][k] is None
+            continue
+        gr, gn = out["grads"][k].reshape(-1), float(g["gnorm:" + k])
+        assert abs(float(gr.norm()) - gn) / gn < 1e-4, k
+        assert np.abs(gr[sample_idx(k, gr.numel())].numpy() - g["gsamp:" + k]).max() <= 1e-4 * gn + 1e-9, k
+        after = p.detach().reshape(-1)[sample_idx(k, p.numel())].numpy()
+        assert np.abs(after - g["after:" + k]).max() < 2e-5, k
+
+
 def test_g4_config_shape(golden_dir):
     g = load(golden_dir, "g4_config_256x512.npz")
     params, out = _stage1(int(g["seed"]), 1, 256, 512, 49, False)
