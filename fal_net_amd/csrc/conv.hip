@@ -702,11 +702,19 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
 // MFMAs instead of being exposed in front of every small MFMA group, so one or two waves per SIMD keep the matrix
 // pipe busy.  a_of(step, mt) / b_of(step, nt) return the 16-B fragment address of this lane.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
 // Hook(step) runs after the MFMAs of every step, pinned in program order: work that must ISSUE while the matrix pipe is
 // busy (global loads of the next block, the previous block's stores) instead of in front of / behind the whole sequence.
 template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, typename AOf, typename BOf, typename Hook = NoHook>
 __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT], Hook hook = Hook()) {
-    uint4 fa[3][MT], fb[3][NT];
+#ifndef FALNET_MMA_SLOTS
+#define FALNET_MMA_SLOTS 3
+#endif
+#ifndef FALNET_PIN_SCHED
+#define FALNET_PIN_SCHED 0
+#endif
+    constexpr int SLOTS = FALNET_MMA_SLOTS;  // fragment sets in flight (3: two steps ahead; 2: one step ahead, 1/3 fewer registers)
+    uint4 fa[SLOTS][MT], fb[SLOTS][NT];
     auto load = [&](int step, int slot) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[slot][mt] = *reinterpret_cast<const uint4*>(a_of(step, mt));
@@ -714,18 +722,18 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
         for (int nt = 0; nt < NT; ++nt) fb[slot][nt] = *reinterpret_cast<const uint4*>(b_of(step, nt));
     };
     load(0, 0);
-    if (NSTEP > 1) load(1, 1);
+    if (SLOTS > 2 && NSTEP > 1) load(1, 1);
+#if FALNET_PIN_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
-        if (st + 2 < NSTEP) load(st + 2, (st + 2) % 3);
-#ifndef FALNET_PIN_SCHED
-#define FALNET_PIN_SCHED 0
-#endif
+        if (st + SLOTS - 1 < NSTEP) load(st + SLOTS - 1, (st + SLOTS - 1) % SLOTS);
 #if FALNET_PIN_SCHED
-        // optional: pin the issue order (hipcc otherwise sinks the reads back next to their MFMAs); measured -0.8 % on the step
+        // optional: pin the issue order (hipcc otherwise sinks the reads back next to their MFMAs)
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        const int sl = st % 3;
+        const int sl = st % SLOTS;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -804,8 +812,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
     const int ty0 = tiy * TH, tx0 = tix * PT_TW;
     const int n0 = blockIdx.y * BN;
 
-    int nchunks = 0;
-    for (int s = 0; s < p.nsrc; ++s) nchunks += p.src[s].C / KCV;
+    // source descriptors in registers: a runtime-indexed p.src[s] inside the K loop is a scalar LOAD from the kernel-argument
+    // segment (plus its s_waitcnt) in front of every patch row -- in-kernel stamps: ~40 % of a tap was spent there
+    struct SrcRegs { const T* ptrb; int64_t sy; int H, C; };
+    const SrcRegs S0 = {reinterpret_cast<const T*>(p.src[0].ptr) + (int64_t)b * p.src[0].sb, p.src[0].sy, p.src[0].H, p.src[0].C};
+    const SrcRegs S1 = p.nsrc > 1 ? SrcRegs{reinterpret_cast<const T*>(p.src[1].ptr) + (int64_t)b * p.src[1].sb, p.src[1].sy, p.src[1].H, p.src[1].C} : S0;
+    const int nsrc = p.nsrc, IH = p.IH;
+    int nchunks = S0.C / KCV + (nsrc > 1 ? S1.C / KCV : 0);
 
     // ---- loop-invariant per-thread load descriptors (no divisions / 64-bit multiplies in the main loop) ----
     // patch row slots: this thread's (column, segment) inside ANY patch row, per source (upsampling differs)
@@ -854,11 +867,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
 
     // one patch row `pr` of source s / channel offset c0 -> registers
     auto patch_row_load = [&](int pr, int s, int c0, uint4 (&regs)[A_SLOTS]) {
-        const falnet_src_t& S = p.src[s];
+        const T* sptr = s == 0 ? S0.ptrb : S1.ptrb;
+        const int64_t ssy = s == 0 ? S0.sy : S1.sy;
+        const int sH = s == 0 ? S0.H : S1.H;
         int vy = ty0 - 1 + pr;
-        const bool rowok = pr < TH + 2 && vy >= 0 && vy < p.IH;
-        if (S.H != p.IH) vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
-        const T* base = reinterpret_cast<const T*>(S.ptr) + (int64_t)b * S.sb + (int64_t)vy * S.sy + c0;
+        const bool rowok = pr < TH + 2 && vy >= 0 && vy < IH;
+        if (sH != IH) vy = (2 * sH == IH) ? (vy >> 1) : (int)(((int64_t)vy * sH) / IH);
+        const T* base = sptr + (int64_t)vy * ssy + c0;
 #pragma unroll
         for (int u = 0; u < A_SLOTS; ++u) {
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -924,9 +939,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
     auto advance = [&](int& s, int& c0, int& kofs) {
         c0 += KCV;
         kofs += KCV;
-        if (s < 2 && c0 >= p.src[s].C) {
+        if (s < 2 && c0 >= (s == 0 ? S0.C : S1.C)) {
             c0 = 0;
-            s = s + 1 < p.nsrc ? s + 1 : s;
+            s = s + 1 < nsrc ? s + 1 : s;
         }
     };
     // all (8+2) rows are requested before the first one is stored: ONE memory round trip, not ten
@@ -989,6 +1004,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
             advance(s_, c0_, kofs_);
         }
     } else {
+        // mode P.  In-kernel phase stamps (tools/p_stamps.py, 256->256 @64x128, one workgroup of 8 waves per CU): per tap ~40 % of
+        // the time passes while the waves sit in the ISSUE of this tap's 1-3 global loads (12 KB per workgroup through the CU's
+        // load path), ~40 % in fragment reads + MFMAs, 2 % waiting for the loads at the store, the rest in LDS stores and the
+        // barrier.  Tried and measured slower or equal: requesting tiles two taps ahead (hand-counted vmcnt, +25 % time: the
+        // extra loads queue in issue, not in flight), pinning all fragment reads in front of the MFMAs (+2..7 %), hoisting the
+        // source descriptors out of the loop (0 %; kept), letting only the second wave of every SIMD load (0 %).  s_memtime ticks
+        // over the launch time give an in-kernel clock of ~1.57 GHz: the matrix pipe is busy ~42 % of a tap at THAT clock.
         // prologue: patch of chunk 0 and the weight tile of (chunk 0, tap 0), all loads in flight together
         {
             uint4 regs[B_SLOTS];
@@ -999,6 +1021,23 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         __syncthreads();
         int sn = s_, c0n = c0_, kofsn = kofs_;  // next chunk
         advance(sn, c0n, kofsn);
+#ifdef FALNET_P_STAMPS
+        // profiling build (tools/p_stamps.py): per-phase s_memtime sums of workgroup 0, every wave -> p.splitk_ws
+        unsigned int ph_sum[5] = {0, 0, 0, 0, 0};
+        unsigned long long t_prev;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#define P_STAMP(k)                                                                      \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long t_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        ph_sum[k] += (unsigned int)(t_ - t_prev);                                       \
+        t_prev = t_;                                                                    \
+    } while (0)
+#else
+#define P_STAMP(k) do {} while (0)
+#endif
         for (int c = 0; c < nchunks; ++c) {
             const bool next_chunk = ADB && (c + 1 < nchunks);
             const char* Acur = Abuf(c & 1);
@@ -1013,19 +1052,34 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
                     patch_row_load(g, sn, c0n, areg0);
                     if (RPT > 1 && g + 9 < TH + 2) patch_row_load(g + 9, sn, c0n, areg1);
                 }
+                P_STAMP(0);  // loads issued
                 compute_taps(Acur, Bbuf((c + g) & 1), std::integral_constant<int, g>{}, std::integral_constant<int, 1>{});
+                P_STAMP(1);  // fragment reads + MFMAs issued
+#ifdef FALNET_P_STAMPS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                P_STAMP(2);  // this tap's loads landed
+#endif
                 if (more) w_tile_store(Bbuf((c + g + 1) & 1), breg);
                 if (next_chunk) {
                     patch_row_store(Anext, g, areg0);
                     if (RPT > 1 && g + 9 < TH + 2) patch_row_store(Anext, g + 9, areg1);
                 }
+                P_STAMP(3);  // LDS stores issued
                 __syncthreads();
+                P_STAMP(4);  // barrier
             });
             s_ = sn;
             c0_ = c0n;
             kofs_ = kofsn;
             advance(sn, c0n, kofsn);
         }
+#ifdef FALNET_P_STAMPS
+        if (p.splitk_ws && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+            for (int k = 0; k < 5; ++k) p.splitk_ws[wave * 8 + k] = (float)ph_sum[k];
+            p.splitk_ws[wave * 8 + 5] = (float)(9 * nchunks);
+        }
+#endif
+#undef P_STAMP
     }
 
     // ---- epilogue (same contract as the gather kernel), straight from the accumulators: 16-B stores, no LDS ----
