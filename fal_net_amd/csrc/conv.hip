@@ -702,18 +702,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
 // MFMAs instead of being exposed in front of every small MFMA group, so one or two waves per SIMD keep the matrix
 // pipe busy.  a_of(step, mt) / b_of(step, nt) return the 16-B fragment address of this lane.
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+#ifndef FALNET_PIN_S
+#define FALNET_PIN_S 0        // nine-tap stages of the halo-patch kernel: 1 = pinned fragment prefetch
+#define FALNET_PIN_SLOTS_S 3  // ... 2 = one step ahead
+#define FALNET_PIN_WS 0       // weight-stationary kernel: 1 = pinned, two steps ahead
+#endif
 
 // Hook(step) runs after the MFMAs of every step, pinned in program order: work that must ISSUE while the matrix pipe is
 // busy (global loads of the next block, the previous block's stores) instead of in front of / behind the whole sequence.
-template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, typename AOf, typename BOf, typename Hook = NoHook>
+template <typename T, int MT, int NT, int NSTEP, bool SWAPAB = false, int SLOTS = 3, bool PIN = false, typename AOf, typename BOf, typename Hook = NoHook>
 __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][NT], Hook hook = Hook()) {
-#ifndef FALNET_MMA_SLOTS
-#define FALNET_MMA_SLOTS 3
-#endif
-#ifndef FALNET_PIN_SCHED
-#define FALNET_PIN_SCHED 0
-#endif
-    constexpr int SLOTS = FALNET_MMA_SLOTS;  // fragment sets in flight (3: two steps ahead; 2: one step ahead, 1/3 fewer registers)
+    // SLOTS fragment sets in flight (3: reads two steps ahead; 2: one step ahead, a third fewer registers).  PIN: keep that issue
+    // order with sched_barriers -- hipcc otherwise sinks the reads back next to their MFMAs.  Same-box A/B: launched alone with
+    // warm caches, pinned is 4-7 % faster in the nine-tap stages and in the weight-stationary kernel and 2-7 % SLOWER in the
+    // one-tap-per-stage loop; inside the training step (pinned only where it won) the step time and the serial kernel sum do
+    // not move (1124 vs 1124 pairs/s, two alternating runs) -- the chip holds ~1.57 GHz under this load and returns issue
+    // savings as clock -- so the default stays unpinned.
     uint4 fa[SLOTS][MT], fb[SLOTS][NT];
     auto load = [&](int step, int slot) {
 #pragma unroll
@@ -723,16 +727,11 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
     };
     load(0, 0);
     if (SLOTS > 2 && NSTEP > 1) load(1, 1);
-#if FALNET_PIN_SCHED
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         if (st + SLOTS - 1 < NSTEP) load(st + SLOTS - 1, (st + SLOTS - 1) % SLOTS);
-#if FALNET_PIN_SCHED
-        // optional: pin the issue order (hipcc otherwise sinks the reads back next to their MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         const int sl = st % SLOTS;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -926,7 +925,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
         constexpr int t0 = decltype(t0c)::value, NTAPS = decltype(ntapsc)::value;
         const char* ab = A + a_lane;
         const char* bb = Btile + b_lane;
-        mma_steps<T, MT, NT, NTAPS * KSEG, true>(
+        mma_steps<T, MT, NT, NTAPS * KSEG, true, (NTAPS > 1 ? FALNET_PIN_SLOTS_S : 3), (NTAPS > 1 && FALNET_PIN_S)>(
             [&](int st, int mt) { const int t = t0 + st / KSEG, ks = st % KSEG;
                                   return ab + (mt * PT_PW * PITCH + ((t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
             [&](int st, int nt) { const int tt = st / KSEG, ks = st % KSEG;
@@ -1277,7 +1276,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
         // steps: (chunk, tap, k-segment), all operand addresses = lane base + immediate
-        mma_steps<T, MT, NT, NCH * 9 * KSEG, true>(
+        mma_steps<T, MT, NT, NCH * 9 * KSEG, true, 3, FALNET_PIN_WS>(
             [&](int st, int mt) { const int c = st / (9 * KSEG), t = (st / KSEG) % 9, ks = st % KSEG;
                                   return ab + ((c * NPIX + mt * PT_PW + (t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
             [&](int st, int nt) { const int tc = st / KSEG, ks = st % KSEG;

@@ -443,7 +443,7 @@ class WgradBatch:
     region, so they can run back to back) followed by ONE batched slab reduce and ONE batched bias-gradient launch
     that add into the (pre-zeroed or accumulating) flat gradient buffer."""
 
-    SLAB_CAP = 32 << 20  # bytes of partial slabs per layer
+    SLAB_CAP = int(os.environ.get("FALNET_SLAB_CAP_MB", "32")) << 20  # bytes of partial slabs per layer
 
     def __init__(self, dtype, device):
         self.dtype, self.device = dtype, device
