@@ -2704,6 +2704,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     bool c128 = true;  // every source is a whole number of 128-B channel chunks
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
     int variant = p.variant;
+    // 11 / 12: the gather kernel with 32 / 64 output channels per workgroup (instead of the widest tile that divides the layer):
+    // 4x / 2x the workgroups for the small deep layers, whose launches otherwise occupy a fraction of the 256 CUs
+    int forced_bn = 0;
+    if (variant == 11 || variant == 12) {
+        forced_bn = variant == 11 ? 32 : 64;
+        if (p.w_rows % forced_bn != 0 || p.pool_out) {
+            falnet_set_error("conv2d: variant %d (gather, %d channels per workgroup) not applicable to this launch", variant, forced_bn);
+            return -2;
+        }
+        variant = 1;
+    }
     if (g_disable_patch) variant = 1;
     FALNET_CHECK_ARG(variant >= 0 && variant <= 10, "conv2d: unknown variant %d", variant);
     if (variant == 10) {
@@ -2743,7 +2754,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         return -2;
     }
     if (!c.patch) {
-        c.bn = (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (bn64 ? 64 : 32);
+        c.bn = forced_bn ? forced_bn : (p.w_rows % 128 == 0 && p.Cout > 64) ? 128 : (bn64 ? 64 : 32);
         c.kcb = 64; c.tps = 1; c.adb = 0; c.th = 0; c.nwaves = 4;
         return 0;
     }
@@ -2914,7 +2925,7 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
             if (int r = check_src(p.src[s], p.dtype == FALNET_BF16 ? 32 : 16, "conv2d_multi")) return r;
         ConvChoice c;
         falnet_conv_t q = p;
-        q.variant = 1;
+        q.variant = (p.variant == 11 || p.variant == 12) ? p.variant : 1;  // member 0's tile width is the launch's
         if (int r = choose_conv_kernel(q, c)) return r;
         if (i == 0) c0 = c;
         const int64_t M = (int64_t)p.B * p.TH * p.TW;

@@ -184,16 +184,20 @@ class FalnetPlan:
                     members.append(self._conv_call(*args, autotune=False, **kw))
                     singles.append(self._conv_call(*args, **kw))
             multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
+            multis = [multi]
+            if ops.GATHER_NARROW and B * IH * IW // 4 <= 32768:  # small levels: narrower workgroups fill more of the chip
+                multis += [ops.conv_multi_call(members, name="dgrad(s2 x4) " + name, bn=nb) for nb in (64, 32)
+                           if nb < ops.gather_bn(cg, cg) and cg % nb == 0]
 
             def separate(calls=tuple(singles)):
                 for c in calls:
                     c()
             import os as _os
-            chosen = ops.best_of(multi, separate) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
-            if chosen is multi:
-                self.bwd_body.append(multi)
-            else:
+            chosen = ops.best_of(*multis, separate) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
+            if chosen is separate:
                 self.bwd_body.extend(singles)
+            else:
+                self.bwd_body.append(chosen)
 
     def _wgrad(self, pc, srcs, IH, IW, gout, name="", on_main=False):
         OH, OW = gout.shape[1], gout.shape[2]

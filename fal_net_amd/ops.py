@@ -262,8 +262,8 @@ def _splitk_workspace(device, owner=None, nbytes=32 << 20):
     return _SPLITK_WS[key]
 
 
-def best_of(call_a, call_b, reps=5):
-    """Plan-build-time choice between two equivalent launch sequences (zero-argument callables)."""
+def best_of(*calls, reps=5):
+    """Plan-build-time choice between equivalent launch sequences (zero-argument callables); ties go to the earlier one."""
     def t(c):
         c()
         best = None
@@ -276,20 +276,30 @@ def best_of(call_a, call_b, reps=5):
             e1.synchronize()
             best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
         return best
-    return call_a if t(call_a) <= t(call_b) else call_b
+    times = [t(c) for c in calls]
+    return calls[times.index(min(times))]
 
 
-def conv_multi_call(calls, name="conv multi"):
-    """Fuse up to four conv_call launches (built with autotune off: gather kernel) into one falnet_conv2d_multi."""
+GATHER_NARROW = os.environ.get("FALNET_GATHER_NARROW", "0") == "1"  # opt-in: autotune also tries 32 / 64-channel gather workgroups on small layers (same-box A/B: no gain)
+
+
+def gather_bn(w_rows, Cout):
+    """Output channels per workgroup the gather kernel picks by itself (conv.hip: choose_conv_kernel)."""
+    return 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
+
+
+def conv_multi_call(calls, name="conv multi", bn=None):
+    """Fuse up to four conv_call launches (built with autotune off: gather kernel) into one falnet_conv2d_multi.
+    bn = 32 / 64: narrower workgroups than the default (variants 11 / 12: more workgroups for small layers)."""
     lib = L.lib()
     n = len(calls)
     arr = (L.Conv * n)()
     for i, c in enumerate(calls):
         C.memmove(C.byref(arr[i]), C.byref(c.desc), C.sizeof(L.Conv))
-        arr[i].variant, arr[i].ksplit = 1, 1
+        arr[i].variant, arr[i].ksplit = {32: 11, 64: 12}.get(bn, 1), 1
     keep = (arr, calls)
     dn = "DF16b" if arr[0].dtype == L.BF16 else "f"
-    bn = 128 if (arr[0].w_rows % 128 == 0 and arr[0].Cout > 64) else (64 if (arr[0].w_rows % 64 == 0 and arr[0].Cout > 32) else 32)
+    bn = bn or gather_bn(arr[0].w_rows, arr[0].Cout)
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d_multi(arr, n, L.stream_ptr()), name)
@@ -308,6 +318,13 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     wgs = ((M + 127) // 128) * ((Cout + bn - 1) // bn)
     if wgs < 256 and M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
         cands += [(1, k) for k in (2, 4, 8, 16) if wgs * k <= 2048]
+    if wgs < 256 and GATHER_NARROW:  # narrower workgroups (gather variants 11 / 12 = 32 / 64 channels): 2-4x the workgroups without split-K's second pass
+        for v, nb in ((12, 64), (11, 32)):
+            if nb < bn and w_rows % nb == 0:
+                w2 = ((M + 127) // 128) * ((Cout + nb - 1) // nb)
+                cands += [(v, 1)]
+                if M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
+                    cands += [(v, k) for k in (2, 4) if w2 * k <= 2048]
     cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1), (10, 1)]
     if wgs < 512:
         cands += [(8, 1), (9, 1)]

@@ -4,7 +4,7 @@
 rev=$1; tag=$2; tmp=$(mktemp -d)
 git -C "$(dirname "$0")/.." archive "$rev" fal_net_amd/csrc include | tar -x -C "$tmp"
 objs=""
-for f in api.cpp med_head.hip losses.hip elementwise.hip conv.hip; do
+for f in api.cpp med_head.hip losses.hip elementwise.hip data.hip conv.hip; do
   x=""; [[ $f == *.hip ]] && x="-x hip"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function $x -c "$tmp/fal_net_amd/csrc/$f" -o "$tmp/$f.o" &
   objs="$objs $tmp/$f.o"
