@@ -31,7 +31,7 @@ def main():
     import models
     dev = torch.device('cuda', 0)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    data = torch.load(args.model_dir, map_location='cpu') if args.model_dir else {'state_dict': synthetic.seeded_falnetb_state_dict(args.no_levels)}
+    data = torch.load(args.model_dir, map_location='cpu') if args.model_dir else {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
     pan_model = models.__dict__[args.m_model](data, no_levels=args.no_levels, compute_dtype=dtype).to(dev).eval()
     left, _, _, _ = synthetic.synthetic_pair(1, args.height, args.width, seed=7)
     left = left.to(dev)

@@ -50,7 +50,7 @@ def main():
     LF.set_compute_dtype(dtype)
 
     def load(path):
-        return torch.load(path, map_location='cpu') if path else {'state_dict': synthetic.seeded_falnetb_state_dict(args.no_levels)}
+        return torch.load(path, map_location='cpu') if path else {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
     m_model = models.__dict__[args.m_model](load(args.pretrained), no_levels=args.no_levels, compute_dtype=dtype).to(dev).train()
     fix_model = models.__dict__[args.m_model](load(args.fix_model), no_levels=args.no_levels, compute_dtype=dtype).to(dev).eval()
     for p in fix_model.parameters():

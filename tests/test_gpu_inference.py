@@ -56,6 +56,10 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     ["Train_Stage1_K.py", "--synthetic", "--gpu-augment", "--epochs", "1", "--epoch_size", "2", "-b", "2", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage1_Kslow.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage2_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
+    # the other two model variants through the same scripts (FAL_netA: 3x1 / 1x3 residual convs + its align_corners=False right mask in Stage 2)
+    ["Test_KITTI.py", "-mm", "FAL_netA", "-no_levels", "33", "--height", "96", "--width", "320", "--iters", "2", "--dtype", "f32"],
+    ["Train_Stage1_K.py", "-mm", "FAL_netC", "-no_levels", "33", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
+    ["Train_Stage2_K.py", "-mm", "FAL_netA", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
 ])
 def test_entry_scripts_synthetic(cmd, tmp_path):
     extra = ["--save-path", str(tmp_path)] if cmd[0].startswith("Train_Stage1_K") else []
