@@ -210,6 +210,28 @@ def test_falnet_variants_bf16_step_runs(arch):
     assert abs(losses[torch.bfloat16] - losses[torch.float32]) / losses[torch.float32] < 3e-2, losses
 
 
+def test_stage2_step_falnetA_vs_oracle():
+    """Stage-2 step with FAL_netA: its right occlusion mask (align_corners=False sampling, FAL_netA.py:264) feeds O_R, the masked
+    reconstruction and the mirror loss.  Checked against the oracle (pinned for FAL_netA's masks by g10, for the Stage-2 body by g3)."""
+    from fal_net_amd import models as M
+    LF.set_compute_dtype(torch.float32)
+    sd = synthetic.seeded_state_dict("A", 7)
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=33, distinct=True)
+    m = M.FAL_netA({"state_dict": sd}, no_levels=7, compute_dtype=torch.float32).to(DEV).train()
+    fix = M.FAL_netA({"state_dict": sd}, no_levels=7, compute_dtype=torch.float32).to(DEV).eval()
+    out = train.stage2_step(m, fix, train.FlatAdam(m, lr=5e-5), left.to(DEV), right.to(DEV), mx.to(DEV))
+    params = O.leaf_params(sd)
+    ref = O.stage2_losses(params, sd, synthetic.seeded_vgg19_state_dict(), left, right, mn, mx)
+    for k in ("loss", "rec", "sm", "mirror"):
+        assert abs(float(out[k]) - float(ref[k])) / abs(float(ref[k])) < TOL, (k, float(out[k]), float(ref[k]))
+    for k in ("O_L", "O_R"):
+        assert rel(out[k], ref[k]) < 2e-4, k
+    ref["loss"].backward()
+    for k, p in m.named_parameters():
+        gn = float(params[k].grad.norm())
+        assert abs(float(p.grad.norm()) - gn) / gn < 1e-3, k
+
+
 def test_bf16_step_runs_and_tracks_f32():
     """bf16 throughput path: same step, deviation reported (no 1e-4 gate; the reference is f32-only)."""
     left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=21, distinct=True)
