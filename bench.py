@@ -193,7 +193,7 @@ def main():
     pairs_per_s = world * args.batch * args.steps / elapsed
 
     result = {
-        "metric": "stereo-pairs/sec Stage-1 step @256x512 N=49",
+        "metric": f"stereo-pairs/sec Stage-1 step @{args.height}x{args.width} N={args.levels}",
         "value": pairs_per_s, "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
