@@ -28,6 +28,17 @@ def sample_idx(key, numel, k=16):
     return g.integers(0, numel, size=min(k, numel))
 
 
+def check_after_adam(after, golden_after, golden_gsamp, gnorm, numel, key, tol=2.5e-5, lr=1e-4):
+    """Weights after the FIRST Adam step: the update is lr * g / (|g| + eps) = +-lr for every element whose gradient is not ~0, so
+    a sampled element whose gradient lies within run-to-run noise of zero (f32 atomics reorder the split-K sums) can land on the
+    other sign: 2*lr away.  Elements with |g| > 1 % of the tensor's RMS gradient are sign-stable and must match tightly; the
+    others may differ by at most that flip."""
+    d = np.abs(after - golden_after)
+    stable = np.abs(golden_gsamp) > 1e-2 * gnorm / np.sqrt(numel)
+    assert d[stable].max(initial=0.0) < tol, key
+    assert d.max(initial=0.0) < 2 * lr + tol, key
+
+
 def build(n_levels, dtype=torch.float32):
     LF.set_compute_dtype(dtype)
     m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(n_levels)}, no_levels=n_levels, compute_dtype=dtype)
@@ -55,7 +66,7 @@ def test_stage1_step_vs_golden(golden_dir):
         idx = sample_idx(k, gr.numel())
         assert np.abs(gr[idx].cpu().numpy() - g["gsamp:" + k]).max() <= 5e-4 * gn + 1e-9, k
         after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
-        assert np.abs(after - g["after:" + k]).max() < 2.5e-5, k  # first Adam step moves by ~lr=1e-4
+        check_after_adam(after, g["after:" + k], g["gsamp:" + k], gn, p.numel(), k)  # first Adam step moves by ~lr=1e-4
 
 
 def test_stage1_config_shape_vs_golden(golden_dir):
@@ -157,7 +168,7 @@ def test_stage1_slow_step_vs_golden(golden_dir):
         assert abs(float(gr.norm()) - gn) / gn < 1e-3, k
         assert np.abs(gr[sample_idx(k, gr.numel())].cpu().numpy() - g["gsamp:" + k]).max() <= 1e-3 * gn + 1e-9, k
         after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
-        assert np.abs(after - g["after:" + k]).max() < 2e-5, k
+        check_after_adam(after, g["after:" + k], g["gsamp:" + k], gn, p.numel(), k)
 
 
 @pytest.mark.parametrize("arch", ["A", "C"])
@@ -191,7 +202,7 @@ def test_falnet_variants_vs_golden(golden_dir, arch):
         assert abs(float(gr.norm()) - gn) / gn < 5e-4, k
         assert np.abs(gr[sample_idx(k, gr.numel())].cpu().numpy() - g["gsamp:" + k]).max() <= 5e-4 * gn + 1e-9, k
         after = p.detach().reshape(-1)[sample_idx(k, p.numel())].cpu().numpy()
-        assert np.abs(after - g["after:" + k]).max() < 2.5e-5, k
+        check_after_adam(after, g["after:" + k], g["gsamp:" + k], gn, p.numel(), k)
 
 
 @pytest.mark.parametrize("arch", ["A", "C"])
