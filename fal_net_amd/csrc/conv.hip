@@ -638,13 +638,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(const falnet_c
 // classes of a stride-2 data gradient, which are otherwise four small latency-bound launches.
 struct falnet_conv4_t { falnet_conv_t c[4]; };
 template <typename T, int BN>
-__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_multi_kernel(const falnet_conv4_t pp) {
-    conv_igemm_body<T, BN, false>(pp.c[blockIdx.z], 0, 1);
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_multi_kernel(const falnet_conv4_t pp, int ksplit) {
+    // blockIdx.z = member * ksplit + K slice (ksplit > 1: f32 atomics into the MEMBER's own splitk_ws region, then
+    // splitk_epilogue_multi_kernel)
+    conv_igemm_body<T, BN, false>(pp.c[blockIdx.z / ksplit], blockIdx.z % ksplit, ksplit);
 }
 
 // split-K epilogue: ws[m][n] (f32 sums) -> bias / residual / activation / activation-gradient -> NHWC output
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_t p) {
+__device__ __forceinline__ void splitk_epilogue_body(const falnet_conv_t& p) {
     // Reads the f32 sums the split-K workgroups accumulated with atomics, applies the epilogue, and ZEROES what it read:
     // the workspace is all-zero between launches (contract of falnet_conv_t::splitk_ws), so no memset dispatch is needed
     // in front of the next split-K launch (~40 per training step, each a ~5 us hole on the critical stream).
@@ -684,6 +686,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_
         t.set8(v);
         t.store(out + off);
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const falnet_conv_t p) {
+    splitk_epilogue_body<T>(p);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_epilogue_multi_kernel(const falnet_conv4_t pp) {  // blockIdx.y = member
+    splitk_epilogue_body<T>(pp.c[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------------------------------ 3x3 halo-patch kernel
@@ -2919,8 +2929,17 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
     for (int i = 0; i < n; ++i) {
         const falnet_conv_t& p = descs[i];
         FALNET_CHECK_ARG(p.dtype == descs[0].dtype && p.w_rows == descs[0].w_rows && p.Cout == descs[0].Cout && p.out_layout == FALNET_OUT_NHWC &&
-                         p.ksplit <= 1 && p.nsrc >= 1 && p.nsrc <= 2 && p.weight && p.out && p.ntaps >= 1 && p.ntaps <= 9,
-                         "conv2d_multi: members must share dtype / Cout / w_rows and be plain NHWC gather launches");
+                         p.ksplit == descs[0].ksplit && p.nsrc >= 1 && p.nsrc <= 2 && p.weight && p.out && p.ntaps >= 1 && p.ntaps <= 9,
+                         "conv2d_multi: members must share dtype / Cout / w_rows / ksplit and be plain NHWC gather launches");
+        if (p.ksplit > 1) {  // every member accumulates into its OWN all-zero workspace region
+            const int64_t need = (int64_t)p.B * p.TH * p.TW * p.w_rows * 4;
+            FALNET_CHECK_ARG(p.splitk_ws && p.Cout % 8 == 0 && need <= p.splitk_ws_bytes, "conv2d_multi: split-K needs a workspace of %lld bytes per member", (long long)need);
+            for (int j = 0; j < i; ++j) {
+                const char* a = (const char*)p.splitk_ws; const char* bq = (const char*)descs[j].splitk_ws;
+                const int64_t needj = (int64_t)descs[j].B * descs[j].TH * descs[j].TW * descs[j].w_rows * 4;
+                FALNET_CHECK_ARG(a + need <= bq || bq + needj <= a, "conv2d_multi: split-K workspace regions of members %d and %d overlap", j, i);
+            }
+        }
         for (int s = 0; s < p.nsrc; ++s)
             if (int r = check_src(p.src[s], p.dtype == FALNET_BF16 ? 32 : 16, "conv2d_multi")) return r;
         ConvChoice c;
@@ -2933,17 +2952,24 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
         pp.c[i] = p;
     }
     for (int i = n; i < 4; ++i) pp.c[i] = descs[0];
-    const dim3 grid((unsigned)((maxM + CONV_BM - 1) / CONV_BM), (unsigned)((descs[0].Cout + c0.bn - 1) / c0.bn), (unsigned)n);
+    const int ksplit = descs[0].ksplit > 1 ? descs[0].ksplit : 1;
+    const dim3 grid((unsigned)((maxM + CONV_BM - 1) / CONV_BM), (unsigned)((descs[0].Cout + c0.bn - 1) / c0.bn), (unsigned)(n * ksplit));
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_MULTI(T)                                                                                              \
     do {                                                                                                             \
-        if (c0.bn == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 128>), grid, dim3(CONV_THREADS), 0, st, pp); \
-        else if (c0.bn == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 64>), grid, dim3(CONV_THREADS), 0, st, pp); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 32>), grid, dim3(CONV_THREADS), 0, st, pp);  \
+        if (c0.bn == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 128>), grid, dim3(CONV_THREADS), 0, st, pp, ksplit); \
+        else if (c0.bn == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 64>), grid, dim3(CONV_THREADS), 0, st, pp, ksplit); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 32>), grid, dim3(CONV_THREADS), 0, st, pp, ksplit);  \
     } while (0)
     if (descs[0].dtype == FALNET_BF16) LAUNCH_MULTI(bf16_t);
     else LAUNCH_MULTI(float);
 #undef LAUNCH_MULTI
+    if (ksplit > 1) {
+        const int64_t total = maxM * (descs[0].w_rows / 8);
+        const dim3 eg((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), (unsigned)n);
+        if (descs[0].dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_multi_kernel<bf16_t>, eg, dim3(256), 0, st, pp);
+        else hipLaunchKernelGGL(splitk_epilogue_multi_kernel<float>, eg, dim3(256), 0, st, pp);
+    }
     FALNET_RETURN_LAUNCH();
 }
 

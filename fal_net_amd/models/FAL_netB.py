@@ -185,6 +185,15 @@ class FalnetPlan:
                     singles.append(self._conv_call(*args, **kw))
             multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
             multis = [multi]
+            if ops.AUTOTUNE and os.environ.get("FALNET_S2_SPLITK", "1") == "1":
+                # small levels: the four classes as ONE split-K launch + ONE epilogue instead of one long-K launch or 4 x (split-K + epilogue)
+                wgs = 4 * ((B * ((IH + 1) // 2) * ((IW + 1) // 2) + 127) // 128) * ((cg + ops.gather_bn(cg, cg) - 1) // ops.gather_bn(cg, cg))
+                for k in (2, 4, 8):
+                    if wgs * k <= 2048 and wgs < 512:
+                        try:
+                            multis.append(ops.conv_multi_call(members, name=f"dgrad(s2 x4, k{k}) " + name, ksplit=k))
+                        except ValueError:
+                            pass
             if ops.GATHER_NARROW and B * IH * IW // 4 <= 32768:  # small levels: narrower workgroups fill more of the chip
                 multis += [ops.conv_multi_call(members, name="dgrad(s2 x4) " + name, bn=nb) for nb in (64, 32)
                            if nb < ops.gather_bn(cg, cg) and cg % nb == 0]

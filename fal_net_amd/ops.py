@@ -288,15 +288,25 @@ def gather_bn(w_rows, Cout):
     return 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
 
 
-def conv_multi_call(calls, name="conv multi", bn=None):
+def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1):
     """Fuse up to four conv_call launches (built with autotune off: gather kernel) into one falnet_conv2d_multi.
-    bn = 32 / 64: narrower workgroups than the default (variants 11 / 12: more workgroups for small layers)."""
+    bn = 32 / 64: narrower workgroups than the default (variants 11 / 12: more workgroups for small layers).
+    ksplit > 1: split-K over blockIdx.z with one fused epilogue; the members share the plan's split-K workspace, each with its
+    own region (raises ValueError when it does not fit)."""
     lib = L.lib()
     n = len(calls)
     arr = (L.Conv * n)()
+    off = 0
     for i, c in enumerate(calls):
         C.memmove(C.byref(arr[i]), C.byref(c.desc), C.sizeof(L.Conv))
-        arr[i].variant, arr[i].ksplit = {32: 11, 64: 12}.get(bn, 1), 1
+        arr[i].variant, arr[i].ksplit = {32: 11, 64: 12}.get(bn, 1), ksplit
+        if ksplit > 1:
+            need = (arr[i].B * arr[i].TH * arr[i].TW * arr[i].w_rows * 4 + 255) // 256 * 256
+            if not c.desc.splitk_ws or off + need > c.desc.splitk_ws_bytes or arr[i].Cout % 8:
+                raise ValueError("split-K workspace too small for a fused multi launch")
+            arr[i].splitk_ws = c.desc.splitk_ws + off
+            arr[i].splitk_ws_bytes = need
+            off += need
     keep = (arr, calls)
     dn = "DF16b" if arr[0].dtype == L.BF16 else "f"
     bn = bn or gather_bn(arr[0].w_rows, arr[0].Cout)

@@ -113,8 +113,9 @@ int falnet_conv2d(const falnet_conv_t* p, void* stream);
  * loss_functions.py:21) with the f32 OIHW weights as they are -> NHWC `dtype` [B][H][W][Cout], Cout in {32, 64}, bias + act fused. */
 int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int Cout,
                       int act, int dtype, void* stream);
-/* n <= 4 gather launches of one family (same dtype / Cout / packed rows, NHWC output, no split-K) in ONE grid:
- * the four output-parity classes of a stride-2 data gradient */
+/* n <= 4 gather launches of one family (same dtype / Cout / packed rows / ksplit, NHWC output) in ONE grid: the four
+ * output-parity classes of a stride-2 data gradient.  ksplit > 1: every member needs its OWN all-zero splitk_ws region
+ * (B*TH*TW*w_rows floats, non-overlapping); one fused epilogue launch follows and leaves the regions zero. */
 int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream);
 /* symbol (as rocprofv3 reports it) of the kernel falnet_conv2d launches for this descriptor */
 int falnet_conv2d_kernel_name(const falnet_conv_t* p, char* buf, int len);

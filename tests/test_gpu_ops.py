@@ -354,6 +354,43 @@ def test_conv_backward(case, dtype):
     assert rel(gw, 2 * w.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ksplit", [1, 4])
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 128, 12, 20), (1, 128, 256, 9, 15), (2, 32, 64, 16, 32)])
+def test_stride2_dgrad_fused_launch(B, cin, cout, H, W, ksplit, dtype):
+    """falnet_conv2d_multi: the four output-parity classes of a stride-2 data gradient in ONE launch (optionally split-K with one
+    fused epilogue, every member accumulating into its own workspace region), with addend and activation gradient, vs autograd."""
+    g = torch.Generator().manual_seed(B * H + W)
+    x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    y = F.conv2d(F.elu(x), w, None, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    skip = torch.randn(B, cin, H, W, generator=g)
+    y.backward(gy)
+    # (dgrad wrt the conv input + addend) * elu'(pre-activation), the epilogue contract of falnet_conv_t
+    ref = (F.conv_transpose2d(gy, w, stride=2, padding=1, output_padding=(1 - H % 2, 1 - W % 2)) + skip) * torch.where(x > 0, torch.ones_like(x), F.elu(x) + 1.0)
+    pc = packed(w, None, [cin], 2, dtype)
+    OH, OW = y.shape[2], y.shape[3]
+    g_t, add_t, act_t = to_nhwc(gy, dtype), to_nhwc(skip, dtype), to_nhwc(F.elu(x.detach()), dtype)
+    cg = pc.groups_pad[0]
+    gin = torch.full((B, H, W, cg), float("nan"), dtype=dtype, device=DEV)
+    members = []
+    for py in range(2):
+        for px in range(2):
+            th, tw = (H - py + 1) // 2, (W - px + 1) // 2
+            members.append(ops.conv_call(dtype, [ops.nhwc_src(g_t)], OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, th,
+                                         tw, gin, H, W, cg, cg, out_step=(2, 2, py, px), addend=add_t, actout=act_t, actout_kind=L.ACT_ELU,
+                                         autotune=False))
+    call = ops.conv_multi_call(members, ksplit=ksplit)
+    for _ in range(2):  # twice: the split-K epilogue must leave the workspace zero for the next launch
+        gin.fill_(float("nan"))
+        call()
+        torch.cuda.synchronize()
+        assert rel(to_nchw(gin, cin), ref.detach()) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+    ws = ops._splitk_workspace(torch.device(DEV, torch.cuda.current_device()))
+    assert float(ws.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", [PATCH_CASES[2], PATCH_CASES[4], PATCH_CASES[8], (1, [64], 64, 9, 37, 1, 3, False, L.ACT_ELU, False)])
 def test_wgrad_big_tiles(case, monkeypatch):
     """falnet_wgrad variant 2 (64x64 channels per workgroup, LDS-DMA staging, opt-in) against autograd: border patches
