@@ -477,69 +477,82 @@ __device__ __forceinline__ void conv_igemm_body(const falnet_conv_t& p, const in
         }
     }
 
-    int niter_all = 0;
-    for (int s = 0; s < p.nsrc; ++s) niter_all += p.ntaps * (p.src[s].C / KCV);
+    // source descriptors and the current tap in registers: a runtime-indexed p.src[s] / p.tap_dy[t] inside the K loop is a scalar
+    // LOAD from the kernel-argument segment in front of every gather -- on the small deep layers (K loops of 5-20 dependent
+    // global -> LDS -> MFMA rounds per workgroup) that latency is on the critical path of every round
+    struct SrcRegs { const T* ptr; int64_t sb, sy, sx; int H, W, C; };
+    const SrcRegs S0 = {reinterpret_cast<const T*>(p.src[0].ptr), p.src[0].sb, p.src[0].sy, p.src[0].sx, p.src[0].H, p.src[0].W, p.src[0].C};
+    const SrcRegs S1 = p.nsrc > 1 ? SrcRegs{reinterpret_cast<const T*>(p.src[1].ptr), p.src[1].sb, p.src[1].sy, p.src[1].sx, p.src[1].H, p.src[1].W, p.src[1].C} : S0;
+    const int ntaps = p.ntaps, IH = p.IH, IW = p.IW, cin_total = p.cin_total;
+    const int ch0 = S0.C / KCV, ch1 = p.nsrc > 1 ? S1.C / KCV : 0;   // K chunks per tap of each source
+    const int niter_all = ntaps * (ch0 + ch1);
     // split-K: blockIdx.z owns K iterations [it0, it1); partial sums go to an f32 workspace with atomics
     const int it0 = (int)((int64_t)niter_all * zi / nz), it1 = (int)((int64_t)niter_all * (zi + 1) / nz);
     const int niter = it1 - it0;
 
-    // K-walk state: source s, tap t, channel offset c0; srcoff = packed-weight offset of source s
+    // K-walk state: source s, tap t, channel offset c0; srcoff = packed-weight offset of source s.  Closed form of the walk
+    // (source-major, then tap, then chunk) at iteration it0 -- the last split of a 16-way launch would otherwise step there
     int s_ = 0, t_ = 0, c0_ = 0, srcoff_ = 0;
-    for (int i = 0; i < it0; ++i) {  // fast-forward to this split's first iteration (scalar, <= a few hundred steps)
-        c0_ += KCV;
-        if (c0_ >= p.src[s_].C) {
-            c0_ = 0;
-            if (++t_ >= p.ntaps) {
-                t_ = 0;
-                srcoff_ += p.src[s_].C;
-                ++s_;
-            }
+    {
+        int r = it0;
+        if (r >= ntaps * ch0 && ch1 > 0) {
+            r -= ntaps * ch0;
+            s_ = 1;
+            srcoff_ = S0.C;
+        }
+        const int chs = s_ ? ch1 : ch0;
+        if (chs > 0) {
+            t_ = r / chs;
+            c0_ = (r % chs) * KCV;
         }
     }
+    int cur_dy = p.tap_dy[t_ < ntaps ? t_ : 0], cur_dx = p.tap_dx[t_ < ntaps ? t_ : 0], cur_w = p.tap_w[t_ < ntaps ? t_ : 0];
     uint4 areg[A_LOADS], breg[B_LOADS];
 
     auto gload = [&]() {
-        const falnet_src_t& S = p.src[s_];
-        const int dy = p.tap_dy[t_], dx = p.tap_dx[t_];
-        const bool ups = (S.H != p.IH) || (S.W != p.IW);
+        const SrcRegs S = s_ == 0 ? S0 : S1;
+        const int dy = cur_dy, dx = cur_dx;
+        const bool ups = (S.H != IH) || (S.W != IW);
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             const int seg = (tid + i * CONV_THREADS) & 3;
             int vy = a_y[i] + dy, vx = a_x[i] + dx;
-            const bool ok = a_b[i] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW;
+            const bool ok = a_b[i] >= 0 && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
                 if (ups) {
-                    vy = (2 * S.H == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / p.IH);
-                    vx = (2 * S.W == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / p.IW);
+                    vy = (2 * S.H == IH) ? (vy >> 1) : (int)(((int64_t)vy * S.H) / IH);
+                    vx = (2 * S.W == IW) ? (vx >> 1) : (int)(((int64_t)vx * S.W) / IW);
                 }
-                const T* src = reinterpret_cast<const T*>(S.ptr) + (int64_t)a_b[i] * S.sb + (int64_t)vy * S.sy +
-                               (int64_t)vx * S.sx + c0_ + seg * EPS;
+                const T* src = S.ptr + (int64_t)a_b[i] * S.sb + (int64_t)vy * S.sy + (int64_t)vx * S.sx + c0_ + seg * EPS;
                 v = *reinterpret_cast<const uint4*>(src);
             }
             areg[i] = v;
         }
-        const int64_t wk = (int64_t)p.tap_w[t_] * p.cin_total + srcoff_ + c0_;
+        const int64_t wk = (int64_t)cur_w * cin_total + srcoff_ + c0_;
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             const int idx = tid + i * CONV_THREADS;
             const int row = idx >> 2, seg = idx & 3;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < BN && n0 + row < w_rows) {
-                const T* w = reinterpret_cast<const T*>(p.weight) + (int64_t)(n0 + row) * p.w_taps * p.cin_total + wk + seg * EPS;
+                const T* w = reinterpret_cast<const T*>(p.weight) + (int64_t)(n0 + row) * p.w_taps * cin_total + wk + seg * EPS;
                 v = *reinterpret_cast<const uint4*>(w);
             }
             breg[i] = v;
         }
-        // advance the K walk
+        // advance the K walk (the next tap's offsets are requested here, a whole round before the gather that uses them)
         c0_ += KCV;
         if (c0_ >= S.C) {
             c0_ = 0;
-            if (++t_ >= p.ntaps) {
+            if (++t_ >= ntaps) {
                 t_ = 0;
                 srcoff_ += S.C;
                 ++s_;
             }
+            cur_dy = p.tap_dy[t_];
+            cur_dx = p.tap_dx[t_];
+            cur_w = p.tap_w[t_];
         }
     };
     auto lstore = [&](int buf) {
