@@ -43,6 +43,8 @@ if kind == "conv":
                          H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU if actout is None else L.ACT_NONE, addend=addend,
                          actout=actout, actout_kind=L.ACT_ELU if actout is not None else L.ACT_NONE)
     call.desc.variant = int(sys.argv[6])
+    if os.environ.get("KSPLIT"):  # gather kernel only; the workspace conv_call attached must hold B*H*W*cout_pad floats
+        call.desc.ksplit = int(os.environ["KSPLIT"])
     run = call
 else:
     gout = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype)
