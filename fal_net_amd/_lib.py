@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 OUT_NHWC, OUT_PLANAR_F32 = 0, 1
 CPAD = 32  # channel padding granule of NHWC tensors / packed weights (falnet_channel_pad)
@@ -44,7 +44,8 @@ class Wgrad(C.Structure):
                 ("gout", C.c_void_p), ("gC", C.c_int32), ("ntaps", C.c_int32),
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("isy", C.c_int32), ("isx", C.c_int32),
                 ("B", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("cin_total", C.c_int32),
-                ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32), ("bias_grad", C.c_void_p)]
+                ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32), ("bias_grad", C.c_void_p),
+                ("cout", C.c_int32)]
 
 
 class ReduceDesc(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "falnet_conv2d_kernel_name": [C.POINTER(Conv), C.c_char_p, _I],
     "falnet_wgrad_workspace_bytes": [C.POINTER(Wgrad)],
     "falnet_wgrad": [C.POINTER(Wgrad), _P],
+    "falnet_wgrad_fuses_bias": [C.POINTER(Wgrad)],
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
     "falnet_pack_weights_batched": [_P, _I, _I, _I, _P],
@@ -150,4 +152,6 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise ValueError(f"unsupported compute dtype {dt}")

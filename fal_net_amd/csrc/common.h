@@ -27,12 +27,15 @@ void falnet_set_error(const char* fmt, ...);
     } while (0)
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
 // wave64 sum via DPP-free shuffles, then one LDS hop across the block's waves
 __device__ __forceinline__ float wave_sum(float v) {

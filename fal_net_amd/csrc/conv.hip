@@ -1880,7 +1880,7 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
         if (patch + 1 < pend) lstore(cur ^ 1, R0);
         __syncthreads();
     }
-    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.gC);
+    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.cout);
     // every wave owns its three taps: no cross-wave reduction
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
         if (patch + 1 < pend) lstore(0, R0);
         __syncthreads();
     }
-    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.gC);
+    if (do_bias) bias_grad_flush<T, COT, WP_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, co0, p.cout);
     const int r = lane & 31, h = lane >> 5;
     const int ci = ci0 + r;
     if (ci < p.cin_total) {
@@ -2181,7 +2181,7 @@ __global__ __launch_bounds__(WC3_THREADS) void wgrad3x3_c3_kernel(const falnet_w
         __syncthreads();
     }
     if (do_bias) {
-        bias_grad_flush<T, 1, WC3_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, 0, p.gC);
+        bias_grad_flush<T, 1, WC3_THREADS>(reinterpret_cast<float*>(lds), tid, bsum, p.bias_grad, 0, p.cout);
         __syncthreads();
     }
     // sum the four waves' partial tiles through LDS ([wave][co][k], pitch 33), then one thread per (co, k)
@@ -2993,13 +2993,60 @@ extern "C" int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p) {
     return (int64_t)p->nsplit * p->ntaps * round32(p->gC) * p->cin_total * (int64_t)sizeof(float);
 }
 
-extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
-    FALNET_CHECK_ARG(pp, "wgrad: null descriptor");
-    const falnet_wgrad_t& p = *pp;
-    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16, "wgrad: bad dtype %d", p.dtype);
+// kernel selection of falnet_wgrad -- ONE place, also behind falnet_wgrad_fuses_bias (the host must not re-derive it)
+enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_BIG, WGK_S2, WGK_C3, WGK_ROWS };
+bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p);           // wgrad_rows.hip
+int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st);
+
+static bool canonical_taps9(const falnet_wgrad_t& p) {
+    if (p.ntaps != 9) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1) return false;
+    return true;
+}
+
+// returns the kernel; on WGK_BAD the error text is set
+static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
+    const int w_rows = round32(p.gC);
+    const bool h16 = p.dtype == FALNET_BF16;  // (f16: only the row-streaming kernel so far)
+    const bool canon = canonical_taps9(p);
+    if (p.variant == 6) {  // first layer: planar f32 3-channel source (src[0].ptr = [B][3][IH][IW] f32), 16-bit gout, Cout 32
+        const bool ok = h16 && canon && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.gC == 32 && w_rows == 32 && p.cin_total == 32 && p.nsrc == 1;
+        if (!ok) { falnet_set_error("wgrad: variant 6 is the Cin=3 / Cout=32 first layer in bf16 / f16 (dense 3x3, cin_total 32)"); return WGK_BAD; }
+        return WGK_C3;
+    }
+    if (p.variant == 5) {  // stride-2 3x3 (16-bit): parity-plane halo kernel
+        bool ok = h16 && canon && p.isy == 2 && p.isx == 2 && p.TW >= 16 && p.TH == (p.IH + 1) / 2 && p.TW == (p.IW + 1) / 2;
+        for (int s = 0; s < p.nsrc && ok; ++s) ok = p.src[s].C % 32 == 0 && ((p.src[s].H == p.IH && p.src[s].W == p.IW) || (p.src[s].sy == 0 && p.src[s].sx == 0));
+        if (!ok) { falnet_set_error("wgrad: variant 5 needs a 16-bit 3x3 stride-2 pad-1 launch with sources at the input size"); return WGK_BAD; }
+        return WGK_S2;
+    }
+    if (p.variant == 7) {
+        if (!falnet_wgrad_rows_applicable(p)) { falnet_set_error("wgrad: variant 7 needs a 16-bit dense 3x3 stride-1 launch with sources at the launch size or half of it"); return WGK_BAD; }
+        return WGK_ROWS;
+    }
+    // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
+    const bool dense = canon && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
+    if (dense) {
+        // variant 2: 64 x 64 channels per workgroup (bf16, both channel counts multiples of 64); 0 / other: 32 x 32
+        const bool big = p.variant == 2 && p.dtype == FALNET_BF16 && p.cin_total % 64 == 0 && w_rows % 64 == 0;
+        if (p.variant == 2 && !big) { falnet_set_error("wgrad: variant 2 needs bf16 and channel counts that are multiples of 64"); return WGK_BAD; }
+        if (big) return WGK_BIG;
+        if (p.variant == 3 || p.variant == 4) {  // 32 x 64 / 64 x 32 channels per workgroup (register staged, two workgroups per CU)
+            const bool co2 = p.variant == 3;
+            if (!(h16 && (co2 ? w_rows : p.cin_total) % 64 == 0)) { falnet_set_error("wgrad: variant %d needs 16-bit operands and a channel count that is a multiple of 64", p.variant); return WGK_BAD; }
+            return co2 ? WGK_PATCH12 : WGK_PATCH21;
+        }
+        return WGK_PATCH11;
+    }
+    return WGK_TAP;
+}
+
+static int check_wgrad_desc(const falnet_wgrad_t& p) {
+    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16 || p.dtype == FALNET_F16, "wgrad: bad dtype %d", p.dtype);
     FALNET_CHECK_ARG(p.nsrc == 1 || p.nsrc == 2, "wgrad: nsrc=%d", p.nsrc);
     int ctot = 0;
-    if (p.variant != 6) {  // (variant 6 reads a planar f32 3-channel image: its own checks below)
+    if (p.variant != 6) {  // (variant 6 reads a planar f32 3-channel image: its own checks)
         for (int s = 0; s < p.nsrc; ++s) {
             if (int r = check_src(p.src[s], 32, "wgrad")) return r;
             ctot += p.src[s].C;
@@ -3008,71 +3055,73 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     } else {
         FALNET_CHECK_ARG(p.src[0].ptr && p.src[0].C == 3, "wgrad: variant 6 needs a 3-channel planar f32 source");
     }
-    FALNET_CHECK_ARG(p.gout && p.partial && p.gC > 0 && p.gC % 32 == 0 && p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= 9, "wgrad: bad argument");
+    FALNET_CHECK_ARG(p.gout && p.gC > 0 && p.gC % 32 == 0 && p.nsplit >= 1 && p.ntaps >= 1 && p.ntaps <= 9, "wgrad: bad argument");
     FALNET_CHECK_ARG(p.B > 0 && p.TH > 0 && p.TW > 0, "wgrad: empty shape");
+    FALNET_CHECK_ARG(p.cout >= 0 && p.cout <= p.gC, "wgrad: cout=%d exceeds gC=%d", p.cout, p.gC);
+    return 0;
+}
+
+static bool wgrad_kernel_fuses_bias(WgradKernel k) {
+    return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS;
+}
+
+extern "C" int falnet_wgrad_fuses_bias(const falnet_wgrad_t* pp) {
+    if (!pp || check_wgrad_desc(*pp) != 0) return 0;
+    return wgrad_kernel_fuses_bias(choose_wgrad_kernel(*pp)) ? 1 : 0;
+}
+
+extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
+    FALNET_CHECK_ARG(pp, "wgrad: null descriptor");
+    falnet_wgrad_t p = *pp;
+    if (int r = check_wgrad_desc(p)) return r;
+    FALNET_CHECK_ARG(p.partial, "wgrad: no workspace");
+    if (p.cout == 0) p.cout = p.gC;
     const int w_rows = round32(p.gC);
-    // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
-    bool dense = p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
-    for (int t = 0; t < p.ntaps && dense; ++t) dense = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;  // canonical forward order
-    if (p.variant == 6) {  // first layer: planar f32 3-channel source (src[0].ptr = [B][3][IH][IW] f32), bf16 gout, Cout 32
-        bool ok = p.dtype == FALNET_BF16 && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.gC == 32 && w_rows == 32 && p.cin_total == 32 && p.nsrc == 1;
-        for (int t = 0; t < p.ntaps && ok; ++t) ok = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;
-        FALNET_CHECK_ARG(ok, "wgrad: variant 6 is the Cin=3 / Cout=32 first layer in bf16 (dense 3x3, cin_total 32)");
-        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
-        const int npatch = p.B * tiles_x * tiles_y;
-        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
-        hipLaunchKernelGGL(wgrad3x3_c3_kernel, dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-        FALNET_RETURN_LAUNCH();
+    const WgradKernel k = choose_wgrad_kernel(p);
+    if (k == WGK_BAD) return -1;
+    if (p.bias_grad && !wgrad_kernel_fuses_bias(k)) {
+        falnet_set_error("wgrad: bias_grad is set but the selected kernel (%d) cannot fuse it -- ask falnet_wgrad_fuses_bias first", (int)k);
+        return -3;
     }
-    if (p.variant == 5) {  // stride-2 3x3 (bf16): parity-plane halo kernel
-        bool ok = p.dtype == FALNET_BF16 && p.ntaps == 9 && p.isy == 2 && p.isx == 2 && p.TW >= 16 && p.TH == (p.IH + 1) / 2 && p.TW == (p.IW + 1) / 2;
-        for (int t = 0; t < p.ntaps && ok; ++t) ok = p.tap_dy[t] == t / 3 - 1 && p.tap_dx[t] == t % 3 - 1;
-        for (int s = 0; s < p.nsrc && ok; ++s) ok = p.src[s].C % 32 == 0 && ((p.src[s].H == p.IH && p.src[s].W == p.IW) || (p.src[s].sy == 0 && p.src[s].sx == 0));
-        FALNET_CHECK_ARG(ok, "wgrad: variant 5 needs a bf16 3x3 stride-2 pad-1 launch with sources at the input size");
-        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
-        const int npatch = p.B * tiles_x * tiles_y;
-        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
-        if (w_rows % 64 == 0) {
-            const dim3 grid(p.cin_total / 32, w_rows / 64, p.nsplit);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<2>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-        } else {
-            const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-        }
-        FALNET_RETURN_LAUNCH();
-    }
-    if (dense) {
-        const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
-        const int npatch = p.B * tiles_x * tiles_y;
-        const int pps = (npatch + p.nsplit - 1) / p.nsplit;
-        // variant 2: 64 x 64 channels per workgroup (bf16, both channel counts multiples of 64); 0 / other: 32 x 32
-        const bool big = p.variant == 2 && p.dtype == FALNET_BF16 && p.cin_total % 64 == 0 && w_rows % 64 == 0;
-        FALNET_CHECK_ARG(p.variant != 2 || big, "wgrad: variant 2 needs bf16 and channel counts that are multiples of 64");
-        if (big) {
-            const dim3 grid(p.cin_total / 64, w_rows / 64, p.nsplit);
-            hipLaunchKernelGGL(wgrad3x3_big_kernel, grid, dim3(WPB_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-            FALNET_RETURN_LAUNCH();
-        }
-        if (p.variant == 3 || p.variant == 4) {  // 32 x 64 / 64 x 32 channels per workgroup (register staged, two workgroups per CU)
-            const bool co2 = p.variant == 3;
-            FALNET_CHECK_ARG(p.dtype == FALNET_BF16 && (co2 ? w_rows : p.cin_total) % 64 == 0, "wgrad: variant %d needs bf16 and a channel count that is a multiple of 64", p.variant);
-            const dim3 grid(p.cin_total / (co2 ? 32 : 64), w_rows / (co2 ? 64 : 32), p.nsplit);
-            if (co2) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 2>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 2, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-            FALNET_RETURN_LAUNCH();
-        }
-        const dim3 grid(p.cin_total / 32, w_rows / 32, p.nsplit);
-        if (p.dtype == FALNET_BF16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (p.TW + WP_TW - 1) / WP_TW, tiles_y = (p.TH + WP_TH - 1) / WP_TH;
+    const int npatch = p.B * tiles_x * tiles_y;
+    const int pps = (npatch + p.nsplit - 1) / p.nsplit;
+    switch (k) {
+    case WGK_ROWS:
+        return falnet_wgrad_rows_launch(p, st);
+    case WGK_C3:
+        hipLaunchKernelGGL(wgrad3x3_c3_kernel, dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    case WGK_S2:
+        if (w_rows % 64 == 0)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<float, 1, 1>), grid, dim3(WP_THREADS), 0, (hipStream_t)stream, p, w_rows, tiles_x, tiles_y, pps);
-        FALNET_RETURN_LAUNCH();
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    case WGK_BIG:
+        hipLaunchKernelGGL(wgrad3x3_big_kernel, dim3(p.cin_total / 64, w_rows / 64, p.nsplit), dim3(WPB_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    case WGK_PATCH12:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    case WGK_PATCH21:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 2, 1>), dim3(p.cin_total / 64, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    case WGK_PATCH11:
+        if (p.dtype != FALNET_F32)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<float, 1, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+        break;
+    default: {
+        const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);
+        if (p.dtype != FALNET_F32)
+            hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, st, p, w_rows);
+        else
+            hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(CONV_THREADS), 0, st, p, w_rows);
     }
-    const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);
-    if (p.dtype == FALNET_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(CONV_THREADS), 0, (hipStream_t)stream, p, w_rows);
+    }
     FALNET_RETURN_LAUNCH();
 }
 

@@ -1,0 +1,343 @@
+// Row-streaming weight gradient of the dense 3x3 / stride-1 convolutions (16-bit operands: bf16 or f16), gfx950.
+//
+//   dW[co][ky][kx][ci] = sum over pixels of gout[y][x][co] * in[y + ky - 1][x + kx - 1][ci]
+//
+// (autograd of the conv2d call sites models/FAL_netB.py:38,45,55,73,75,127 of the reference).  GEMM view: M = cout,
+// N = 9 * cin, K = pixels.  A workgroup owns a 64 (cout) x 64 (cin) channel block for ALL nine taps -- its four waves one
+// 32 x 32 sub-block each, nine f32 accumulator tiles per wave -- and streams a 32-pixel-wide column strip of the image
+// top to bottom, ONE image row per step:
+//   * the step's gout row (32 px x 64 ch) and input row (34 px x 64 ch, the +-1 column halo) arrive by LDS-DMA
+//     (global_load_lds_dwordx4: whole 128-B pixel lines, no VGPR staging) into a ring of D+1 row slots, D steps ahead;
+//     out-of-image pixels are fetched from a 128-B page of zeros, so every wave issues the same piece count per step
+//     (counted vmcnt + raw s_barrier, one barrier per step);
+//   * input row i meets gout rows i+1, i, i-1 (ky = 0, 1, 2): the three gout fragments live in a rolling REGISTER
+//     window, so a step reads one new gout fragment and three shifted input fragments (kx = 0, 1, 2) per 16-pixel half
+//     and issues nine MFMAs on them: 0.44 fragments (0.9 transposed 8-B LDS reads) per v_mfma_f32_32x32x16, against
+//     1.7-2.7 reads per MFMA of the patch kernel (wgrad3x3_patch_kernel) whose waves re-read both operands per tap row;
+//   * rows are never re-fetched for a halo inside a strip (the patch form re-staged 6 rows for 4): 282 FLOP per
+//     fetched byte.
+// LDS image: [pixel][64 channels], 128-B rows as the DMA writes them; the two 64-B halves of pixels with bit 1 set are
+// exchanged (on the SOURCE address: the DMA destination is lane-linear), which makes the ds_read_b64_tr_b16 fragment
+// reads of any four consecutive pixels conflict-free.
+// Split-K: the (sample, strip, row) units are cut into nsplit contiguous ranges; every workgroup writes one f32 slab
+// [9][64][64] into partial[split][tap][co][ci] (falnet_wgrad_reduce_batched sums them).  blockIdx -> (split, tile) keeps
+// the channel tiles of one pixel range on one XCD (they stream the same rows: L2 hits).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+    static __device__ __forceinline__ f32x16 mma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float f32(short v) { return __uint_as_float(((unsigned)(unsigned short)v) << 16); }
+};
+template <> struct Mma16<f16_t> {
+    static __device__ __forceinline__ f32x16 mma(s16x8 a, s16x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float f32(short v) { return (float)__builtin_bit_cast(_Float16, v); }
+};
+
+#define WR_THREADS 256
+#define WR_TW 32                 // output pixels per strip row
+#define WR_GROW (WR_TW * 128)    // gout row: 32 px x 64 ch x 2 B
+#define WR_XPX 40                // input row: 34 px used, rounded up to whole 8-pixel DMA pieces
+#define WR_XROW (WR_XPX * 128)
+#define WR_SLOT (WR_GROW + WR_XROW)
+
+__device__ uint4 g_wr_zero[8] = {};  // 128 B of zeros: source of every out-of-image / out-of-range 16-B piece
+
+typedef __attribute__((address_space(1))) const void* wr_gptr_t;
+typedef __attribute__((address_space(3))) void* wr_lptr_t;
+typedef s16x4 __attribute__((address_space(3))) * wr_lds_v4;
+
+// One 1-KiB LDS-DMA piece: lane l's 16 B from its own global address to LDS byte lds_dst + 16 l.  Inline asm on purpose:
+// hipcc orders every ds_read behind ALL outstanding builtin global_load_lds with s_waitcnt vmcnt(0) (its LDS-DMA alias
+// tracking), which drains the row ring at every step; an asm statement is outside that bookkeeping, the counted
+// wr_vmcnt<> waits below are the only ordering (cdna_hip_programming.md section 5.7).  M0 is saved and restored inside
+// the statement (compiler-reserved register).
+__device__ __forceinline__ void wr_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int K>
+__device__ __forceinline__ void wr_vmcnt() {
+    if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (K == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (K == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else static_assert(K == 0, "unsupported vmcnt");
+}
+
+struct WrCursor { int u, n, s, b, x0, y0; };  // item = rows [y0, y0+n) of column strip x0 of sample b; s = step inside it (0..n+1)
+
+template <typename T, int D>
+__global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
+    constexpr int NS = D + 1;
+    static_assert(D >= 1 && D <= 3, "prefetch distance");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * WR_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(wr_lptr_t)lds;  // LDS byte address of the ring
+    const int nsplit = p.nsplit;
+    int tile, split;
+    {
+        const int wg = blockIdx.x;
+        if ((nsplit & 7) == 0) {  // the channel tiles of one pixel range share an XCD (blocks b and b + 8 do)
+            const int idx = wg >> 3;
+            split = (idx / ntiles) * 8 + (wg & 7);
+            tile = idx % ntiles;
+        } else {
+            tile = wg % ntiles;
+            split = wg / ntiles;
+        }
+    }
+    const int ci0 = (tile % ntci) * 64, co0 = (tile / ntci) * 64;
+    const int a_t = wave >> 1, c_t = wave & 1;  // this wave's 32-channel sub-tiles (cin, cout)
+    const int H = p.TH, TW = p.TW, gC = p.gC;
+    const int R = p.B * nstrips * H;
+    const int u0 = (int)((int64_t)R * split / nsplit), u1 = (int)((int64_t)R * (split + 1) / nsplit);
+
+    // ---- per-lane DMA geometry: lane = (pixel pl of an 8-pixel piece, 16-B chunk position cpos of its 128-B line) ----
+    const int pl = lane >> 3, cpos = lane & 7;
+    const int gch = cpos ^ (((pl >> 1) & 1) << 2);  // channel chunk this lane FETCHES (64-B halves exchanged on pixels with bit 1 set)
+    const char* const zero_page = reinterpret_cast<const char*>(g_wr_zero);
+    const bool g_chok = co0 + 8 * gch < gC;
+    const int ch = ci0 + 8 * gch;
+    const bool x_chok = ch < p.cin_total;
+    const int c_first = p.src[0].C;
+    const bool second = p.nsrc > 1 && ch >= c_first;
+    const falnet_src_t& S = second ? p.src[1] : p.src[0];
+    const int l_hs = S.H != p.IH ? 1 : 0, l_ws = S.W != p.IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+    const int64_t l_sy = S.sy, l_sx = S.sx, l_sb = S.sb;
+    const T* const l_ptr = reinterpret_cast<const T*>(S.ptr) + (second ? ch - c_first : ch);
+
+    // lane bases of the current ISSUE item (recomputed when the issue cursor enters a new item)
+    const T* gbase = nullptr;
+    const T* xbase0 = nullptr;
+    const T* xbase4 = nullptr;
+    bool g_ok = false, x_ok0 = false, x_ok4 = false;
+    auto item_bases = [&](const WrCursor& c) {
+        const int gx = c.x0 + 8 * wave + pl;
+        g_ok = g_chok && gx < TW;
+        gbase = reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H) * TW + gx) * gC + co0 + 8 * gch;
+        const int x0i = c.x0 - 1 + 8 * wave + pl;
+        x_ok0 = x_chok && x0i >= 0 && x0i < p.IW;
+        xbase0 = l_ptr + (int64_t)c.b * l_sb + (int64_t)(x0i >> l_ws) * l_sx;
+        const int x4 = c.x0 - 1 + 32 + pl;
+        x_ok4 = x_chok && pl < 2 && x4 < p.IW;
+        xbase4 = l_ptr + (int64_t)c.b * l_sb + (int64_t)(x4 >> l_ws) * l_sx;
+    };
+    auto load_item = [&](WrCursor& c, int u) {
+        c.u = u;
+        const int bs = u / H;
+        c.y0 = u - bs * H;
+        c.n = min((bs + 1) * H, u1) - u;
+        c.b = bs / nstrips;
+        c.x0 = (bs - c.b * nstrips) * WR_TW;
+        c.s = 0;
+    };
+    auto advance = [&](WrCursor& c) -> bool {  // next step; false once the range is exhausted.  true = entered a new item
+        if (++c.s < c.n + 2) return false;
+        load_item(c, c.u + c.n);
+        return true;
+    };
+    const int nst = u1 > u0 ? (u1 - u0) + 2 * ((u1 - 1) / H - u0 / H + 1) : 0;  // n + 2 steps per item
+
+    auto issue = [&](const WrCursor& c, int slot) {
+        const unsigned Gs = lds_base + slot * WR_SLOT, Xs = Gs + WR_GROW;
+        const int yg = c.y0 + c.s;
+        const bool gv = c.s < c.n;
+        const char* ga = (gv && g_ok) ? reinterpret_cast<const char*>(gbase + (int64_t)yg * TW * gC) : zero_page;
+        wr_glds16(ga, Gs + wave * 1024);
+        const int i = c.y0 - 1 + c.s;
+        const bool xv = i >= 0 && i < p.IH;
+        const int64_t ro = (int64_t)(i >> l_hs) * l_sy;
+        const char* xa = (xv && x_ok0) ? reinterpret_cast<const char*>(xbase0 + ro) : zero_page;
+        wr_glds16(xa, Xs + wave * 1024);
+        if (wave == 0) {
+            const char* xb = (xv && x_ok4) ? reinterpret_cast<const char*>(xbase4 + ro) : zero_page;
+            wr_glds16(xb, Xs + 4 * 1024);
+        }
+    };
+
+    // ---- fragment read geometry (as the patch kernels: channel on lane & 31, k = pixel on lane >> 5 and element) ----
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
+    auto frag_off = [&](int tile32, int pshift) {  // byte offset of this lane's first transposed read: pixel pshift + q + 8 kh
+        const int gc = tile32 * 4 + cb * 2 + (pc >> 1);
+        const int sw = ((pshift + q) >> 1) & 1;
+        return (q + 8 * kh) * 128 + ((gc ^ (sw << 2)) * 16) + (pc & 1) * 8;
+    };
+    const int offA = frag_off(c_t, 0);
+    const int offB0 = frag_off(a_t, 0), offB1 = frag_off(a_t, 1) + 128, offB2 = frag_off(a_t, 2) + 256;
+    auto frag = [&](const char* base) -> s16x8 {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base + 4 * 128));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[dy][dx][j] = 0.f;
+    s16x8 aw1[2], aw2[2];  // gout fragments of the two previous rows (per 16-pixel half)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw1[hf][j] = aw2[hf][j] = 0;
+    const bool a_live = ci0 + 32 * a_t < p.cin_total && co0 + 32 * c_t < gC;  // a 64-channel block may be half empty
+    const bool do_bias = p.bias_grad != nullptr && (tile % ntci) == 0 && a_t == 0;
+    float bsum = 0.f;
+
+    WrCursor ci_, cc_;  // issue / compute cursors
+    if (nst > 0) {
+        load_item(ci_, u0);
+        cc_ = ci_;
+        item_bases(ci_);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < nst) {
+                issue(ci_, d);
+                if (d + 1 < nst && advance(ci_)) item_bases(ci_);
+            }
+        }
+    }
+    int slot = 0, islot = D;  // slot of step g; slot the step g + D is issued into
+    for (int g = 0; g < nst; ++g) {
+        // this wave's pieces of step g have landed once at most k steps' worth of younger pieces are outstanding
+        const int k = min(D - 1, nst - 1 - g);
+        if (wave == 0) {
+            if (k >= 2) wr_vmcnt<(D >= 3 ? 6 : 0)>();
+            else if (k == 1) wr_vmcnt<(D >= 2 ? 3 : 0)>();
+            else wr_vmcnt<0>();
+        } else {
+            if (k >= 2) wr_vmcnt<(D >= 3 ? 4 : 0)>();
+            else if (k == 1) wr_vmcnt<(D >= 2 ? 2 : 0)>();
+            else wr_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of step g - 1 are done (slot reuse below)
+        __builtin_amdgcn_s_barrier();
+        if (g + D < nst) {
+            issue(ci_, islot);
+            if (g + D + 1 < nst && advance(ci_)) item_bases(ci_);
+        }
+        const char* Gs = lds + slot * WR_SLOT;
+        const char* Xs = Gs + WR_GROW;
+        const int s = cc_.s, n = cc_.n;
+        const int i = cc_.y0 - 1 + s;
+        const bool xv = i >= 0 && i < p.IH;
+        const bool m0 = s < n, m1 = s >= 1 && s - 1 < n, m2 = s >= 2;  // gout rows y0+s, y0+s-1, y0+s-2 inside the item
+        s16x8 a0[2], bf[2][3];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            a0[hf] = frag(Gs + offA + hf * 16 * 128);
+            bf[hf][0] = frag(Xs + offB0 + hf * 16 * 128);
+            bf[hf][1] = frag(Xs + offB1 + hf * 16 * 128);
+            bf[hf][2] = frag(Xs + offB2 + hf * 16 * 128);
+        }
+        if (a_live && xv) {  // wave-uniform branches around groups of three MFMAs (a fast path duplicating the eighteen made hipcc spill)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (m0) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(a0[hf], bf[hf][dx], acc[0][dx]);
+                }
+                if (m1) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(aw1[hf], bf[hf][dx], acc[1][dx]);
+                }
+                if (m2) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(aw2[hf], bf[hf][dx], acc[2][dx]);
+                }
+            }
+        }
+        if (do_bias && m0) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += Mma16<T>::f32(a0[hf][j]);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            aw2[hf] = aw1[hf];
+            aw1[hf] = a0[hf];
+        }
+        if (g + 1 < nst && advance(cc_)) {  // new item: the window restarts (m1 / m2 are false on its first steps anyway)
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    }
+
+    // ---- slab: partial[split][tap][co][ci] (every workgroup writes its whole block, zeros included) ----
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + 32 * a_t + r;
+    if (ci < p.cin_total) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float* dst = p.partial + (((int64_t)split * 9 + dy * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int co = co0 + 32 * c_t + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dy][dx][j];
+                }
+            }
+    }
+    if (do_bias) {  // lane (r, h) summed the pixels 8h..8h+7 (+16) of every row for channel co0 + 32 c_t + r
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int co = co0 + 32 * c_t + r;
+        if (h == 0 && co < p.cout) atomicAdd(p.bias_grad + co, bsum);
+    }
+}
+
+// does this launch fit the row-streaming kernel?  (16-bit operands, canonical dense 3x3 stride 1, sources at the launch
+// size or exactly half of it, at least one 64-channel side)
+bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.ntaps != 9 || p.isy != 1 || p.isx != 1 || p.TH != p.IH || p.TW != p.IW) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1) return false;
+    if (p.gC % 32 || p.cin_total % 32 || p.nsrc < 1 || p.nsrc > 2) return false;
+    int ctot = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const falnet_src_t& S = p.src[s];
+        if (S.C % 32) return false;
+        if (!((S.H == p.IH || 2 * S.H == p.IH) && (S.W == p.IW || 2 * S.W == p.IW))) return false;
+        ctot += S.C;
+    }
+    if (ctot != p.cin_total) return false;
+    if ((int64_t)p.B * ((p.TW + WR_TW - 1) / WR_TW) * p.TH >= (1ll << 30)) return false;
+    return true;
+}
+
+int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
+    const int w_rows = (p.gC + 31) / 32 * 32;
+    const int ntci = (p.cin_total + 63) / 64, ntco = (w_rows + 63) / 64;
+    const int ntiles = ntci * ntco;
+    const int nstrips = (p.TW + WR_TW - 1) / WR_TW;
+    const dim3 grid((unsigned)(ntiles * p.nsplit));
+    if (p.dtype == FALNET_BF16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<bf16_t, 3>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<f16_t, 3>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    FALNET_RETURN_LAUNCH();
+}

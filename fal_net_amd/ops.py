@@ -364,67 +364,101 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     return best
 
 
+def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_pad, max_slabs, target_wgs=1536):
+    """(variant, nsplit, kernel symbol) of one weight-gradient launch -- the host-side mirror of conv.hip's kernel choice
+    (falnet_wgrad re-checks the variant and fails loudly; whether the bias gradient is fused is ASKED from the library,
+    falnet_wgrad_fuses_bias, never re-derived here)."""
+    M = B * TH * TW
+    h16 = dtype in (torch.bfloat16, torch.float16)
+    tn = {torch.bfloat16: "DF16b", torch.float16: "DF16_", torch.float32: "f"}[dtype]
+    dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
+    c3 = len(srcs) == 1 and srcs[0].C == 3  # planar f32 image source (ops.planar_src): first-layer kernel, variant 6
+    npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
+    if c3:
+        assert h16 and dense and cout_pad == 32 and cin_pad == 32, "variant 6: 16-bit first layer, Cout 32"
+        variant, nsplit, sym = 6, max(1, min(_WGRAD_WGS, npatch)), "_Z18wgrad3x3_c3_kernel14falnet_wgrad_tiiii"
+    elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
+        tiles = (cin_pad // 32) * (cout_pad // (64 if cout_pad % 64 == 0 else 32))
+        variant, nsplit = 5, max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
+        sym = f"_Z18wgrad3x3_s2_kernelILi{2 if cout_pad % 64 == 0 else 1}EEv14falnet_wgrad_tiiii"
+    elif _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
+        tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
+        units = B * ((TW + 31) // 32) * TH
+        nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
+        if nsplit >= 8:
+            nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
+        variant, sym = 7, f"_Z20wgrad3x3_rows_kernelI{tn}Li3EEv14falnet_wgrad_tiiii"
+    elif dense:
+        big = _wgrad_big(dtype, dense, cin_pad, cout_pad)
+        co2 = not big and _wgrad_co2(dtype, dense, cin_pad, cout_pad)
+        tiles = (cin_pad // 32) * (cout_pad // 32) // (4 if big else 2 if co2 else 1)
+        nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
+        variant = 2 if big else 3 if co2 else 0
+        sym = "_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii"
+    else:
+        tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64) * len(taps)
+        variant, nsplit, sym = 0, max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256)), f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
+    return variant, max(1, min(nsplit, max_slabs)), sym
+
+
+def _fill_wgrad(d, dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc):
+    d.nsrc = len(srcs)
+    for i, s in enumerate(srcs):
+        d.src[i] = s
+    d.IH, d.IW = IH, IW
+    gC = gout.shape[-1]
+    d.gout, d.gC, d.cout = gout.data_ptr(), gC, pc.cout
+    _fill_taps(d, taps)
+    d.isy = d.isx = stride_in
+    d.B, d.TH, d.TW = B, TH, TW
+    d.cin_total = pc.cin_pad
+    d.dtype = L.dtype_code(dtype)
+
+
+def _fuse_bias(lib, d, grad_b):
+    """Point the launch at the bias gradient when -- and only when -- the kernel the LIBRARY selects for it sums it."""
+    if grad_b is None or not _FUSED_BIAS:
+        return False
+    if lib.falnet_wgrad_fuses_bias(C.byref(d)) != 1:
+        return False
+    d.bias_grad = grad_b.data_ptr()
+    return True
+
+
+
 def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, ws, target_wgs=1536,
                 name="wgrad", flops=0):
     """Weight (+bias) gradient of one conv: split-K partial slabs in `ws`, then a reduce into the
     OIHW f32 views `grad_w` / `grad_b`.  Returns a callable taking (accumulate)."""
     lib = L.lib()
     d = L.Wgrad()
-    d.nsrc = len(srcs)
-    for i, s in enumerate(srcs):
-        d.src[i] = s
-    d.IH, d.IW = IH, IW
+    _fill_wgrad(d, dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc)
     gC = gout.shape[-1]
-    d.gout, d.gC = gout.data_ptr(), gC
-    _fill_taps(d, taps)
-    d.isy = d.isx = stride_in
-    d.B, d.TH, d.TW = B, TH, TW
-    d.cin_total = pc.cin_pad
     M = B * TH * TW
     slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
-    dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
-    big = _wgrad_big(dtype, dense, pc.cin_pad, pad_c(gC))
-    co2 = not big and _wgrad_co2(dtype, dense, pc.cin_pad, pad_c(gC))
-    s2 = _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs)
-    if s2:
-        tiles = (pc.cin_pad // 32) * (pad_c(gC) // (64 if pad_c(gC) % 64 == 0 else 32))
-        npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-        nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
-    elif dense:
-        tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
-        npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-        nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
-    else:
-        tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
-        nsplit = max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256))
-    nsplit = max(1, min(nsplit, ws.numel() * 4 // slab))
+    d.variant, nsplit, sym = _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, pc.cin_pad, pad_c(gC), ws.numel() * 4 // slab,
+                                         target_wgs)
     d.nsplit = nsplit
     d.partial = ws.data_ptr()
-    d.dtype = L.dtype_code(dtype)
-    d.variant = 5 if s2 else 2 if big else 3 if co2 else 0
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
     c0_real, c0_pad = pc.group_channels()
-    red_args = (L.ptr(ws), nsplit, len(taps), pad_c(gC), pc.cin_pad, L.ptr(grad_w), pc.cout, pc.cin, c0_real, c0_pad)
     npix = M
     keep = (d, srcs, gout, grad_w, grad_b, ws)
-
-    dname = "bf16" if dtype == torch.bfloat16 else "f32"
 
     def k_wgrad(accumulate=0, _keep=keep):
         L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
 
-    fused_bias = grad_b is not None and (s2 or (dense and not big)) and _FUSED_BIAS
-    if fused_bias:
-        d.bias_grad = grad_b.data_ptr()
+    fused_bias = _fuse_bias(lib, d, grad_b)
 
     def k_reduce(accumulate=0):
         st = L.stream_ptr()
-        L.check(lib.falnet_wgrad_reduce(*red_args, int(accumulate), st), name + " reduce")
+        L.check(lib.falnet_wgrad_reduce(L.ptr(ws), d.nsplit, len(taps), pad_c(gC), pc.cin_pad, L.ptr(grad_w), pc.cout, pc.cin, c0_real, c0_pad,
+                                        int(accumulate), st), name + " reduce")
         if grad_b is not None and not fused_bias:
             L.check(lib.falnet_bias_grad(L.ptr(gout), npix, gC, pc.cout, L.ptr(grad_b), int(accumulate),
                                          L.dtype_code(dtype), st), name + " bias")
-    t_wgrad = _timed(f"{'wgrad3x3_patch_kernel' if dense else 'wgrad_kernel'}<{dname}>", flops, 0, k_wgrad)
+    t_wgrad = _timed(sym, flops, 0, k_wgrad)
     t_reduce = _timed("wgrad_reduce+bias_grad", 0, 0, k_reduce)
 
     def call(accumulate=0):
@@ -438,6 +472,21 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
 
 _FUSED_BIAS = os.environ.get("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients inside the halo weight-gradient kernels
 _WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
+
+
+_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "512"))  # workgroups per row-streaming weight-gradient launch (two per CU)
+_WGRAD_ROWS_MIN_ROWS = int(os.environ.get("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
+
+
+def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
+    """Row-streaming weight-gradient kernel (falnet_wgrad variant 7, csrc/wgrad_rows.hip): 16-bit dense 3x3 stride-1 layers with
+    at least 64 channels on one side (a 64 x 64 block per workgroup; 32 -> 32 layers would leave three of its four waves idle),
+    32-pixel strips, sources at the launch size or exactly half of it."""
+    if not (dense and dtype in (torch.bfloat16, torch.float16) and TW >= 32 and max(cin_pad, cout_pad) >= 64):
+        return False
+    if any(not ((s.H == IH or 2 * s.H == IH) and (s.W == IW or 2 * s.W == IW)) or s.C % 32 for s in srcs):
+        return False
+    return os.environ.get("FALNET_WGRAD_ROWS", "1") == "1"
 
 
 def _wgrad_big(dtype, dense, cin_pad, cout_pad):
@@ -480,58 +529,22 @@ class WgradBatch:
     def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0, bucket=0):
         lib = L.lib()
         d = L.Wgrad()
-        d.nsrc = len(srcs)
-        for i, s in enumerate(srcs):
-            d.src[i] = s
-        d.IH, d.IW = IH, IW
+        _fill_wgrad(d, self.dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc)
         gC = gout.shape[-1]
-        d.gout, d.gC = gout.data_ptr(), gC
-        _fill_taps(d, taps)
-        d.isy = d.isx = stride_in
-        d.B, d.TH, d.TW = B, TH, TW
-        d.cin_total = pc.cin_pad
         M = B * TH * TW
         slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
-        dense = len(taps) == 9 and stride_in == 1 and TW >= 16
-        big = _wgrad_big(self.dtype, dense, pc.cin_pad, pad_c(gC))
-        co2 = not big and _wgrad_co2(self.dtype, dense, pc.cin_pad, pad_c(gC))
-        s2 = _wgrad_s2(self.dtype, taps, stride_in, TH, TW, IH, IW, srcs)
-        c3 = len(srcs) == 1 and srcs[0].C == 3  # planar f32 image source (ops.planar_src): first-layer kernel, variant 6
-        if c3:
-            assert self.dtype == torch.bfloat16 and dense and gC == 32 and pc.cin_pad == 32, "variant 6: bf16 first layer, Cout 32"
-            big = co2 = False
-            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-            nsplit = max(1, min(_WGRAD_WGS, npatch))
-        elif s2:
-            tiles = (pc.cin_pad // 32) * (pad_c(gC) // (64 if pad_c(gC) % 64 == 0 else 32))
-            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-            nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
-        elif dense:
-            tiles = (pc.cin_pad // 32) * (pad_c(gC) // 32) // (4 if big else 2 if co2 else 1)
-            npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
-            nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
-        else:
-            tiles = ((pc.cin_pad + 63) // 64) * ((gC + 63) // 64) * len(taps)
-            nsplit = max(1, min((1536 + tiles - 1) // tiles, (M + 255) // 256))
-        nsplit = max(1, min(nsplit, self.SLAB_CAP // slab))
-        d.nsplit, d.dtype, d.variant = nsplit, L.dtype_code(self.dtype), (6 if c3 else 5 if s2 else 2 if big else 3 if co2 else 0)
+        d.variant, nsplit, sym = _wgrad_plan(self.dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, pc.cin_pad, pad_c(gC), max(1, self.SLAB_CAP // slab))
+        d.nsplit = nsplit
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
-        dname = "bf16" if self.dtype == torch.bfloat16 else "f32"
 
         def launch(_keep=keep):
             L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
         c0_real, c0_pad = pc.group_channels()
         self.items.append(dict(bucket=bucket, d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
-        fused_bias = grad_b is not None and (s2 or (dense and not big)) and _FUSED_BIAS
-        if fused_bias:
-            d.bias_grad = grad_b.data_ptr()  # summed from the gout tiles the halo kernel stages anyway
-        elif grad_b is not None:
+        if not _fuse_bias(lib, d, grad_b) and grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
-        tn = "DF16b" if self.dtype == torch.bfloat16 else "f"  # symbols as rocprofv3 reports them
-        sym = "_Z18wgrad3x3_c3_kernel14falnet_wgrad_tiiii" if c3 else f"_Z18wgrad3x3_s2_kernelILi{2 if pad_c(gC) % 64 == 0 else 1}EEv14falnet_wgrad_tiiii" if s2 else ("_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii") \
-            if dense else f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
         return _timed(sym, flops, 0, launch, name)
 
     def finalize(self):

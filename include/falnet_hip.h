@@ -14,9 +14,10 @@
  *     caller-owned (`*_workspace_bytes` queries).
  *   - return value: 0 ok, <0 bad argument (see falnet_last_error()), >0 hipError_t.
  *   - re-entrant: forward runs on the Python main thread, backward on autograd's thread.
- *   - dtype enum: activations/weights are either FALNET_F32 (exact-f32 MFMA, parity path) or
- *     FALNET_BF16 (bf16 MFMA, f32 accumulate; throughput path).  Reductions, losses, the MED
- *     head and Adam are f32 in both.
+ *   - dtype enum: activations/weights are FALNET_F32 (exact-f32 MFMA, parity path), FALNET_BF16
+ *     (bf16 MFMA, f32 accumulate; throughput path) or FALNET_F16 (IEEE half MFMA, f32 accumulate:
+ *     11 significant bits instead of bf16's 8; BASELINE configs[4]).  Reductions, losses, the MED
+ *     head and Adam are f32 in all three.
  *   - activation layout inside the network: NHWC ("pixel-major"), channels padded to a
  *     multiple of falnet_channel_pad(dtype) with zeros.  The boundary tensors of the
  *     reference API (images, disparity, synthesised view, MED logits) are planar NCHW f32.
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-enum { FALNET_F32 = 0, FALNET_BF16 = 1 };
+enum { FALNET_F32 = 0, FALNET_BF16 = 1, FALNET_F16 = 2 };
 enum { FALNET_ACT_NONE = 0, FALNET_ACT_ELU = 1, FALNET_ACT_RELU = 2 };
 enum { FALNET_OUT_NHWC = 0, FALNET_OUT_PLANAR_F32 = 1 };
 
@@ -147,11 +148,19 @@ typedef struct {
                                   counts multiples of 64, LDS-DMA staged), 3 / 4 halo-patch with 32x64 / 64x32 (cin x cout)
                                   channels per workgroup (bf16), 5 parity-plane halo kernel for 3x3 stride-2 launches (bf16),
                                   6 first layer: src[0].ptr = planar f32 [B][3][IH][IW] image (src[0].C = 3), bf16 gout with 32
-                                  channels, cin_total 32 (slab layout) */
+                                  channels, cin_total 32 (slab layout),
+                                  7 row-streaming kernel (bf16 / f16, dense 3x3 stride 1, sources at the launch size or exactly
+                                  half of it): 64 x 64 channels per workgroup, LDS-DMA row ring, gout fragments in a rolling
+                                  register window; nsplit = ranges of (sample, 32-pixel column strip, row) units */
     float* bias_grad;          /* optional, halo kernels (dense 3x3 stride 1, variant 5): db[co] += sum over positions of gout[.,co]
                                   (f32 atomics, [gC]) from the gout tiles the kernel stages anyway -- replaces a falnet_bias_grad
-                                  pass over the same tensor; ignored by the per-tap kernel and variant 2 */
+                                  pass over the same tensor.  Only the kernels falnet_wgrad_fuses_bias() reports fuse it;
+                                  falnet_wgrad returns -3 when it is set for a launch whose kernel cannot */
+    int32_t cout;              /* real output channels (<= gC): bound of the fused bias gradient (bias_grad holds `cout` floats);
+                                  0 = gC */
 } falnet_wgrad_t;
+/* 1 when the kernel falnet_wgrad selects for this descriptor sums the bias gradient itself (bias_grad honoured), else 0 */
+int falnet_wgrad_fuses_bias(const falnet_wgrad_t* p);
 int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p);
 int falnet_wgrad(const falnet_wgrad_t* p, void* stream);
 /* partial [nsplit][ntaps][CoutPad][CinTot] -> grad OIHW f32 [Cout][Cin][kh][kw] (taps in kh*kw+kw order) */

@@ -652,3 +652,56 @@ def test_data_resize_full_size_properties():
     ref = D.pil_bicubic_resize_u8(img[:40].numpy(), ow, 40)  # horizontal pass only on a strip (the oracle is slow)
     hgot = DT.resize_bicubic_u8(img[:40].contiguous().to(DEV), ow, 40).cpu().numpy()
     assert np.array_equal(hgot, ref) and got.shape == (oh, ow, 3)
+
+
+def _nhwc_torch(x, dtype):
+    """NCHW f32 -> NHWC `dtype` with zero-padded channels, built with torch (dtypes the layout kernel does not take yet)."""
+    B, C, H, W = x.shape
+    out = torch.zeros(B, H, W, ops.pad_c(C), dtype=dtype, device=DEV)
+    out[..., :C] = x.to(DEV).permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+ROWS_CASES = [
+    # B, Cin groups, Cout, H, W, upsample-from (h, w) or None, bias
+    (2, [64], 64, 9, 33, None, True),            # ragged strip (one valid column in the second), bias from the register window
+    (1, [128, 256], 256, 16, 32, None, True),    # two sources, 6 x 4 channel tiles
+    (2, [32, 32], 49, 12, 40, None, True),       # one 64-channel block straddles both sources; Cout 49 -> gC 64
+    (1, [64, 32], 49, 10, 70, None, False),      # cin 96: second channel block half empty
+    (2, [64], 32, 16, 40, (8, 20), False),       # fused 2x nearest upsample of the source; gC 32: cout sub-tile 1 dead
+    (1, [64], 128, 37, 64, None, False),         # odd row count, ranges that cut columns at arbitrary rows
+    (8, [64], 64, 24, 64, None, True),           # many units: 8-aligned split counts take the XCD-grouped block mapping
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_wgrad_rows(case, dtype):
+    """falnet_wgrad variant 7 (row-streaming kernel, csrc/wgrad_rows.hip) against autograd of F.conv2d on the operands rounded
+    to the compute dtype, for several split-K factors (ranges that start / end mid-column, empty ranges, 8-aligned counts)."""
+    B, groups, Cout, H, W, up, bias = case
+    g = torch.Generator().manual_seed(H * W + Cout)
+    xs = [torch.randn(B, c, *(up or (H, W)), generator=g) for c in groups]
+    go = torch.randn(B, Cout, H, W, generator=g)
+    # reference on the rounded operands: what is left is the f32 summation order
+    xr = [x.to(dtype).float() for x in xs]
+    gr = go.to(dtype).float()
+    w = torch.zeros(Cout, sum(groups), 3, 3, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    xin = [F.interpolate(x, size=(H, W), mode="nearest") if up else x for x in xr]
+    (F.conv2d(torch.cat(xin, 1), w, b, padding=1) * gr).sum().backward()
+    pc = packed(w.detach(), b.detach() if bias else None, groups, 1, torch.bfloat16)
+    srcs_t = [_nhwc_torch(x, dtype) for x in xs]
+    g_t = _nhwc_torch(go, dtype)
+    ws = torch.empty(16 << 20, device=DEV)
+    taps = [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)]
+    for nsplit in (1, 3, 8, 16, 40):
+        gw = torch.full(w.shape, float("nan"), device=DEV)
+        gb = torch.full((Cout,), float("nan"), device=DEV) if bias else None
+        call = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, g_t, taps, 1, B, H, W, pc, gw, gb, ws)
+        assert call.desc.variant == 7
+        call.desc.nsplit = min(nsplit, ws.numel() * 4 // (9 * ops.pad_c(Cout) * pc.cin_pad * 4))
+        call(0)
+        assert rel(gw, w.grad) < 2e-5, (nsplit, rel(gw, w.grad))
+        if bias:
+            assert rel(gb, b.grad) < 2e-5
