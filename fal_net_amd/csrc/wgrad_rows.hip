@@ -22,6 +22,7 @@
 // Split-K: the (sample, strip, row) units are cut into nsplit contiguous ranges; every workgroup writes one f32 slab
 // [9][64][64] into partial[split][tap][co][ci] (falnet_wgrad_reduce_batched sums them).  blockIdx -> (split, tile) keeps
 // the channel tiles of one pixel range on one XCD (they stream the same rows: L2 hits).
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -84,7 +85,7 @@ __device__ __forceinline__ void wr_vmcnt() {
 
 struct WrCursor { int u, n, s, b, x0, y0; };  // item = rows [y0, y0+n) of column strip x0 of sample b; s = step inside it (0..n+1)
 
-template <typename T, int D>
+template <typename T, int D, int ABL = 0>  // ABL: timing-only ablations (1 no DMA in the loop, 2 no MFMAs, 3 no fragment reads / MFMAs)
 __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
     constexpr int NS = D + 1;
     static_assert(D >= 1 && D <= 3, "prefetch distance");
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
     for (int g = 0; g < nst; ++g) {
         // this wave's pieces of step g have landed once at most k steps' worth of younger pieces are outstanding
         const int k = min(D - 1, nst - 1 - g);
-        if (wave == 0) {
+        if (ABL == 1) {
+        } else if (wave == 0) {
             if (k >= 2) wr_vmcnt<(D >= 3 ? 6 : 0)>();
             else if (k == 1) wr_vmcnt<(D >= 2 ? 3 : 0)>();
             else wr_vmcnt<0>();
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of step g - 1 are done (slot reuse below)
         __builtin_amdgcn_s_barrier();
-        if (g + D < nst) {
+        if (ABL != 1 && g + D < nst) {
             issue(ci_, islot);
             if (g + D + 1 < nst && advance(ci_)) item_bases(ci_);
         }
@@ -247,12 +249,17 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
         s16x8 a0[2], bf[2][3];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
+            if (ABL == 3) {
+                a0[hf] = aw1[hf];
+                bf[hf][0] = bf[hf][1] = bf[hf][2] = aw2[hf];
+                continue;
+            }
             a0[hf] = frag(Gs + offA + hf * 16 * 128);
             bf[hf][0] = frag(Xs + offB0 + hf * 16 * 128);
             bf[hf][1] = frag(Xs + offB1 + hf * 16 * 128);
             bf[hf][2] = frag(Xs + offB2 + hf * 16 * 128);
         }
-        if (a_live && xv) {  // wave-uniform branches around groups of three MFMAs (a fast path duplicating the eighteen made hipcc spill)
+        if (ABL < 2 && a_live && xv) {  // wave-uniform branches around groups of three MFMAs (a fast path duplicating the eighteen made hipcc spill)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 if (m0) {
@@ -309,6 +316,338 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Eight-wave form (the one the dispatcher launches): ONE workgroup per CU.  The four (cin, cout) sub-tile roles exist twice,
+// once per 16-pixel half of the strip, so both wave groups consume the SAME rows in LDS (half the L2 -> LDS traffic per MFMA
+// of two independent four-wave workgroups) and their accumulators are summed through LDS before one slab leaves the CU:
+// 256 slabs per layer instead of 512.  A step moves TWO image rows (18 MFMAs per wave and barrier); every wave keeps running
+// per-lane source pointers (one 64-bit add per piece and step; lanes outside the image or the channel range sit on the zero
+// page with increment 0), so the steady-state loop has no address arithmetic beyond that.
+#define WR8_THREADS 512
+#define WR8_SLOT (2 * WR_GROW + 2 * WR_XROW)   // 18 KiB: gout rows r0, r1, input rows j0, j1
+#define WR8_RED (4 * 9 * 4 * 1024)             // epilogue: 4 waves x 9 accumulator tiles x 4 KiB
+
+struct Wr8Item { int u, n, T, t, b, x0, y0; };  // rows [y0, y0+n) of strip x0 of sample b; t = step inside it (two rows per step)
+
+template <typename T, int D, int ABL = 0, bool STAGGER = true>
+__global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
+    constexpr int NS = D + 1;
+    static_assert(D >= 1 && D <= 3, "prefetch distance");
+    constexpr int LDS_BYTES = NS * WR8_SLOT > WR8_RED ? NS * WR8_SLOT : WR8_RED;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(wr_lptr_t)lds;
+    const int nsplit = p.nsplit;
+    int tile, split;
+    {
+        const int wg = blockIdx.x;
+        if ((nsplit & 7) == 0) {  // the channel tiles of one pixel range share an XCD (blocks b and b + 8 do)
+            const int idx = wg >> 3;
+            split = (idx / ntiles) * 8 + (wg & 7);
+            tile = idx % ntiles;
+        } else {
+            tile = wg % ntiles;
+            split = wg / ntiles;
+        }
+    }
+    const int ci0 = (tile % ntci) * 64, co0 = (tile / ntci) * 64;
+    const int hf = wave >> 2, a_t = (wave >> 1) & 1, c_t = wave & 1;  // 16-pixel half, 32-channel sub-tiles (cin, cout)
+    const int rsel = wave >> 2, pw = wave & 3;                        // DMA role: row of the step's pair, 8-pixel piece
+    const int H = p.TH, TW = p.TW, gC = p.gC, IH = p.IH;
+    const int R = p.B * nstrips * H;
+    const int u0 = (int)((int64_t)R * split / nsplit), u1 = (int)((int64_t)R * (split + 1) / nsplit);
+
+    // ---- per-lane DMA geometry (as the four-wave kernel) ----
+    const int pl = lane >> 3, cpos = lane & 7;
+    const int gch = cpos ^ (((pl >> 1) & 1) << 2);
+    const char* const zero_page = reinterpret_cast<const char*>(g_wr_zero);
+    const bool g_chok = co0 + 8 * gch < gC;
+    const int ch = ci0 + 8 * gch;
+    const bool x_chok = ch < p.cin_total;
+    const int c_first = p.src[0].C;
+    const bool second = p.nsrc > 1 && ch >= c_first;
+    const falnet_src_t& S = second ? p.src[1] : p.src[0];
+    const int l_hs = S.H != IH ? 1 : 0, l_ws = S.W != p.IW ? 1 : 0;
+    const int64_t l_sy = S.sy, l_sx = S.sx, l_sb = S.sb;
+    const T* const l_ptr = reinterpret_cast<const T*>(S.ptr) + (second ? ch - c_first : ch);
+
+    auto load_item = [&](Wr8Item& c, int u) {
+        c.u = u;
+        const int bs = u / H;
+        c.y0 = u - bs * H;
+        c.n = min((bs + 1) * H, u1) - u;
+        c.T = (c.n + 3) >> 1;
+        c.b = bs / nstrips;
+        c.x0 = (bs - c.b * nstrips) * WR_TW;
+        c.t = 0;
+    };
+    int nst = 0;
+    for (int u = u0; u < u1;) {
+        const int e = min((u / H + 1) * H, u1);
+        nst += (e - u + 3) >> 1;
+        u = e;
+    }
+
+    // running per-lane source pointers of THIS wave's pieces (rows y0 + rsel + 2t / y0 - 1 + rsel + 2t) and their per-step increments
+    const char* gptr = zero_page;
+    const char* xptr = zero_page;
+    const char* x4ptr = zero_page;
+    unsigned g_inc = 0, x_inc = 0, x4_inc = 0;
+    auto item_pointers = [&](const Wr8Item& c) {
+        const int gx = c.x0 + 8 * pw + pl;
+        const bool g_ok = g_chok && gx < TW;
+        gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H + c.y0 + rsel) * TW + gx) * gC + co0 + 8 * gch) : zero_page;
+        g_inc = g_ok ? (unsigned)(2 * TW * gC * (int)sizeof(T)) : 0u;
+        const int i = c.y0 - 1 + rsel;
+        const int64_t rowoff = (int64_t)c.b * l_sb + (int64_t)(i >> l_hs) * l_sy;
+        const unsigned xi = (unsigned)((l_hs ? l_sy : 2 * l_sy) * (int)sizeof(T));
+        const int xa = c.x0 - 1 + 8 * pw + pl;
+        const bool x_ok = x_chok && xa >= 0 && xa < p.IW;
+        xptr = x_ok ? reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)(xa >> l_ws) * l_sx) : zero_page;
+        x_inc = x_ok ? xi : 0u;
+        const int xb = c.x0 - 1 + 32 + pl;
+        const bool x4_ok = x_chok && pl < 2 && xb < p.IW;
+        x4ptr = x4_ok ? reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)(xb >> l_ws) * l_sx) : zero_page;
+        x4_inc = x4_ok ? xi : 0u;
+    };
+    auto issue = [&](const Wr8Item& c, int slot) {
+        const unsigned base = lds_base + slot * WR8_SLOT;
+        const bool gv = 2 * c.t + rsel < c.n;                    // gout row inside the item
+        const int i = c.y0 - 1 + 2 * c.t + rsel;
+        const bool xv = i >= 0 && i < IH;                         // input row inside the image
+        wr_glds16(gv ? gptr : zero_page, base + rsel * WR_GROW + pw * 1024);
+        wr_glds16(xv ? xptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + pw * 1024);
+        if (pw == 0) wr_glds16(xv ? x4ptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + 4 * 1024);
+        gptr += g_inc;
+        xptr += x_inc;
+        x4ptr += x4_inc;
+    };
+
+    // ---- fragment read geometry ----
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
+    auto frag_off = [&](int tile32, int pshift) {
+        const int gc = tile32 * 4 + cb * 2 + (pc >> 1);
+        const int sw = ((pshift + q) >> 1) & 1;
+        return (q + 8 * kh) * 128 + ((gc ^ (sw << 2)) * 16) + (pc & 1) * 8;
+    };
+    const int offA = frag_off(c_t, 0) + hf * 16 * 128;
+    const int offB0 = 2 * WR_GROW + frag_off(a_t, 0) + hf * 16 * 128, offB1 = 2 * WR_GROW + frag_off(a_t, 1) + 128 + hf * 16 * 128,
+              offB2 = 2 * WR_GROW + frag_off(a_t, 2) + 256 + hf * 16 * 128;
+    auto frag = [&](const char* base) -> s16x8 {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base + 4 * 128));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[dy][dx][j] = 0.f;
+    s16x8 w_a, w_b;  // gout fragments of the two previous rows (relative rows 2t-2, 2t-1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w_a[j] = w_b[j] = 0;
+    const bool a_live = ci0 + 32 * a_t < p.cin_total && co0 + 32 * c_t < gC;
+    const bool do_bias = p.bias_grad != nullptr && (tile % ntci) == 0 && a_t == 0;
+    float bsum = 0.f;
+
+    Wr8Item ci_, cc_;
+    if (nst > 0) {
+        load_item(ci_, u0);
+        cc_ = ci_;
+        item_pointers(ci_);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < nst) {
+                issue(ci_, d);
+                if (d + 1 < nst && ++ci_.t == ci_.T) {
+                    load_item(ci_, ci_.u + ci_.n);
+                    item_pointers(ci_);
+                }
+            }
+        }
+    }
+    int slot = 0, islot = D;
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int seg) {  // ABL == 9 (diagnostic build): cycles of the loop segment that ends here
+        if constexpr (ABL == 9) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (seg >= 0) st_sum[seg] += t - st_prev;
+            st_prev = t;
+        }
+    };
+    stamp(-1);
+    const unsigned long long rt0 = ABL == 9 ? __builtin_amdgcn_s_memrealtime() : 0ull, ct0 = st_prev;
+    // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD" item 9): waves w and w + 4 share a SIMD and run the same program
+    // between the same barriers, so un-staggered their MFMA phases collide and their DMA-issue / fragment-read phases leave
+    // the matrix pipe idle together (stamps: 1150 of 2450 cycles per step in MFMAs).  Waves 4-7 (`lag`) therefore run the
+    // MFMAs of step g - 1 right AFTER barrier g and only then issue their DMA pieces and read the fragments of step g, while
+    // waves 0-3 issue / read first and multiply last: matrix work of one group beside the memory work of the other.  The
+    // fragments and their validity flags simply stay in registers across the barrier; nothing else changes.
+    const bool lag = STAGGER && hf == 1;
+    s16x8 n_a, n_b, xa[3], xb[3];
+    int m_t2 = 0, m_n = 0;          // relative row 2t and row count of the step whose fragments are in registers
+    bool m_vx0 = false, m_vx1 = false, m_have = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n_a[j] = n_b[j] = 0;
+    auto issue_and_read = [&](int g) {  // DMA pieces of step g + D, then this wave's fragments of step g
+        if (ABL != 1 && g + D < nst) {
+            issue(ci_, islot);
+            if (g + D + 1 < nst && ++ci_.t == ci_.T) {
+                load_item(ci_, ci_.u + ci_.n);
+                item_pointers(ci_);
+            }
+        }
+        stamp(2);
+        const char* sb = lds + slot * WR8_SLOT;
+        m_t2 = 2 * cc_.t;
+        m_n = cc_.n;
+        const int i0 = cc_.y0 - 1 + m_t2;
+        m_vx0 = i0 >= 0 && i0 < IH;
+        m_vx1 = i0 + 1 >= 0 && i0 + 1 < IH;
+        m_have = true;
+        if (ABL == 3) {
+            n_a = w_a; n_b = w_b;
+            xa[0] = xa[1] = xa[2] = xb[0] = xb[1] = xb[2] = w_a;
+        } else {
+            n_a = frag(sb + offA);
+            n_b = frag(sb + WR_GROW + offA);
+            xa[0] = frag(sb + offB0);
+            xa[1] = frag(sb + offB1);
+            xa[2] = frag(sb + offB2);
+            xb[0] = frag(sb + WR_XROW + offB0);
+            xb[1] = frag(sb + WR_XROW + offB1);
+            xb[2] = frag(sb + WR_XROW + offB2);
+        }
+        if (g + 1 < nst && ++cc_.t == cc_.T) load_item(cc_, cc_.u + cc_.n);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        islot = islot + 1 == NS ? 0 : islot + 1;
+        stamp(3);
+    };
+    for (int g = 0; g <= nst; ++g) {
+        if (g < nst) {
+            // this wave's pieces of step g have landed once at most k steps' worth of younger pieces are outstanding
+            const int k = min(D - 1, nst - 1 - g);
+            if (ABL == 1) {
+            } else if (pw == 0) {
+                if (k >= 2) wr_vmcnt<(D >= 3 ? 6 : 0)>();
+                else if (k == 1) wr_vmcnt<(D >= 2 ? 3 : 0)>();
+                else wr_vmcnt<0>();
+            } else {
+                if (k >= 2) wr_vmcnt<(D >= 3 ? 4 : 0)>();
+                else if (k == 1) wr_vmcnt<(D >= 2 ? 2 : 0)>();
+                else wr_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of step g - 1 are done (slot reuse)
+            stamp(0);
+            __builtin_amdgcn_s_barrier();
+            stamp(1);
+            if (!lag) issue_and_read(g);
+        }
+        if (m_have) {  // the step whose fragments are in registers: g for waves 0-3, g - 1 for the lagging waves 4-7
+            const int t2 = m_t2;
+            auto vr = [&](int r) { return (unsigned)r < (unsigned)m_n; };
+            if ((ABL < 2 || ABL == 9) && a_live) {  // wave-uniform branches around groups of three MFMAs
+                if (m_vx0) {  // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
+                    if (vr(t2)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_a, xa[dx], acc[0][dx]);
+                    }
+                    if (vr(t2 - 1)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(w_b, xa[dx], acc[1][dx]);
+                    }
+                    if (vr(t2 - 2)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_a, xa[dx], acc[2][dx]);
+                    }
+                }
+                if (m_vx1) {  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
+                    if (vr(t2 + 1)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_b, xb[dx], acc[0][dx]);
+                    }
+                    if (vr(t2)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(n_a, xb[dx], acc[1][dx]);
+                    }
+                    if (vr(t2 - 1)) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_b, xb[dx], acc[2][dx]);
+                    }
+                }
+            }
+            if (do_bias) {  // rows outside the item arrive as zeros
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += Mma16<T>::f32(n_a[j]) + Mma16<T>::f32(n_b[j]);
+            }
+            w_a = n_a;
+            w_b = n_b;
+            m_have = false;
+        }
+        stamp(4);
+        if (lag && g < nst) issue_and_read(g);
+    }
+
+    // ---- the two halves' accumulators are summed through LDS: waves 4-7 deposit, waves 0-3 add and write the slab ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is past its last ring read: the ring space is reused
+    float* red = reinterpret_cast<float*>(lds) + (wave & 3) * (9 * 4 * 256) + lane * 4;
+    if (hf == 1) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    *reinterpret_cast<float4*>(red + ((dy * 3 + dx) * 4 + j4) * 256) =
+                        make_float4(acc[dy][dx][4 * j4], acc[dy][dx][4 * j4 + 1], acc[dy][dx][4 * j4 + 2], acc[dy][dx][4 * j4 + 3]);
+    }
+    __syncthreads();
+    if (do_bias) {  // lane (r, h) summed pixels 8h..8h+7 of its half of every row for channel co0 + 32 c_t + r
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int co = co0 + 32 * c_t + (lane & 31);
+        if ((lane >> 5) == 0 && co < p.cout) atomicAdd(p.bias_grad + co, bsum);
+    }
+    if (hf == 1 && ABL != 9) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + 32 * a_t + r;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float* dst = p.partial + (((int64_t)split * 9 + dy * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const float4 o = *reinterpret_cast<const float4*>(red + ((dy * 3 + dx) * 4 + j4) * 256);
+                const float v[4] = {acc[dy][dx][4 * j4] + o.x, acc[dy][dx][4 * j4 + 1] + o.y, acc[dy][dx][4 * j4 + 2] + o.z, acc[dy][dx][4 * j4 + 3] + o.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * j4 + e;
+                    const int co = co0 + 32 * c_t + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (ci < p.cin_total && co < w_rows) dst[(int64_t)co * p.cin_total + ci] = v[e];
+                }
+            }
+        }
+    __syncthreads();
+    if constexpr (ABL == 9) {  // per-wave segment sums + step count into the head of this workgroup's slab (timing-only build)
+        if (lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.partial + (int64_t)split * 9 * w_rows * p.cin_total) + (tile * 8 + wave) * 8;
+            for (int q2 = 0; q2 < 5; ++q2) o[q2] = st_sum[q2];
+            o[5] = (unsigned long long)nst;
+            o[6] = __builtin_amdgcn_s_memrealtime() - rt0;  // 100 MHz ticks over the loop
+            o[7] = st_prev - ct0;                            // shader cycles over the loop
+        }
+    }
+}
+
 // does this launch fit the row-streaming kernel?  (16-bit operands, canonical dense 3x3 stride 1, sources at the launch
 // size or exactly half of it, at least one 64-channel side)
 bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p) {
@@ -335,9 +674,22 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
     const int ntiles = ntci * ntco;
     const int nstrips = (p.TW + WR_TW - 1) / WR_TW;
     const dim3 grid((unsigned)(ntiles * p.nsplit));
-    if (p.dtype == FALNET_BF16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<bf16_t, 3>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<f16_t, 3>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    static const int abl = [] { const char* e = getenv("FALNET_WR_ABL"); return e ? atoi(e) : 0; }();
+    static const int form = [] { const char* e = getenv("FALNET_WR_FORM"); return e ? atoi(e) : 8; }();  // 8: eight-wave form (default), 4: four waves
+#define WR_LAUNCH8(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<TT, DD, AA>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
+#define WR_LAUNCH4(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<TT, DD, AA>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
+    if (form == 4) {
+        if (p.dtype == FALNET_F16) WR_LAUNCH4(f16_t, 3, 0);
+        else WR_LAUNCH4(bf16_t, 3, 0);
+    } else if (p.dtype == FALNET_F16) {
+        WR_LAUNCH8(f16_t, 2, 0);
+    } else if (abl == 1) WR_LAUNCH8(bf16_t, 2, 1);
+    else if (abl == 2) WR_LAUNCH8(bf16_t, 2, 2);
+    else if (abl == 3) WR_LAUNCH8(bf16_t, 2, 3);
+    else if (abl == 13) WR_LAUNCH8(bf16_t, 3, 0);
+    else if (abl == 9) WR_LAUNCH8(bf16_t, 2, 9);
+    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else if (abl == 29) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 9, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else WR_LAUNCH8(bf16_t, 2, 0);
     FALNET_RETURN_LAUNCH();
 }

@@ -387,7 +387,7 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
         if nsplit >= 8:
             nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
-        variant, sym = 7, f"_Z20wgrad3x3_rows_kernelI{tn}Li3EEv14falnet_wgrad_tiiii"
+        variant, sym = 7, f"_Z21wgrad3x3_rows8_kernelI{tn}Li2ELi0EEv14falnet_wgrad_tiiii"
     elif dense:
         big = _wgrad_big(dtype, dense, cin_pad, cout_pad)
         co2 = not big and _wgrad_co2(dtype, dense, cin_pad, cout_pad)
@@ -474,7 +474,7 @@ _FUSED_BIAS = os.environ.get("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients 
 _WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
 
 
-_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "512"))  # workgroups per row-streaming weight-gradient launch (two per CU)
+_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "256"))  # workgroups per row-streaming weight-gradient launch (one eight-wave workgroup per CU)
 _WGRAD_ROWS_MIN_ROWS = int(os.environ.get("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
 
 
