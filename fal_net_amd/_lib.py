@@ -82,7 +82,8 @@ SIGNATURES = {
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
     "falnet_pack_weights_batched": [_P, _I, _I, _I, _P],
-    "falnet_wgrad_reduce_batched": [_P, _I, _I, _P],
+    "falnet_wgrad_reduce_batched": [_P, _I, _I, _I, _P],
+    "falnet_wgrad_reduce_blocks": [_I, _I, _I],
     "falnet_bias_grad_batched": [_P, _I, _I, _I, _P],
     "falnet_pack_weights": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "falnet_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -518,6 +518,7 @@ class FalnetPlan:
         if g_pan is not None:
             b["g_pan"].copy_(g_pan)
         self._accumulate = self.model._begin_grad_accumulation()
+        self.wbatch.accumulate = 1 if self._accumulate else 0
         if not self._accumulate:
             self.model._flat_grad.zero_()  # the batched reduce / bias kernels ADD into the flat gradient buffer
         if getattr(self.model, "_compose_logits", False):

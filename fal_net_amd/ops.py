@@ -474,7 +474,10 @@ _FUSED_BIAS = os.environ.get("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients 
 _WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
 
 
-_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "256"))  # workgroups per row-streaming weight-gradient launch (one eight-wave workgroup per CU)
+_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "128"))  # workgroups (one per CU, eight waves) per row-streaming weight-gradient launch: half the chip,
+# the other half runs the data-gradient chain beside it (same-box A/B: 128 beats 256 by 3 % on the step and halves the slab bytes)
+_REDUCE_PER_LAYER = os.environ.get("FALNET_REDUCE_PER_LAYER", "0") == "1"
+_REDUCE_BLOCKS = int(os.environ.get("FALNET_REDUCE_BLOCKS", "64"))  # blocks per layer of the batched slab reduce (split over slab groups)
 _WGRAD_ROWS_MIN_ROWS = int(os.environ.get("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
 
 
@@ -525,6 +528,7 @@ class WgradBatch:
         self.dtype, self.device = dtype, device
         self.items, self.bias = [], []
         self.ws = None
+        self.accumulate = 1  # set per backward by the plan: 0 = the step's gradient buffer was zeroed, single-writer entries may overwrite
 
     def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0, bucket=0):
         lib = L.lib()
@@ -538,14 +542,23 @@ class WgradBatch:
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
 
+        post = []  # per-layer mode: this layer's slab reduce, launched right behind the wgrad (finalize() fills it in)
+
         def launch(_keep=keep):
             L.check(lib.falnet_wgrad(ref, L.stream_ptr()), name)
         c0_real, c0_pad = pc.group_channels()
-        self.items.append(dict(bucket=bucket, d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
+        self.items.append(dict(bucket=bucket, post=post, d=d, bytes=nsplit * slab, nsplit=nsplit, ntaps=len(taps), w_rows=pad_c(gC), cin_total=pc.cin_pad,
                                cout=pc.cout, cin=pc.cin, c0_real=c0_real, c0_pad=c0_pad, grad=grad_w))
         if not _fuse_bias(lib, d, grad_b) and grad_b is not None:
             self.bias.append(dict(bucket=bucket, g=gout, npix=M, gC=gC, cout=pc.cout, db=grad_b))
-        return _timed(sym, flops, 0, launch, name)
+        t_launch = _timed(sym, flops, 0, launch, name)
+
+        def launch_and_reduce():
+            t_launch()
+            for c in post:
+                c()
+        launch_and_reduce.tag, launch_and_reduce.flops, launch_and_reduce.name = t_launch.tag, flops, name
+        return launch_and_reduce
 
     def finalize(self):
         """Allocate the slab arena, point every wgrad descriptor at its region, upload the descriptor tables.
@@ -562,15 +575,32 @@ class WgradBatch:
         out, self._tables = {}, []
         code = L.dtype_code(self.dtype)
         for bucket in sorted({it["bucket"] for it in self.items}):
-            items = [it for it in self.items if it["bucket"] == bucket]
-            red = (L.ReduceDesc * len(items))()
+            all_items = [it for it in self.items if it["bucket"] == bucket]
+            # per-layer mode: a layer's slabs (<= 19 MB) are reduced right behind its wgrad launch, while they still sit in
+            # L2 / the 256 MiB Infinity Cache, instead of by one launch per bucket that re-reads 100-300 MB from HBM
+            items = [] if _REDUCE_PER_LAYER else all_items
+            for it in (all_items if _REDUCE_PER_LAYER else []):
+                one = (L.ReduceDesc * 1)()
+                base = lib.falnet_wgrad_reduce_blocks(it["cout"], it["cin_total"], 1)
+                groups = max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
+                r = one[0]
+                r.partial, r.grad = it["partial"], it["grad"].data_ptr()
+                r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
+                r.cout, r.cin, r.c0_real, r.c0_pad, r.groups, r.block_begin = it["cout"], it["cin"], it["c0_real"], it["c0_pad"], groups, 0
+                one_dev = torch.frombuffer(bytearray(bytes(one)), dtype=torch.uint8).to(self.device)
+                self._tables.append(one_dev)
+
+                def reduce_one(one_dev=one_dev, blocks=base * groups):
+                    L.check(lib.falnet_wgrad_reduce_batched(L.ptr(one_dev), 1, blocks, int(self.accumulate), L.stream_ptr()), "wgrad_reduce")
+                it["post"].append(_timed("wgrad_reduce_batched", 0, 0, reduce_one, "wgrad_reduce(layer)"))
+            red = (L.ReduceDesc * max(len(items), 1))()
             blk = 0
             for i, it in enumerate(items):
-                blocks = it["cout"] * ((it["cin_total"] + 63) // 64)
-                groups = 1
-                if it["nsplit"] >= 16 and blocks < 1024:
-                    groups = (1024 + blocks - 1) // blocks
-                groups = max(1, min(groups, it["nsplit"] // 8))
+                # slab groups: enough blocks to pull the slabs at the HBM rate (a block keeps <= 18 16-B loads per thread in
+                # flight), at least four slabs per group; groups > 1 makes the kernel add with atomics
+                base = lib.falnet_wgrad_reduce_blocks(it["cout"], it["cin_total"], 1)
+                groups = max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
+                blocks = base
                 r = red[i]
                 r.partial, r.grad = it["partial"], it["grad"].data_ptr()
                 r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
@@ -591,7 +621,8 @@ class WgradBatch:
             self._tables += [red_dev, bias_dev]
 
             def reduce_all(red_dev=red_dev, n=len(items), blocks=blk):
-                L.check(lib.falnet_wgrad_reduce_batched(L.ptr(red_dev), n, blocks, L.stream_ptr()), "wgrad_reduce_batched")
+                if n:
+                    L.check(lib.falnet_wgrad_reduce_batched(L.ptr(red_dev), n, blocks, int(self.accumulate), L.stream_ptr()), "wgrad_reduce_batched")
 
             def bias_all(bias_dev=bias_dev, n=len(biases), blocks=bblk):
                 if n:

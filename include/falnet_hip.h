@@ -172,10 +172,13 @@ int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pa
 int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db,
                      int accumulate, int dtype, void* stream);
 
-/* Batched forms: device-resident descriptor tables, ONE launch for all layers of a step.  Both ADD into the
- * gradient buffers (f32 atomics): the caller zeroes the flat gradient buffer once per step (or keeps it to accumulate).
- * block_begin = first blockIdx.x of the entry; reduce entry uses cout * ceil(cin_total/64) * groups blocks
- * (block -> (co, 64-channel chunk, slab group)), bias entry uses `blocks` blocks. */
+/* Batched forms: device-resident descriptor tables, ONE launch for all layers of a step.  The bias form ADDS into the
+ * gradient buffers (f32 atomics), the reduce form as its `accumulate` argument says: the caller zeroes the flat gradient
+ * buffer once per step (or keeps it to accumulate).
+ * block_begin = first blockIdx.x of the entry; a reduce entry uses ceil(cout / cob) * groups blocks with
+ * cob = max(1, 1024 / cin_total) output channels per block (falnet_wgrad_reduce_blocks; block -> (channel block, slab group);
+ * groups == 1: plain read-modify-write of the gradient, else f32 atomics); ntaps in {1, 3, 9}; bias entry uses `blocks` blocks. */
+int falnet_wgrad_reduce_blocks(int cout, int cin_total, int groups);
 typedef struct {
     const float* partial; float* grad;
     int32_t nsplit, ntaps, w_rows, cin_total, cout, cin, c0_real, c0_pad, groups, block_begin;
@@ -189,7 +192,9 @@ typedef struct {
     int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps 9, 3 or 1 */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
-int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, void* stream);
+/* accumulate == 0: entries with groups == 1 OVERWRITE their gradient (plain stores), entries with groups > 1 add into it
+ * (atomics: the caller zeroes those); accumulate != 0: every entry adds */
+int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, int accumulate, void* stream);
 int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 
 /*
