@@ -67,29 +67,56 @@ def hbm_traffic_from_profiles(kernel_symbol):
     return None
 
 
-def cpu_baseline(height, width, levels, sample_batch=8):
-    """Reported CPU baseline: the oracle's Stage-1 step (fp32, torch CPU) on a bounded sample.
+def cpu_baseline(workload, height, width, levels, sample_batch=2, timed=3):
+    """Reported CPU baseline: the oracle's step of the same workload (fp32, torch CPU) on a bounded sample: one warm-up
+    step, then `timed` steps, plus the single-pair forward of BASELINE configs[0].
     Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get *slower* beyond that
     (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
     from fal_net_amd import synthetic
     from oracle import falnet_oracle as O
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    if height * width > 256 * 512:
+        sample_batch, timed = 1, 2  # 384x1280, N=96: one pair per step keeps the leg under a minute
     left, right, mn, mx = synthetic.synthetic_pair(sample_batch, height, width, seed=1234)
-    params = O.leaf_params(synthetic.seeded_falnetb_state_dict(levels))
+    sd = synthetic.seeded_falnetb_state_dict(levels)
+    params = O.leaf_params(sd)
     vsd = synthetic.seeded_vgg19_state_dict()
     opt = O.OracleAdam(params)
+
+    def step():
+        if workload == "stage2":
+            for q in params.values():
+                q.grad = None
+            O.stage2_losses(params, sd, vsd, left, right, mn, mx)["loss"].backward()
+            opt.step()
+        else:
+            O.stage1_step(params, opt, vsd, left, right, mn, mx)
+    step()  # warm-up (allocator, thread pool)
     t0 = time.time()
-    O.stage1_step(params, opt, vsd, left, right, mn, mx)
-    dt = time.time() - t0
+    for _ in range(timed):
+        step()
+    dt = (time.time() - t0) / timed
+    one = synthetic.synthetic_pair(1, 256, 512, seed=99)
+    sd49 = sd if levels == 49 else synthetic.seeded_falnetb_state_dict(49)
+    with torch.no_grad():
+        O.falnet_forward(sd49, one[0], one[2], one[3])
+        t1 = time.time()
+        for _ in range(3):
+            O.falnet_forward(sd49, one[0], one[2], one[3])
+        fwd = (time.time() - t1) / 3
+    name = {"stage1": "Stage-1 step (fwd+VGG+losses+bwd+Adam)", "stage2": "Stage-2 step (teacher fwd, 2B student fwd, masks, losses, bwd, Adam)",
+            "highres": "Stage-1 step (fwd+VGG+losses+bwd+Adam)"}[workload]
     return {"value": sample_batch / dt, "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 Stage-1 step (fwd+VGG+losses+bwd+Adam), B={sample_batch}, {height}x{width}, N={levels}, "
-                      f"fp32 torch-CPU oracle, {torch.get_num_threads()} threads, {dt:.1f} s"}
+            "sample": f"1 warm-up + {timed} timed x {name}, B={sample_batch}, {height}x{width}, N={levels}, "
+                      f"fp32 torch-CPU oracle, {torch.get_num_threads()} threads, {dt:.2f} s per step",
+            "configs0_forward_pairs_per_s": 1.0 / fwd,
+            "configs0_sample": f"FAL_netB forward, one 256x512 pair, N=49, fp32 torch-CPU oracle, {fwd * 1e3:.0f} ms (mean of 3 after 1 warm-up)"}
 
 
 def parity_vs_oracle(height, width, levels, dev):
     """SURVEY 8(d) `abs_rel vs ref`: one seeded pair through the CPU oracle (fixture-pinned restatement of the reference) and
-    through the HIP path in f32 (gate 1e-4) and bf16 (reported); depth = f*b/disp, abs_rel = mean(|d_ref - d_hip| / d_ref)
+    through the HIP path in f32 (gate 1e-4), bf16 and f16 (reported); depth = f*b/disp, abs_rel = mean(|d_ref - d_hip| / d_ref)
     (myUtils.py:225).  Part of the cpu_baseline leg: the only place bench.py touches oracle/."""
     import numpy as np
     from fal_net_amd import synthetic
@@ -101,7 +128,7 @@ def parity_vs_oracle(height, width, levels, dev):
         ref = O.falnet_forward(sd, left, mn, mx)
     d_ref = O.disp_to_depth(ref.numpy())
     out = {}
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         m = FAL_netB({"state_dict": sd}, no_levels=levels, compute_dtype=dt).to(dev).eval()
         with torch.no_grad():
             disp = m(left.to(dev), mn.to(dev), mx.to(dev)).float().cpu()
@@ -123,13 +150,20 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--levels", type=int, default=49)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="stage1", choices=["stage1", "stage2", "highres"],
+                    help="stage1: BASELINE configs[1] (default); stage2: configs[3] (Train_Stage2_K.py:233-331, teacher = copy of the "
+                         "student); highres: configs[4] (Stage-1 step at 384x1280, N=96, f16 unless --dtype says otherwise)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.0: off by default)")
     ap.add_argument("--launch-table", default=None, help="write the per-launch time table of the instrumented pass here")
     args = ap.parse_args()
+    if args.workload == "highres":
+        args.height, args.width, args.levels = 384, 1280, 96
+    if args.dtype is None:
+        args.dtype = "f16" if args.workload == "highres" else "bf16"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -150,7 +184,7 @@ def main():
     from fal_net_amd import ops, synthetic, train
     from fal_net_amd.models import FAL_netB
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     LF.set_compute_dtype(dtype)
     model = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(args.levels)}, no_levels=args.levels,
                      compute_dtype=dtype).to(dev).train()
@@ -158,11 +192,20 @@ def main():
     left, right, mn, mx = synthetic.synthetic_pair(args.batch, args.height, args.width, seed=1234 + rank)
     left, right, mx = left.to(dev), right.to(dev), mx.to(dev)  # inputs resident in HBM before the timed region
 
+    fix_model = None
+    if args.workload == "stage2":  # frozen Stage-1 teacher (Train_Stage2_K.py:190-198): here a copy of the student's weights
+        fix_model = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(args.levels)}, no_levels=args.levels,
+                             compute_dtype=dtype).to(dev).eval()
+        for q in fix_model.parameters():
+            q.requires_grad_(False)
+
     def eager_step():
+        if fix_model is not None:
+            return train.stage2_step(model, fix_model, opt, left, right, mx)
         return train.stage1_step(model, opt, left, right, mx)
 
     step, graphed = eager_step, False
-    if args.graph:
+    if args.graph and args.workload != "stage2":
         try:
             step = train.GraphedStage1Step(model, opt, left, right, mx)
             graphed = True
@@ -192,12 +235,14 @@ def main():
     ms = elapsed * 1e3 / args.steps
     pairs_per_s = world * args.batch * args.steps / elapsed
 
+    stage = "Stage-2" if args.workload == "stage2" else "Stage-1"
+    cfg_name = {"stage1": "BASELINE configs[1]", "stage2": "BASELINE configs[3] on one GPU", "highres": "BASELINE configs[4] on one GPU"}[args.workload]
     result = {
-        "metric": f"stereo-pairs/sec Stage-1 step @{args.height}x{args.width} N={args.levels}",
+        "metric": f"stereo-pairs/sec {stage} step @{args.height}x{args.width} N={args.levels}",
         "value": pairs_per_s, "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-        "config": {"workload": f"Stage-1 training step (BASELINE configs[1]), batch {args.batch}/GPU, "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{stage} training step ({cfg_name}), batch {args.batch}/GPU, "
                                f"{args.height}x{args.width}, N={args.levels}, seeded weights, seeded VGG19",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss,
                    "launch": "hipGraph replay" if graphed else "eager"},
@@ -225,7 +270,7 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values()) / 3
         dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
         d = agg[dom_tag]
-        peak = 2500.0 if dtype == torch.bfloat16 else 157.3
+        peak = 157.3 if dtype == torch.float32 else 2500.0  # exact-f32 MFMA / dense bf16 = f16 MFMA (MI355X_MICROARCH.md)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         mfma_ms = sum(a["ms"] for a in agg.values() if a["flops"] > 0) / 3
         mfma_fl = sum(a["flops"] for a in agg.values()) / 3
@@ -245,7 +290,7 @@ def main():
                                                   "unit": "GB/s", "frac": hb / (hms * 1e-3) / 1e9 / 8000.0, "ms_per_step": hms}
         result["kernel_breakdown_ms_per_step"] = {t: round(a["ms"] / 3, 4) for t, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.height, args.width, args.levels)
+        result["cpu_baseline"] = cpu_baseline(args.workload, args.height, args.width, args.levels)
         result["abs_rel_vs_ref"] = parity_vs_oracle(args.height, args.width, args.levels, dev)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -37,6 +37,44 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 
+// ---- 16-bit float operand types (bf16: 8 significant bits / f32 range; f16: 11 bits / 6e-5..65504) ----------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }          // element 0 of a packed pair
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }  // element 1
+    static __device__ __forceinline__ unsigned short bits(float v) { return __builtin_bit_cast(unsigned short, (bf16_t)v); }
+    static __device__ __forceinline__ f32x16_t mma(s16x8_t a, s16x8_t b, f32x16_t c) {  // v_mfma_f32_32x32x16_bf16
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct H16<f16_t> {
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+    static __device__ __forceinline__ unsigned short bits(float v) { return __builtin_bit_cast(unsigned short, (f16_t)v); }
+    static __device__ __forceinline__ f32x16_t mma(s16x8_t a, s16x8_t b, f32x16_t c) {  // v_mfma_f32_32x32x16_f16
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <typename T> __device__ __forceinline__ unsigned pack16x2(float lo, float hi) {
+    return (unsigned)H16<T>::bits(lo) | ((unsigned)H16<T>::bits(hi) << 16);
+}
+// launch dispatch over the three operand types: X(T) is a statement using the type
+#define FALNET_DISPATCH_DTYPE(dtype, X)             \
+    do {                                            \
+        if ((dtype) == FALNET_BF16) { X(bf16_t); }  \
+        else if ((dtype) == FALNET_F16) { X(f16_t); } \
+        else { X(float); }                          \
+    } while (0)
+#define FALNET_DISPATCH_16(dtype, X)                \
+    do {                                            \
+        if ((dtype) == FALNET_F16) { X(f16_t); }    \
+        else { X(bf16_t); }                         \
+    } while (0)
+
 // wave64 sum via DPP-free shuffles, then one LDS hop across the block's waves
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -17,8 +17,7 @@
 #include <type_traits>
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f32x16_t f32x16;
 
 #define CONV_THREADS 256
 #define CONV_BM 128
@@ -28,6 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <typename T> struct KC;
 template <> struct KC<float> { static constexpr int value = 16; };
 template <> struct KC<bf16_t> { static constexpr int value = 32; };
+template <> struct KC<f16_t> { static constexpr int value = 32; };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == FALNET_ACT_ELU) return v > 0.f ? v : (__expf(v) - 1.f);
@@ -46,21 +46,17 @@ __device__ __forceinline__ float act_grad_from_out(float y, int kind) {
 // bound.  Instead every wave stages one 32-row accumulator slab at a time through its private LDS area
 // (f32, pitch NT*32+4 floats) and then owns (row, 8-channel segment) pieces: bias / residual / activation /
 // activation-gradient are applied on 8 values and written with 16-B stores; addend / actout come in 16-B loads.
-template <typename T> struct Vec8;
-template <> struct Vec8<bf16_t> {
+template <typename T> struct Vec8 {  // 16-bit operand types (bf16 / f16)
     uint4 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const uint4*>(p); }
-    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = v; }
+    __device__ __forceinline__ void load(const T* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = v; }
     __device__ __forceinline__ float get(int i) const {
         const unsigned w = (&v.x)[i >> 1];
-        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+        return (i & 1) ? H16<T>::hi(w) : H16<T>::lo(w);
     }
     __device__ __forceinline__ void set8(const float (&f)[8]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t lo = (bf16_t)f[2 * i], hi = (bf16_t)f[2 * i + 1];
-            (&v.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-        }
+        for (int i = 0; i < 4; ++i) (&v.x)[i] = pack16x2<T>(f[2 * i], f[2 * i + 1]);
     }
 };
 template <> struct Vec8<float> {
@@ -200,10 +196,6 @@ __device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {  // lanes 
     a = r[0];
     b = r[1];
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const bf16_t l = (bf16_t)lo, u = (bf16_t)hi;
-    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, u) << 16);
-}
 // this lane's 16 channels (accumulator order) of pixel offset o (-1: none) from an NHWC tensor; cbase = first channel of the tile
 template <typename T>
 __device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o, int cbase, int h, int Cout, float (&v)[16]) {
@@ -219,10 +211,10 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned w0 = (k & 1) ? c[k >> 1].z : c[k >> 1].x, w1 = (k & 1) ? c[k >> 1].w : c[k >> 1].y;
-            v[4 * k + 0] = __uint_as_float(w0 << 16);
-            v[4 * k + 1] = __uint_as_float(w0 & 0xffff0000u);
-            v[4 * k + 2] = __uint_as_float(w1 << 16);
-            v[4 * k + 3] = __uint_as_float(w1 & 0xffff0000u);
+            v[4 * k + 0] = H16<T>::lo(w0);
+            v[4 * k + 1] = H16<T>::hi(w0);
+            v[4 * k + 2] = H16<T>::lo(w1);
+            v[4 * k + 3] = H16<T>::hi(w1);
         }
     } else {
 #pragma unroll
@@ -242,8 +234,8 @@ __device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int 
         unsigned w[4][2];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            w[k][0] = pack_bf16x2(v[4 * k + 0], v[4 * k + 1]);
-            w[k][1] = pack_bf16x2(v[4 * k + 2], v[4 * k + 3]);
+            w[k][0] = pack16x2<T>(v[4 * k + 0], v[4 * k + 1]);
+            w[k][1] = pack16x2<T>(v[4 * k + 2], v[4 * k + 3]);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -383,19 +375,18 @@ __device__ __forceinline__ void mma_tile(const char* __restrict__ As, const char
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[MT], b[NT];
+            s16x8_t a[MT], b[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                a[mt] = *reinterpret_cast<const bf16x8*>(As + (arow0 + mt * 32 + r) * ROWP + (ks * 2 + h) * 16);
+                a[mt] = *reinterpret_cast<const s16x8_t*>(As + (arow0 + mt * 32 + r) * ROWP + (ks * 2 + h) * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                b[nt] = *reinterpret_cast<const bf16x8*>(Bs + (brow0 + nt * 32 + r) * ROWP + (ks * 2 + h) * 16);
+                b[nt] = *reinterpret_cast<const s16x8_t*>(Bs + (brow0 + nt * 32 + r) * ROWP + (ks * 2 + h) * 16);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt], a[mt], acc[mt][nt], 0, 0, 0)
-                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = SWAP ? H16<T>::mma(b[nt], a[mt], acc[mt][nt]) : H16<T>::mma(a[mt], b[nt], acc[mt][nt]);
         }
     } else {
         float a[MT][8], b[NT][8];
@@ -762,8 +753,8 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = SWAPAB  // exchanged operands: pixels on lanes, channels in the accumulators (epilogue_direct)
-                        ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[sl][nt]), __builtin_bit_cast(bf16x8, fa[sl][mt]), acc[mt][nt], 0, 0, 0)
-                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][mt]), __builtin_bit_cast(bf16x8, fb[sl][nt]), acc[mt][nt], 0, 0, 0);
+                        ? H16<T>::mma(__builtin_bit_cast(s16x8_t, fb[sl][nt]), __builtin_bit_cast(s16x8_t, fa[sl][mt]), acc[mt][nt])
+                        : H16<T>::mma(__builtin_bit_cast(s16x8_t, fa[sl][mt]), __builtin_bit_cast(s16x8_t, fb[sl][nt]), acc[mt][nt]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1380,14 +1371,14 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_c3_kernel(const float
                 const int co = nt * 32 + r, k = (ks * 2 + h) * KJ + j;
                 wv[ks][nt][j] = (co < p.Cout && k < 27) ? w_oihw[co * 27 + k] : 0.f;
             }
-    bf16x8 bfr[sizeof(T) == 2 ? 2 : 1][NT];
+    s16x8_t bfr[sizeof(T) == 2 ? 2 : 1][NT];
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bfr[ks][nt][j] = (bf16_t)wv[ks][nt][j];
+                for (int j = 0; j < 8; ++j) bfr[ks][nt][j] = (short)H16<T>::bits(wv[ks][nt][j]);
     }
     constexpr int MT = PT_TH / 4;  // rows per wave
     // im2col element k of output pixel (row, r): patch[c][row + t/3][r + t%3], k = c*9 + t.  k0 / k1 are the k of lane
@@ -1427,11 +1418,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_c3_kernel(const float
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const float* base = patch + (wave * MT + mt) * PW + r;
-                    bf16x8 afr;
+                    s16x8_t afr;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) afr[j] = (bf16_t)a_elem(base, ks * 16 + j, ks * 16 + 8 + j);
+                    for (int j = 0; j < 8; ++j) afr[j] = (short)H16<T>::bits(a_elem(base, ks * 16 + j, ks * 16 + 8 + j));
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][nt], afr, acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<T>::mma(bfr[ks][nt], afr, acc[mt][nt]);
                 }
             }
         } else {
@@ -1558,7 +1549,7 @@ __global__ __launch_bounds__(CONV_THREADS) void wgrad_kernel(const falnet_wgrad_
                 typedef short s16x8 __attribute__((ext_vector_type(8)));
                 s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                acc = H16<T>::mma(__builtin_bit_cast(s16x8_t, av), __builtin_bit_cast(s16x8_t, bv), acc);
             }
         } else {
             const int r = lane & 31, h = lane >> 5;
@@ -1616,8 +1607,8 @@ __device__ __forceinline__ void bias_grad_accumulate(const char* G, int tid, flo
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned w = (&v.x)[i];
-                bsum[2 * i] += __uint_as_float(w << 16);
-                bsum[2 * i + 1] += __uint_as_float(w & 0xffff0000u);
+                bsum[2 * i] += H16<T>::lo(w);
+                bsum[2 * i + 1] += H16<T>::hi(w);
             }
         } else {
 #pragma unroll
@@ -1821,12 +1812,12 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {  // K = 128 positions: image row ks>>1 of the patch, 16-position half ks&1
                 const int goff = ks * 16 * PITCH;
-                bf16x8 av[COT];
+                s16x8_t av[COT];
 #pragma unroll
                 for (int c = 0; c < COT; ++c) {
                     s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
                     s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
-                    av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    av[c] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int a = 0; a < CIT; ++a)
@@ -1835,9 +1826,9 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
                         const int ioff = a * I_PLANE + ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
                         s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
                         s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                        const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[dx][a][c], 0, 0, 0);
+                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = H16<T>::mma(av[c], bv, acc[dx][a][c]);
                     }
             }
         } else {
@@ -1911,10 +1902,9 @@ __global__ __launch_bounds__(WP_THREADS) void wgrad3x3_patch_kernel(const falnet
 // (The per-tap gather kernel it replaces ran these layers at 65-130 TFLOP/s on the longest chain of the backward pass.)
 #define WS2_RH (2 * WP_TH + 1)   // region rows
 #define WS2_RW (2 * WP_TW + 1)   // region columns
-template <int COT>
+template <typename T, int COT>
 __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
                                                                  int patches_per_split) {
-    typedef bf16_t T;
     constexpr int EPS = 8, SEGS = 4, PITCH = 64;
     constexpr int NE_R = WP_TH + 1, NO_R = WP_TH, NE_C = WP_TW + 1, NO_C = WP_TW;  // even / odd region rows and columns
     // plane (row parity, column parity) -> pixel offset of its first pixel; E = even region index
@@ -2014,12 +2004,12 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {  // K = 128 output positions: block row ks>>1, 16-position half ks&1
             const int goff = ks * 16 * PITCH;
-            bf16x8 av[COT];
+            s16x8_t av[COT];
 #pragma unroll
             for (int c = 0; c < COT; ++c) {
                 s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
                 s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
-                av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                av[c] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
             const int prow = (ks >> 1) + row_shift;  // row inside the parity plane
 #pragma unroll
@@ -2030,9 +2020,9 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
                 const int ioff = (pbase + prow * pw + (ks & 1) * 16 + (kx == 2 ? 1 : 0)) * PITCH;
                 s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
                 s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                const s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int c = 0; c < COT; ++c) acc[kx][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[kx][c], 0, 0, 0);
+                for (int c = 0; c < COT; ++c) acc[kx][c] = H16<T>::mma(av[c], bv, acc[kx][c]);
             }
         }
     };
@@ -2080,9 +2070,9 @@ __global__ __launch_bounds__(WP_THREADS, 2) void wgrad3x3_s2_kernel(const falnet
 // the LDS patch.  Four waves split the eight 16-position K steps of a 4x32 block; partial sums are reduced through LDS and
 // written as a standard [tap][co][cin_pad] slab (the batched reduce un-pads it).
 #define WC3_THREADS 256
+template <typename T>
 __global__ __launch_bounds__(WC3_THREADS) void wgrad3x3_c3_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
                                                                   int patches_per_split) {
-    typedef bf16_t T;
     constexpr int PITCH = 64, SEGS = 4;
     constexpr int G_BYTES = WP_TH * WP_TW * PITCH, X_FLOATS = 3 * (WP_TH + 2) * WP_PW;
     constexpr int G_LOADS = WP_TH * WP_TW * SEGS, G_SLOTS = (G_LOADS + WC3_THREADS - 1) / WC3_THREADS;
@@ -2169,12 +2159,12 @@ __global__ __launch_bounds__(WC3_THREADS) void wgrad3x3_c3_kernel(const falnet_w
             const int ks = wave * 2 + kk;  // 16-position K step: block row ks>>1, half ks&1
             s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + ks * 16 * PITCH));
             s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + ks * 16 * PITCH + 4 * PITCH));
-            const bf16x8 av = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-            bf16x8 bv;
+            const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            s16x8_t bv;
             const float* xr = X + koff + (ks >> 1) * WP_PW + (ks & 1) * 16 + h * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bv[j] = (bf16_t)(kvalid ? xr[j] : 0.f);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+            for (int j = 0; j < 8; ++j) bv[j] = (short)H16<T>::bits(kvalid ? xr[j] : 0.f);
+            acc = H16<T>::mma(av, bv, acc);
         }
         if (do_bias) bias_grad_accumulate<T, 1, WC3_THREADS>(Gbuf(cur), tid, bsum);
         if (patch + 1 < pend) lstore(cur ^ 1, R0);
@@ -2197,191 +2187,6 @@ __global__ __launch_bounds__(WC3_THREADS) void wgrad3x3_c3_kernel(const falnet_w
         const float v = red[(0 * 32 + co) * 33 + k] + red[(1 * 32 + co) * 33 + k] + red[(2 * 32 + co) * 33 + k] + red[(3 * 32 + co) * 33 + k];
         const int c = k / 9, t = k % 9;
         if (co < w_rows) p.partial[(((int64_t)split * 9 + t) * w_rows + co) * p.cin_total + c] = v;
-    }
-}
-
-// 64 x 64 channels per workgroup, staged by LDS-DMA (bf16).  The 2x2-tile form above needs 192 accumulator registers per
-// wave, so one workgroup fits a CU and nothing overlaps the global-load issue of the next patch.  Here a patch (16 KB gout +
-// 26 KB halo) arrives as 42 global_load_lds_dwordx4 pieces (16 pixels x 64 B of one channel plane = 1 KiB, written
-// lane-linearly, no VGPR staging) spread over FOUR waves: waves 0-2 multiply (tap rows, 3 x 2 x 2 tiles each), wave 3 -- on
-// the SIMD the three-wave form leaves idle -- only moves data.  Three LDS buffers: the pieces of patch i+2 are in flight
-// while patch i+1 lands and patch i is multiplied; counted vmcnt + raw s_barrier (a __syncthreads() would drain the DMA).
-#define WPB_THREADS 256
-__global__ __launch_bounds__(WPB_THREADS) void wgrad3x3_big_kernel(const falnet_wgrad_t p, int w_rows, int tiles_x, int tiles_y,
-                                                                   int patches_per_split) {
-    typedef bf16_t T;
-    constexpr int EPS = 8, PITCH = 64, CIT = 2, COT = 2;
-    constexpr int G_PER_PLANE = WP_TH * WP_TW / 16, I_PER_PLANE = (WP_NPIX + 15) / 16;  // 1-KiB DMA pieces per plane
-    constexpr int G_PLANE = WP_TH * WP_TW * PITCH, I_PLANE = I_PER_PLANE * 1024;        // halo plane rounded up to whole pieces
-    constexpr int G_BYTES = COT * G_PLANE, I_BYTES = CIT * I_PLANE;
-    constexpr int NPIECE = COT * G_PER_PLANE + CIT * I_PER_PLANE;
-    static_assert(NPIECE == 42, "the counted vmcnt waits below assume 42 pieces: waves 0,1 issue 11 each, waves 2,3 ten");
-    __shared__ __attribute__((aligned(16))) char lds[3 * (G_BYTES + I_BYTES)];
-    auto Gbuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES); };
-    auto Ibuf = [&](int b) -> char* { return lds + b * (G_BYTES + I_BYTES) + G_BYTES; };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
-    const int npatch = p.B * tiles_x * tiles_y;
-    const int pbeg = split * patches_per_split, pend = min(pbeg + patches_per_split, npatch);
-    const int n = pend - pbeg;
-
-    // per cin tile: source, channel offset, resize (workgroup-uniform; a 64-channel block may straddle a fused concat)
-    const int c_first = p.src[0].C;
-    const T* t_ptr[CIT];
-    int64_t t_sb[CIT], t_sy[CIT], t_sx[CIT];
-    int t_H[CIT], t_W[CIT];
-#pragma unroll
-    for (int t = 0; t < CIT; ++t) {
-        const int c = ci0 + 32 * t;
-        const bool second = c >= c_first;
-        t_ptr[t] = reinterpret_cast<const T*>(second ? p.src[1].ptr : p.src[0].ptr) + (second ? c - c_first : c);
-        t_sb[t] = second ? p.src[1].sb : p.src[0].sb;
-        t_sy[t] = second ? p.src[1].sy : p.src[0].sy;
-        t_sx[t] = second ? p.src[1].sx : p.src[0].sx;
-        t_H[t] = second ? p.src[1].H : p.src[0].H;
-        t_W[t] = second ? p.src[1].W : p.src[0].W;
-    }
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const int lseg = lane & 3, lpix = lane >> 2;
-    auto coords = [&](int patch, int& b, int& y0, int& x0) {
-        int q = patch;
-        const int tix = q % tiles_x;
-        q /= tiles_x;
-        const int tiy = q % tiles_y;
-        b = q / tiles_y;
-        y0 = tiy * WP_TH;
-        x0 = tix * WP_TW;
-    };
-    // Piece id -> wave: id % 4.  Every wave issues EXACTLY its share for every patch (the counted waits depend on it):
-    // coordinates outside the image are clamped to a valid pixel and zero() overwrites those lanes' 16 B once the patch has
-    // landed (border patches only).  cin_total and gC are multiples of 64 here (dispatcher): whole planes are never absent.
-    auto issue = [&](int patch, int buf) {
-        int b, y0, x0;
-        coords(patch, b, y0, x0);
-        const T* gbase = reinterpret_cast<const T*>(p.gout) + ((int64_t)b * p.TH * p.TW) * p.gC + co0 + lseg * EPS;
-#pragma unroll
-        for (int id = 0; id < NPIECE; ++id) {
-            if ((id & 3) != wave) continue;  // wave-uniform
-            if (id < COT * G_PER_PLANE) {
-                const int c = id / G_PER_PLANE, k = id % G_PER_PLANE;
-                const int pix = k * 16 + lpix;
-                const int y = min(y0 + pix / WP_TW, p.TH - 1), x = min(x0 + pix % WP_TW, p.TW - 1);
-                __builtin_amdgcn_global_load_lds((gptr_t)(gbase + ((int64_t)y * p.TW + x) * p.gC + c * 32), (lptr_t)(Gbuf(buf) + c * G_PLANE + k * 1024), 16, 0, 0);
-            } else {
-                const int t = (id - COT * G_PER_PLANE) / I_PER_PLANE, k = (id - COT * G_PER_PLANE) % I_PER_PLANE;
-                const int pix = min(k * 16 + lpix, WP_NPIX - 1);  // the last piece's spare lanes re-read the last pixel into the plane's slack
-                int vy = min(max(y0 - 1 + pix / WP_PW, 0), p.IH - 1), vx = min(max(x0 - 1 + pix % WP_PW, 0), p.IW - 1);
-                if (t_H[t] != p.IH) vy = (2 * t_H[t] == p.IH) ? (vy >> 1) : (int)(((int64_t)vy * t_H[t]) / p.IH);
-                if (t_W[t] != p.IW) vx = (2 * t_W[t] == p.IW) ? (vx >> 1) : (int)(((int64_t)vx * t_W[t]) / p.IW);
-                __builtin_amdgcn_global_load_lds((gptr_t)(t_ptr[t] + (int64_t)b * t_sb[t] + (int64_t)vy * t_sy[t] + (int64_t)vx * t_sx[t] + lseg * EPS),
-                                                 (lptr_t)(Ibuf(buf) + t * I_PLANE + k * 1024), 16, 0, 0);
-            }
-        }
-    };
-    auto zero = [&](int patch, int buf) {  // this wave's pieces of a landed border patch: zero the lanes that were clamped
-        int b, y0, x0;
-        coords(patch, b, y0, x0);
-        const bool border = y0 == 0 || x0 == 0 || y0 + WP_TH + 1 > p.IH || x0 + WP_TW + 1 > p.IW || y0 + WP_TH > p.TH || x0 + WP_TW > p.TW;
-        if (!border) return;  // workgroup-uniform
-#pragma unroll
-        for (int id = 0; id < NPIECE; ++id) {
-            if ((id & 3) != wave) continue;
-            if (id < COT * G_PER_PLANE) {
-                const int c = id / G_PER_PLANE, k = id % G_PER_PLANE;
-                const int pix = k * 16 + lpix;
-                if (y0 + pix / WP_TW >= p.TH || x0 + pix % WP_TW >= p.TW)
-                    *reinterpret_cast<uint4*>(Gbuf(buf) + c * G_PLANE + k * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
-            } else {
-                const int t = (id - COT * G_PER_PLANE) / I_PER_PLANE, k = (id - COT * G_PER_PLANE) % I_PER_PLANE;
-                const int pix = k * 16 + lpix;
-                const int vy = y0 - 1 + pix / WP_PW, vx = x0 - 1 + pix % WP_PW;
-                if (pix < WP_NPIX && (vy < 0 || vy >= p.IH || vx < 0 || vx >= p.IW))
-                    *reinterpret_cast<uint4*>(Ibuf(buf) + t * I_PLANE + k * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto wait_one_patch_in_flight = [&]() {  // all but this wave's pieces of the newest patch have landed
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    };
-
-    f32x16 acc[3][CIT][COT];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int a = 0; a < CIT; ++a)
-#pragma unroll
-            for (int c = 0; c < COT; ++c)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[t][a][c][j] = 0.f;
-    const int i16 = lane & 15, g16 = lane >> 4;
-    const int kh = g16 >> 1, cb = g16 & 1, q4 = i16 >> 2, pc = i16 & 3;
-    typedef s16x4 __attribute__((address_space(3))) * lds_v4;
-    const int lane_off = (kh * 8 + q4) * PITCH + (cb * 16 + pc * 4) * 2;
-
-    if (n > 0) issue(pbeg, 0);
-    if (n > 1) issue(pbeg + 1, 1);
-    if (n > 1) wait_one_patch_in_flight();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (n > 0) zero(pbeg, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int cur = 0, b2 = 2;  // LDS buffers of patch i and of patch i+2 (patch j lives in buffer j % 3)
-    for (int i = 0; i < n; ++i) {
-        if (i + 2 < n) issue(pbeg + i + 2, b2);  // buffer (i+2)%3 = (i-1)%3: released by the barrier that ended iteration i-1
-        if (wave < 3) {  // tap row dy = wave - 1
-            const char* gl = Gbuf(cur) + lane_off;
-            const char* il = Ibuf(cur) + wave * (WP_PW * PITCH) + lane_off;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {  // K = 128 positions: image row ks>>1 of the patch, 16-position half ks&1
-                const int goff = ks * 16 * PITCH;
-                bf16x8 av[COT];
-#pragma unroll
-                for (int c = 0; c < COT; ++c) {
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(gl + c * G_PLANE + goff + 4 * PITCH));
-                    av[c] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-#pragma unroll
-                for (int a = 0; a < CIT; ++a)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int ioff = a * I_PLANE + ((ks >> 1) * WP_PW + (ks & 1) * 16 + dx) * PITCH;
-                        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff));
-                        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(il + ioff + 4 * PITCH));
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-                        for (int c = 0; c < COT; ++c) acc[dx][a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], bv, acc[dx][a][c], 0, 0, 0);
-                    }
-            }
-        }
-        if (i + 2 < n) wait_one_patch_in_flight();  // this wave's pieces of patch i+1 have landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (i + 1 < n) zero(pbeg + i + 1, cur == 2 ? 0 : cur + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of patch i and zero stores are done
-        __builtin_amdgcn_s_barrier();
-        cur = cur == 2 ? 0 : cur + 1;
-        b2 = b2 == 2 ? 0 : b2 + 1;
-    }
-    if (wave == 3) return;
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int a = 0; a < CIT; ++a) {
-        const int ci = ci0 + 32 * a + r;
-        if (ci < p.cin_total) {
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                float* dst = p.partial + (((int64_t)split * 9 + wave * 3 + dx) * w_rows) * p.cin_total;
-#pragma unroll
-                for (int c = 0; c < COT; ++c)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int co = co0 + 32 * c + (j & 3) + 8 * (j >> 2) + 4 * h;
-                        if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dx][a][c][j];
-                    }
-            }
-        }
     }
 }
 
@@ -2659,10 +2464,9 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
 
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
     FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9, 3 or 1, n <= 64)");
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
-    else
-        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+#define PACK_B(T) hipLaunchKernelGGL(pack_weights_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
+    FALNET_DISPATCH_DTYPE(dtype, PACK_B);
+#undef PACK_B
     FALNET_RETURN_LAUNCH();
 }
 
@@ -2680,10 +2484,9 @@ extern "C" int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int
 
 extern "C" int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
     FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "bias_grad_batched: bad argument");
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(bias_grad_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
-    else
-        hipLaunchKernelGGL(bias_grad_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+#define BIAS_B(T) hipLaunchKernelGGL(bias_grad_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
+    FALNET_DISPATCH_DTYPE(dtype, BIAS_B);
+#undef BIAS_B
     FALNET_RETURN_LAUNCH();
 }
 
@@ -2765,7 +2568,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         flip = fwd ? 0 : (bwd ? 1 : -1);
     }
     dense3x3 = dense3x3 && flip >= 0;
-    const int esz = p.dtype == FALNET_BF16 ? 2 : 4;
+    const int esz = p.dtype == FALNET_F32 ? 4 : 2;
     bool c128 = true;  // every source is a whole number of 128-B channel chunks
     for (int s = 0; s < p.nsrc; ++s) c128 = c128 && (p.src[s].C % (128 / esz) == 0);
     int variant = p.variant;
@@ -2847,7 +2650,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     FALNET_CHECK_ARG(pp && buf && len > 0, "conv2d_kernel_name: bad argument");
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
-    const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : "f";
+    const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
     if (c.patch == 2)
         snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb);
     else if (c.patch)
@@ -2860,8 +2663,8 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
 extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG(pp, "conv2d: null descriptor");
     const falnet_conv_t& p = *pp;
-    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16, "conv2d: bad dtype %d", p.dtype);
-    const int kc = p.dtype == FALNET_BF16 ? 32 : 16;
+    FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16 || p.dtype == FALNET_F16, "conv2d: bad dtype %d", p.dtype);
+    const int kc = p.dtype == FALNET_F32 ? 16 : 32;
     FALNET_CHECK_ARG(p.nsrc == 1 || p.nsrc == 2, "conv2d: nsrc=%d", p.nsrc);
     int ctot = 0;
     for (int s = 0; s < p.nsrc; ++s) {
@@ -2890,13 +2693,11 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         if (gx > ntiles) gx = ntiles;
         const dim3 grid((unsigned)gx, (unsigned)ny);
 #define LAUNCH_WS(T, BN, NCH) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip)
-        if (p.dtype == FALNET_BF16) {
-            if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(bf16_t, 64, 2); else LAUNCH_WS(bf16_t, 64, 1); }
-            else { if (c.kcb == 2) LAUNCH_WS(bf16_t, 32, 2); else LAUNCH_WS(bf16_t, 32, 1); }
-        } else {
-            if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(float, 64, 2); else LAUNCH_WS(float, 64, 1); }
-            else { if (c.kcb == 2) LAUNCH_WS(float, 32, 2); else LAUNCH_WS(float, 32, 1); }
-        }
+#define WS_TABLE(T)                                                                                 \
+    if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(T, 64, 2); else LAUNCH_WS(T, 64, 1); }              \
+    else { if (c.kcb == 2) LAUNCH_WS(T, 32, 2); else LAUNCH_WS(T, 32, 1); }
+        FALNET_DISPATCH_DTYPE(p.dtype, WS_TABLE);
+#undef WS_TABLE
 #undef LAUNCH_WS
         FALNET_RETURN_LAUNCH();
     }
@@ -2920,7 +2721,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     TRY_PATCH(T, 64, 64, 9, false, 16, 8) TRY_PATCH(T, 32, 64, 9, false, 16, 8)                                           \
     TRY_PATCH(T, 64, 64, 1, true, 4, 4) TRY_PATCH(T, 32, 64, 1, true, 4, 4)                                               \
     TRY_PATCH(T, 64, 64, 9, false, 4, 4) TRY_PATCH(T, 32, 64, 9, false, 4, 4)
-        if (p.dtype == FALNET_BF16) { PATCH_TABLE(bf16_t) } else { PATCH_TABLE(float) }
+        FALNET_DISPATCH_DTYPE(p.dtype, PATCH_TABLE);
 #undef PATCH_TABLE
 #undef TRY_PATCH
         FALNET_CHECK_ARG(launched, "conv2d: no instantiation for bn=%d kcb=%d tps=%d adb=%d th=%d", c.bn, c.kcb, c.tps, c.adb, c.th);
@@ -2935,18 +2736,17 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         // no memset: the workspace is zero on entry by contract (the epilogue kernel below re-zeroes what it consumes)
     }
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)((p.Cout + bn - 1) / bn), (unsigned)ksplit);
-    if (p.dtype == FALNET_BF16) {
-        if (planar) launch_conv<bf16_t, true>(p, bn, grid, st);
-        else launch_conv<bf16_t, false>(p, bn, grid, st);
-    } else {
-        if (planar) launch_conv<float, true>(p, bn, grid, st);
-        else launch_conv<float, false>(p, bn, grid, st);
-    }
+#define GATHER_L(T)                                          \
+    if (planar) launch_conv<T, true>(p, bn, grid, st);       \
+    else launch_conv<T, false>(p, bn, grid, st);
+    FALNET_DISPATCH_DTYPE(p.dtype, GATHER_L);
+#undef GATHER_L
     if (ksplit > 1) {
         const int64_t total = M * (p.w_rows / 8);
         const unsigned eg = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        if (p.dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_kernel<bf16_t>, dim3(eg), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(splitk_epilogue_kernel<float>, dim3(eg), dim3(256), 0, st, p);
+#define SPLITK_E(T) hipLaunchKernelGGL(splitk_epilogue_kernel<T>, dim3(eg), dim3(256), 0, st, p)
+        FALNET_DISPATCH_DTYPE(p.dtype, SPLITK_E);
+#undef SPLITK_E
     }
     FALNET_RETURN_LAUNCH();
 }
@@ -2966,13 +2766,12 @@ extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const
     const int tiles_x = ((W + PT_TW - 1) / PT_TW + C3_TPW - 1) / C3_TPW /* groups of C3_TPW tiles */, tiles_y = (H + PT_TH - 1) / PT_TH;
     const dim3 grid((unsigned)(B * tiles_x * tiles_y));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == FALNET_BF16) {
-        if (Cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<bf16_t, 2>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<bf16_t, 1>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
-    } else {
-        if (Cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<float, 2>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<float, 1>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
-    }
+#define C3_L(T)                                                                                                                                          \
+    if (Cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<T, 2>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_c3_kernel<T, 1>), grid, dim3(CONV_THREADS), 0, st, x_nchw, w_oihw, p, tiles_x, tiles_y);
+    FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16 || dtype == FALNET_F16, "conv3x3_c3: bad dtype %d", dtype);
+    FALNET_DISPATCH_DTYPE(dtype, C3_L);
+#undef C3_L
     FALNET_RETURN_LAUNCH();
 }
 
@@ -2996,7 +2795,7 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
             }
         }
         for (int s = 0; s < p.nsrc; ++s)
-            if (int r = check_src(p.src[s], p.dtype == FALNET_BF16 ? 32 : 16, "conv2d_multi")) return r;
+            if (int r = check_src(p.src[s], p.dtype == FALNET_F32 ? 16 : 32, "conv2d_multi")) return r;
         ConvChoice c;
         falnet_conv_t q = p;
         q.variant = (p.variant == 11 || p.variant == 12) ? p.variant : 1;  // member 0's tile width is the launch's
@@ -3016,14 +2815,14 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
         else if (c0.bn == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 64>), grid, dim3(CONV_THREADS), 0, st, pp, ksplit); \
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_multi_kernel<T, 32>), grid, dim3(CONV_THREADS), 0, st, pp, ksplit);  \
     } while (0)
-    if (descs[0].dtype == FALNET_BF16) LAUNCH_MULTI(bf16_t);
-    else LAUNCH_MULTI(float);
+    FALNET_DISPATCH_DTYPE(descs[0].dtype, LAUNCH_MULTI);
 #undef LAUNCH_MULTI
     if (ksplit > 1) {
         const int64_t total = maxM * (descs[0].w_rows / 8);
         const dim3 eg((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), (unsigned)n);
-        if (descs[0].dtype == FALNET_BF16) hipLaunchKernelGGL(splitk_epilogue_multi_kernel<bf16_t>, eg, dim3(256), 0, st, pp);
-        else hipLaunchKernelGGL(splitk_epilogue_multi_kernel<float>, eg, dim3(256), 0, st, pp);
+#define SPLITK_M(T) hipLaunchKernelGGL(splitk_epilogue_multi_kernel<T>, eg, dim3(256), 0, st, pp)
+        FALNET_DISPATCH_DTYPE(descs[0].dtype, SPLITK_M);
+#undef SPLITK_M
     }
     FALNET_RETURN_LAUNCH();
 }
@@ -3036,7 +2835,7 @@ extern "C" int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p) {
 }
 
 // kernel selection of falnet_wgrad -- ONE place, also behind falnet_wgrad_fuses_bias (the host must not re-derive it)
-enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_BIG, WGK_S2, WGK_C3, WGK_ROWS };
+enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_S2, WGK_C3, WGK_ROWS };
 bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p);           // wgrad_rows.hip
 int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st);
 
@@ -3050,7 +2849,7 @@ static bool canonical_taps9(const falnet_wgrad_t& p) {
 // returns the kernel; on WGK_BAD the error text is set
 static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
     const int w_rows = round32(p.gC);
-    const bool h16 = p.dtype == FALNET_BF16;  // (f16: only the row-streaming kernel so far)
+    const bool h16 = p.dtype == FALNET_BF16 || p.dtype == FALNET_F16;
     const bool canon = canonical_taps9(p);
     if (p.variant == 6) {  // first layer: planar f32 3-channel source (src[0].ptr = [B][3][IH][IW] f32), 16-bit gout, Cout 32
         const bool ok = h16 && canon && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.gC == 32 && w_rows == 32 && p.cin_total == 32 && p.nsrc == 1;
@@ -3070,10 +2869,6 @@ static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
     // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)
     const bool dense = canon && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.TW >= 16 && !g_disable_patch && p.variant != 1;
     if (dense) {
-        // variant 2: 64 x 64 channels per workgroup (bf16, both channel counts multiples of 64); 0 / other: 32 x 32
-        const bool big = p.variant == 2 && p.dtype == FALNET_BF16 && p.cin_total % 64 == 0 && w_rows % 64 == 0;
-        if (p.variant == 2 && !big) { falnet_set_error("wgrad: variant 2 needs bf16 and channel counts that are multiples of 64"); return WGK_BAD; }
-        if (big) return WGK_BIG;
         if (p.variant == 3 || p.variant == 4) {  // 32 x 64 / 64 x 32 channels per workgroup (register staged, two workgroups per CU)
             const bool co2 = p.variant == 3;
             if (!(h16 && (co2 ? w_rows : p.cin_total) % 64 == 0)) { falnet_set_error("wgrad: variant %d needs 16-bit operands and a channel count that is a multiple of 64", p.variant); return WGK_BAD; }
@@ -3133,35 +2928,31 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     case WGK_ROWS:
         return falnet_wgrad_rows_launch(p, st);
     case WGK_C3:
-        hipLaunchKernelGGL(wgrad3x3_c3_kernel, dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+#define WG_C3(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_c3_kernel<T>), dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+        FALNET_DISPATCH_16(p.dtype, WG_C3);
         break;
     case WGK_S2:
-        if (w_rows % 64 == 0)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
-        break;
-    case WGK_BIG:
-        hipLaunchKernelGGL(wgrad3x3_big_kernel, dim3(p.cin_total / 64, w_rows / 64, p.nsplit), dim3(WPB_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+#define WG_S2_2(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<T, 2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+#define WG_S2_1(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_s2_kernel<T, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+        if (w_rows % 64 == 0) FALNET_DISPATCH_16(p.dtype, WG_S2_2);
+        else FALNET_DISPATCH_16(p.dtype, WG_S2_1);
         break;
     case WGK_PATCH12:
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+#define WG_P12(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<T, 1, 2>), dim3(p.cin_total / 32, w_rows / 64, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+        FALNET_DISPATCH_16(p.dtype, WG_P12);
         break;
     case WGK_PATCH21:
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 2, 1>), dim3(p.cin_total / 64, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+#define WG_P21(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<T, 2, 1>), dim3(p.cin_total / 64, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+        FALNET_DISPATCH_16(p.dtype, WG_P21);
         break;
     case WGK_PATCH11:
-        if (p.dtype != FALNET_F32)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<bf16_t, 1, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<float, 1, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps);
+#define WG_P11(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_patch_kernel<T, 1, 1>), dim3(p.cin_total / 32, w_rows / 32, p.nsplit), dim3(WP_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
+        FALNET_DISPATCH_DTYPE(p.dtype, WG_P11);
         break;
     default: {
         const dim3 grid((p.cin_total + WG_BN - 1) / WG_BN, (w_rows + WG_BM - 1) / WG_BM, p.ntaps * p.nsplit);
-        if (p.dtype != FALNET_F32)
-            hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(CONV_THREADS), 0, st, p, w_rows);
-        else
-            hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(CONV_THREADS), 0, st, p, w_rows);
+#define WG_TAP(T) hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(CONV_THREADS), 0, st, p, w_rows)
+        FALNET_DISPATCH_DTYPE(p.dtype, WG_TAP);
     }
     }
     FALNET_RETURN_LAUNCH();
@@ -3198,10 +2989,9 @@ extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, f
     int64_t gx = (npix + rows * 16 - 1) / (rows * 16);
     gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
     const dim3 grid((unsigned)gx, 1);
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, npix, gC, cout, db);
-    else
-        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, npix, gC, cout, db);
+#define BIAS_L(T) hipLaunchKernelGGL(bias_grad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, npix, gC, cout, db)
+    FALNET_DISPATCH_DTYPE(dtype, BIAS_L);
+#undef BIAS_L
     FALNET_RETURN_LAUNCH();
 }
 
@@ -3212,11 +3002,9 @@ extern "C" int falnet_pack_weights(const float* w_oihw, int cout, int cin, int t
     FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_pad_total, "pack_weights: channel groups do not fit");
     const int64_t total = (int64_t)cout_pad * taps * cin_pad_total;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, taps,
-                           c0_real, c0_pad, cin_pad_total, cout_pad, (bf16_t*)wf, (bf16_t*)wd);
-    else
-        hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, taps,
-                           c0_real, c0_pad, cin_pad_total, cout_pad, (float*)wf, (float*)wd);
+#define PACK_L(T) hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, cout, cin, taps, \
+                                   c0_real, c0_pad, cin_pad_total, cout_pad, (T*)wf, (T*)wd)
+    FALNET_DISPATCH_DTYPE(dtype, PACK_L);
+#undef PACK_L
     FALNET_RETURN_LAUNCH();
 }

@@ -15,26 +15,25 @@ __device__ __forceinline__ void store8_as(float* p, const float (&v)[8]) {
     reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
     reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ void store8_as(bf16_t* p, const float (&v)[8]) {
+template <typename T>  // 16-bit operand types
+__device__ __forceinline__ void store8_as(T* p, const float (&v)[8]) {
     uint4 q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
-        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-    }
+    for (int i = 0; i < 4; ++i) (&q.x)[i] = pack16x2<T>(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = q;
 }
 __device__ __forceinline__ void load8_as(const float* p, float (&v)[8]) {
     const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-__device__ __forceinline__ void load8_as(const bf16_t* p, float (&v)[8]) {
+template <typename T>  // 16-bit operand types
+__device__ __forceinline__ void load8_as(const T* p, float (&v)[8]) {
     const uint4 q = *reinterpret_cast<const uint4*>(p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned w = (&q.x)[i];
-        v[2 * i] = __uint_as_float(w << 16);
-        v[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+        v[2 * i] = H16<T>::lo(w);
+        v[2 * i + 1] = H16<T>::hi(w);
     }
 }
 
@@ -214,13 +213,6 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(const T* __restrict
     }
 }
 
-#define DISPATCH_T(dtype, KERNEL, grid, block, lds, stream, ...)                                                        \
-    do {                                                                                                                \
-        if ((dtype) == FALNET_BF16)                                                                                     \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<bf16_t>), grid, block, lds, (hipStream_t)stream, __VA_ARGS__);   \
-        else                                                                                                            \
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<float>), grid, block, lds, (hipStream_t)stream, __VA_ARGS__);    \
-    } while (0)
 
 extern "C" int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cpad, int dtype,
                                    void* stream) {
@@ -228,10 +220,9 @@ extern "C" int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, in
     const int64_t HW = (int64_t)H * W;
     const dim3 grid((unsigned)((HW + 63) / 64), B);
     const size_t lds = (size_t)64 * (Cpad + 1) * sizeof(float);
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, src, (bf16_t*)dst, C, HW, Cpad);
-    else
-        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, src, (float*)dst, C, HW, Cpad);
+#define EW_L(T) hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, src, (T*)dst, C, HW, Cpad)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }
 
@@ -241,10 +232,9 @@ extern "C" int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, in
     const int64_t HW = (int64_t)H * W;
     const dim3 grid((unsigned)((HW + 63) / 64), B);
     const size_t lds = (size_t)64 * (Cpad + 1) * sizeof(float);
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, (const bf16_t*)src, dst, C, HW, Cpad);
-    else
-        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, (const float*)src, dst, C, HW, Cpad);
+#define EW_L(T) hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(EW_THREADS), lds, (hipStream_t)stream, (const T*)src, dst, C, HW, Cpad)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }
 
@@ -252,24 +242,18 @@ extern "C" int falnet_upsample_bwd(const void* gup, void* gsrc, const void* acto
                                    int C, int dtype, void* stream) {
     FALNET_CHECK_ARG(gup && gsrc && B > 0 && IH >= H && IW >= W && H > 0 && W > 0 && C % 8 == 0, "upsample_bwd: bad argument");
     const int64_t total = (int64_t)B * H * W * (C / 8);
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)gup, (bf16_t*)gsrc, (const bf16_t*)actout, B, IH, IW, H, W, C);
-    else
-        hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)gup, (float*)gsrc, (const float*)actout, B, IH, IW, H, W, C);
+#define EW_L(T) hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)gup, (T*)gsrc, (const T*)actout, B, IH, IW, H, W, C)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }
 
 extern "C" int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     FALNET_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2_fwd: bad argument");
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
-    else
-        hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)x, (float*)y, B, H, W, C);
+#define EW_L(T) hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }
 
@@ -280,31 +264,22 @@ extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy,
                      "maxpool2_bwd: bad argument (even H, W required)");
     if (C % 8 == 0 && (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx) & 15) == 0) {
         const int64_t tv = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
-        if (dtype == FALNET_BF16)
-            hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<bf16_t>, dim3(ew_grid(tv)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                               (const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, B, H, W, C);
-        else
-            hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<float>, dim3(ew_grid(tv)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                               (const float*)x, (const float*)gy, (float*)gx, B, H, W, C);
+#define EW_L(T) hipLaunchKernelGGL(maxpool2_bwd_vec_kernel<T>, dim3(ew_grid(tv)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C)
+        FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
         FALNET_RETURN_LAUNCH();
     }
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, B, H, W, C);
-    else
-        hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)x, (const float*)gy, (float*)gx, B, H, W, C);
+#define EW_L(T) hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }
 
 extern "C" int falnet_act_bwd(const void* g, const void* y, void* gx, int64_t n, int kind, int dtype, void* stream) {
     FALNET_CHECK_ARG(g && y && gx && n > 0, "act_bwd: bad argument");
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const bf16_t*)g, (const bf16_t*)y, (bf16_t*)gx, n, kind);
-    else
-        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                           (const float*)g, (const float*)y, (float*)gx, n, kind);
+#define EW_L(T) hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)g, (const T*)y, (T*)gx, n, kind)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
     FALNET_RETURN_LAUNCH();
 }

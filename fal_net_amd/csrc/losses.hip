@@ -58,13 +58,14 @@ __global__ __launch_bounds__(RED_THREADS) void l1_bwd_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ perceptual MSE on NHWC (loss_functions.py:61-65)
-__device__ __forceinline__ void diff8(const bf16_t* a, const bf16_t* b, float (&d)[8]) {
+template <typename T>  // 16-bit operand types
+__device__ __forceinline__ void diff8(const T* a, const T* b, float (&d)[8]) {
     const uint4 x = *reinterpret_cast<const uint4*>(a), y = *reinterpret_cast<const uint4*>(b);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned u = (&x.x)[i], v = (&y.x)[i];
-        d[2 * i] = __uint_as_float(u << 16) - __uint_as_float(v << 16);
-        d[2 * i + 1] = __uint_as_float(u & 0xffff0000u) - __uint_as_float(v & 0xffff0000u);
+        d[2 * i] = H16<T>::lo(u) - H16<T>::lo(v);
+        d[2 * i + 1] = H16<T>::hi(u) - H16<T>::hi(v);
     }
 }
 __device__ __forceinline__ void diff8(const float* a, const float* b, float (&d)[8]) {
@@ -77,13 +78,11 @@ __device__ __forceinline__ void diff8(const float* a, const float* b, float (&d)
         d[4 * h + 3] = x.w - y.w;
     }
 }
-__device__ __forceinline__ void put8(bf16_t* p, const float (&v)[8]) {
+template <typename T>  // 16-bit operand types
+__device__ __forceinline__ void put8(T* p, const float (&v)[8]) {
     uint4 q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
-        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-    }
+    for (int i = 0; i < 4; ++i) (&q.x)[i] = pack16x2<T>(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = q;
 }
 __device__ __forceinline__ void put8(float* p, const float (&v)[8]) {
@@ -335,8 +334,9 @@ extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cp
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total);
 #define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out)
-    if (dtype == FALNET_BF16) { if (vec) MSE_FWD(bf16_t, true); else MSE_FWD(bf16_t, false); }
-    else { if (vec) MSE_FWD(float, true); else MSE_FWD(float, false); }
+#define MSE_FWD_T(T) if (vec) MSE_FWD(T, true); else MSE_FWD(T, false)
+    FALNET_DISPATCH_DTYPE(dtype, MSE_FWD_T);
+#undef MSE_FWD_T
 #undef MSE_FWD
     FALNET_RETURN_LAUNCH();
 }
@@ -348,8 +348,9 @@ extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cp
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total) * 4;
 #define MSE_BWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_bwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, gscale, (T*)ga)
-    if (dtype == FALNET_BF16) { if (vec) MSE_BWD(bf16_t, true); else MSE_BWD(bf16_t, false); }
-    else { if (vec) MSE_BWD(float, true); else MSE_BWD(float, false); }
+#define MSE_BWD_T(T) if (vec) MSE_BWD(T, true); else MSE_BWD(T, false)
+    FALNET_DISPATCH_DTYPE(dtype, MSE_BWD_T);
+#undef MSE_BWD_T
 #undef MSE_BWD
     FALNET_RETURN_LAUNCH();
 }

@@ -281,13 +281,11 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
     reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+template <typename T>  // 16-bit operand types
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
     uint4 q;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bf16_t lo = (bf16_t)v[2 * i], hi = (bf16_t)v[2 * i + 1];
-        (&q.x)[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-    }
+    for (int i = 0; i < 4; ++i) (&q.x)[i] = pack16x2<T>(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = q;
 }
 // grad_dlog0[n, x'] = (1-a) gwl_n(x'-k) + a gwl_n(x'-k-1) + gd(x') sm_n(x') (d_n - disp(x'))
@@ -733,7 +731,7 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd_nhwc: grad_p_im0 needs left and p_im0");
     FALNET_CHECK_ARG(!grad_disp || disp, "med_head_bwd_nhwc: grad_disp needs disp");
     FALNET_CHECK_ARG(cpad >= N && cpad % 8 == 0, "med_head_bwd_nhwc: cpad=%d must be a multiple of 8 >= N", cpad);
-    FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16, "med_head_bwd_nhwc: bad dtype %d", dtype);
+    FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16 || dtype == FALNET_F16, "med_head_bwd_nhwc: bad dtype %d", dtype);
     const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
     static const bool v1 = [] { const char* e = getenv("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
     if (!v1 && W <= 4 * HEAD_THREADS) {  // LDS-staged plane rows
@@ -742,20 +740,16 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_lds_kernel<T, P>), dim3(B * H), dim3(HEAD_THREADS), lds2, (hipStream_t)stream, dlog0, left, \
                        min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (T*)grad_dlog0_nhwc, N, H, W, cpad)
         const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
-        if (dtype == FALNET_BF16) {
-            if (ppt <= 1) LAUNCH_BWD_LDS(bf16_t, 1); else if (ppt == 2) LAUNCH_BWD_LDS(bf16_t, 2); else LAUNCH_BWD_LDS(bf16_t, 4);
-        } else {
-            if (ppt <= 1) LAUNCH_BWD_LDS(float, 1); else if (ppt == 2) LAUNCH_BWD_LDS(float, 2); else LAUNCH_BWD_LDS(float, 4);
-        }
+#define BWD_LDS_T(T) if (ppt <= 1) LAUNCH_BWD_LDS(T, 1); else if (ppt == 2) LAUNCH_BWD_LDS(T, 2); else LAUNCH_BWD_LDS(T, 4)
+        FALNET_DISPATCH_DTYPE(dtype, BWD_LDS_T);
+#undef BWD_LDS_T
 #undef LAUNCH_BWD_LDS
         FALNET_RETURN_LAUNCH();
     }
-    if (dtype == FALNET_BF16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<bf16_t, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
-                           min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (bf16_t*)grad_dlog0_nhwc, N, H, W, cpad);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<float, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left,
-                           min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (float*)grad_dlog0_nhwc, N, H, W, cpad);
+#define BWD_V1_T(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_kernel<T, true>), dim3(B * H), dim3(HEAD_THREADS), lds, (hipStream_t)stream, dlog0, left, \
+                                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (T*)grad_dlog0_nhwc, N, H, W, cpad)
+    FALNET_DISPATCH_DTYPE(dtype, BWD_V1_T);
+#undef BWD_V1_T
     FALNET_RETURN_LAUNCH();
 }
 

@@ -280,7 +280,7 @@ class FalnetPlan:
             a[i], h_[i], c[i] = self._act(f"a{i}", hh, ww, ch), self._act(f"h{i}", hh, ww, ch), self._act(f"c{i}", hh, ww, ch)
             if i == 0:
                 # bf16: conv0's weight gradient reads the planar f32 image itself (falnet_wgrad variant 6): no NHWC copy of the image
-                self._c3_wgrad = dt == torch.bfloat16 and W >= 16 and os.environ.get("FALNET_WGRAD_C3", "1") == "1"
+                self._c3_wgrad = dt in ops.H16 and W >= 16 and os.environ.get("FALNET_WGRAD_C3", "1") == "1"
                 srcs, ih, iw = [ops.planar_src(left) if self._c3_wgrad else ops.nhwc_src(x0)], H, W
             elif i == 1:
                 ih, iw = sizes[0]

@@ -14,6 +14,8 @@ import torch
 from . import _lib as L
 
 CPAD = L.CPAD
+H16 = (torch.bfloat16, torch.float16)  # 16-bit operand types (bf16 / f16 MFMA, f32 accumulate)
+TYPE_SYM = {torch.bfloat16: "DF16b", torch.float16: "DF16_", torch.float32: "f"}  # Itanium-mangled template argument, as rocprofv3 prints it
 
 # Optional launch timer (bench.py / profiling): object with run(tag, flops, bytes, launch).  None on the
 # product path: launches are then plain C-ABI calls.
@@ -36,7 +38,7 @@ def _timed(tag, flops, nbytes, launch, name=""):
 
 def conv_kernel_tag(dtype, w_rows, Cout, planar, variant=1):
     """Kernel family falnet_conv2d dispatches to (conv.hip: falnet_conv2d), for the bench's per-family totals."""
-    dn = 'bf16' if dtype == torch.bfloat16 else 'f32'
+    dn = {torch.bfloat16: 'bf16', torch.float16: 'f16'}.get(dtype, 'f32')
     if variant >= 2:
         return f"conv3x3_patch_kernel<{dn},{ {2: 'kcb128', 3: 'kcb64', 4: 'single-stage', 5: 'double-stage', 6: 'kcb64,M512', 7: 'single-stage,M512'}[variant]}>"
     bn = 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
@@ -131,7 +133,7 @@ def conv_c3_call(dtype, x_planar, pc, out, act, name="conv0(c3)"):
     B, C, H, W = x_planar.shape
     assert C == 3 and pc.cin == 3 and pc.cout in (32, 64) and out.shape == (B, H, W, pc.cout)
     tail = (L.ptr(pc.weight), L.ptr(pc.bias), L.ptr(out), B, H, W, pc.cout, act, L.dtype_code(dtype))
-    tn, nt = ("DF16b" if dtype == torch.bfloat16 else "f"), pc.cout // 32
+    tn, nt = TYPE_SYM[dtype], pc.cout // 32
     cur = [x_planar]
 
     def launch(_keep=(pc, out)):
@@ -308,7 +310,7 @@ def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1):
             arr[i].splitk_ws_bytes = need
             off += need
     keep = (arr, calls)
-    dn = "DF16b" if arr[0].dtype == L.BF16 else "f"
+    dn = {L.BF16: "DF16b", L.F16: "DF16_"}.get(arr[0].dtype, "f")
     bn = bn or gather_bn(arr[0].w_rows, arr[0].Cout)
 
     def launch(_keep=keep):
@@ -370,17 +372,17 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
     falnet_wgrad_fuses_bias, never re-derived here)."""
     M = B * TH * TW
     h16 = dtype in (torch.bfloat16, torch.float16)
-    tn = {torch.bfloat16: "DF16b", torch.float16: "DF16_", torch.float32: "f"}[dtype]
+    tn = TYPE_SYM[dtype]
     dense = len(taps) == 9 and stride_in == 1 and TW >= 16  # halo-patch kernel (conv.hip: falnet_wgrad)
     c3 = len(srcs) == 1 and srcs[0].C == 3  # planar f32 image source (ops.planar_src): first-layer kernel, variant 6
     npatch = B * ((TH + 3) // 4) * ((TW + 31) // 32)
     if c3:
         assert h16 and dense and cout_pad == 32 and cin_pad == 32, "variant 6: 16-bit first layer, Cout 32"
-        variant, nsplit, sym = 6, max(1, min(_WGRAD_WGS, npatch)), "_Z18wgrad3x3_c3_kernel14falnet_wgrad_tiiii"
+        variant, nsplit, sym = 6, max(1, min(_WGRAD_WGS, npatch)), f"_Z18wgrad3x3_c3_kernelI{tn}Ev14falnet_wgrad_tiiii"
     elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
         tiles = (cin_pad // 32) * (cout_pad // (64 if cout_pad % 64 == 0 else 32))
         variant, nsplit = 5, max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
-        sym = f"_Z18wgrad3x3_s2_kernelILi{2 if cout_pad % 64 == 0 else 1}EEv14falnet_wgrad_tiiii"
+        sym = f"_Z18wgrad3x3_s2_kernelI{tn}Li{2 if cout_pad % 64 == 0 else 1}EEv14falnet_wgrad_tiiii"
     elif _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
         units = B * ((TW + 31) // 32) * TH
@@ -389,12 +391,11 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
             nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
         variant, sym = 7, f"_Z21wgrad3x3_rows8_kernelI{tn}Li2ELi0EEv14falnet_wgrad_tiiii"
     elif dense:
-        big = _wgrad_big(dtype, dense, cin_pad, cout_pad)
-        co2 = not big and _wgrad_co2(dtype, dense, cin_pad, cout_pad)
-        tiles = (cin_pad // 32) * (cout_pad // 32) // (4 if big else 2 if co2 else 1)
-        nsplit = max(1, min(((512 if big else _WGRAD_WGS) + tiles - 1) // tiles, npatch))
-        variant = 2 if big else 3 if co2 else 0
-        sym = "_Z19wgrad3x3_big_kernel14falnet_wgrad_tiiii" if big else f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii"
+        co2 = _wgrad_co2(dtype, dense, cin_pad, cout_pad)
+        tiles = (cin_pad // 32) * (cout_pad // 32) // (2 if co2 else 1)
+        nsplit = max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
+        variant = 3 if co2 else 0
+        sym = f"_Z21wgrad3x3_patch_kernelI{tn}Li1ELi{2 if co2 else 1}EEv14falnet_wgrad_tiiii"
     else:
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64) * len(taps)
         variant, nsplit, sym = 0, max(1, min((target_wgs + tiles - 1) // tiles, (M + 255) // 256)), f"_Z12wgrad_kernelI{tn}Ev14falnet_wgrad_ti"
@@ -492,19 +493,10 @@ def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
     return os.environ.get("FALNET_WGRAD_ROWS", "1") == "1"
 
 
-def _wgrad_big(dtype, dense, cin_pad, cout_pad):
-    """64 x 64-channel workgroup tiles of the halo-patch weight-gradient kernel (falnet_wgrad variant 2, LDS-DMA staged).
-    Opt-in (FALNET_WGRAD_BIG=1): measured 1.2-1.6x SLOWER than the 32 x 32 form on MI355X -- with one workgroup per CU the
-    per-CU fill rate (~25 GB/s of 64-B pieces) bounds it, while the small form hides its (2x larger) traffic behind 3-4
-    resident workgroups and L2 hits.  Kept for the next round's work on the staging path."""
-    return (dense and dtype == torch.bfloat16 and cin_pad % 64 == 0 and cout_pad % 64 == 0
-            and os.environ.get("FALNET_WGRAD_BIG", "0") == "1")
-
-
 def _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
     """Parity-plane halo kernel for 3x3 stride-2 weight gradients (falnet_wgrad variant 5): bf16, canonical taps, sources at
     the input size (or per-sample constants)."""
-    return (dtype == torch.bfloat16 and len(taps) == 9 and stride_in == 2 and TW >= 32 and TH == (IH + 1) // 2 and TW == (IW + 1) // 2
+    return (dtype in H16 and len(taps) == 9 and stride_in == 2 and TW >= 32 and TH == (IH + 1) // 2 and TW == (IW + 1) // 2
             and all((s.H == IH and s.W == IW) or (s.sy == 0 and s.sx == 0) for s in srcs)
             and os.environ.get("FALNET_WGRAD_S2", "1") == "1")
 
@@ -514,7 +506,7 @@ def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
     (1.7 instead of 2.7 transposed LDS reads per MFMA).  In isolation -17 % on 64 -> 64 channel layers and -4 % on 128 -> 128;
     in the step (weight gradients are the longest chain of backward) +2.1 % pairs/s with the cut at 128 input channels, a little
     less with no cut (same-box A/B)."""
-    return dense and dtype == torch.bfloat16 and cin_pad <= int(os.environ.get("FALNET_WGRAD_CO2_MAXCIN", "128")) and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
+    return dense and dtype in H16 and cin_pad <= int(os.environ.get("FALNET_WGRAD_CO2_MAXCIN", "128")) and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
 
 
 class WgradBatch:

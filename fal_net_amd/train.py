@@ -55,6 +55,27 @@ class FlatAdam:
             self.model.mark_weights_changed()
 
 
+# f16 compute path: activation gradients are stored in IEEE half (normal range >= 6.1e-5) while a mean loss over B*3*H*W
+# elements seeds them at ~1e-7 -- they would flush to subnormals / zero.  Static loss scaling: backward runs on S * loss
+# (every autograd node of the step is linear in its upstream gradient), the f32 weight gradients come out S times too
+# large and 1/S is folded into the fused Adam launch beside 1/world.  bf16 / f32 have the f32 exponent range: S = 1.
+_F16_LOSS_SCALE = float(_os.environ.get("FALNET_F16_LOSS_SCALE", "8192"))
+
+
+def loss_scale(model):
+    return _F16_LOSS_SCALE if getattr(model, "compute_dtype", None) == torch.float16 else 1.0
+
+
+def scaled_backward(loss, model):
+    """loss.backward() with the model's loss scale; returns the factor the optimiser must apply to the gradients."""
+    s = loss_scale(model)
+    if s == 1.0:
+        loss.backward()
+        return 1.0
+    (loss * s).backward()
+    return 1.0 / s
+
+
 def enable_overlapped_allreduce(model):
     """Install the bucket hook: as backward finalises each contiguous range of the flat gradient buffer (decoder first,
     deep encoder levels next, the small shallow levels last) its share of the step's all-reduce is launched
@@ -144,11 +165,11 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
         c = int(0.20 * W)
         sm_loss = smoothness(left[:, :, :, c:], ldisp[:, :, :, c:], gamma=2)  # :255
     loss = rec_loss + a_sm * sm_loss  # :258
-    loss.backward()
+    unscale = scaled_backward(loss, model)
     out = {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
-           "rpan": rpan, "ldisp": ldisp}
+           "rpan": rpan, "ldisp": ldisp, "grad_scale": unscale}
     if optimize:
-        opt.step(allreduce_gradients(model))
+        opt.step(allreduce_gradients(model) * unscale)
     return out
 
 
@@ -173,8 +194,8 @@ def stage1_slow_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 /
         sm_loss = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
                    smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
     loss = rec_loss + a_sm * sm_loss  # :281
-    loss.backward()
-    opt.step(allreduce_gradients(model))
+    unscale = scaled_backward(loss, model)
+    opt.step(allreduce_gradients(model) * unscale)
     return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
             "rpan": rpan, "lpan": lpan, "ldisp": ldisp, "rdisp": rdisp}
 
@@ -205,7 +226,7 @@ class GraphedStage1Step:
     def __call__(self):
         self.graph.replay()
         if self.multi:
-            self.opt.step(allreduce_gradients(self.model))
+            self.opt.step(allreduce_gradients(self.model) * self.out["grad_scale"])
         else:
             self.opt.t += 1  # host mirror of the device step count
         return self.out
@@ -273,8 +294,8 @@ def stage2_step(model, fix_model, opt, left, right, max_disp, a_p=0.01, a_sm=0.4
         mirror_loss = (torch.mean(nmaxl * (1 - O_L)[:, :, :, c2:] * torch.abs(ldisp - mldisp)[:, :, :, c2:]) +
                        torch.mean(nmaxr * (1 - O_R)[:, :, :, 0:c8] * torch.abs(rdisp - mrdisp)[:, :, :, 0:c8])) / 2
     loss = rec_loss + a_sm * sm_loss + a_mr * mirror_loss
-    loss.backward()
+    unscale = scaled_backward(loss, model)
     scale = allreduce_gradients(model)
-    opt.step(scale)
+    opt.step(scale * unscale)
     return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss, "mirror": mirror_loss, "ldisp": ldisp, "rdisp": rdisp,
             "O_L": O_L, "O_R": O_R}

@@ -37,7 +37,7 @@ enum { FALNET_OUT_NHWC = 0, FALNET_OUT_PLANAR_F32 = 1 };
 
 int falnet_version(void);
 const char* falnet_last_error(void);
-/* channel padding granule (elements) of NHWC tensors and packed weights: 32 for both dtypes */
+/* channel padding granule (elements) of NHWC tensors and packed weights: 32 for every dtype */
 int falnet_channel_pad(int dtype);
 /* tuning switches for tools/bench_conv.py (kernel A/B inside one process): key 0 = force the gather conv
  * kernel, key 1 = K bytes per chunk of the halo-patch kernel (128 / 64 / 0) */
@@ -144,10 +144,9 @@ typedef struct {
     float* partial;            /* workspace */
     int32_t dtype;
     int32_t variant;           /* 0 heuristic (halo-patch kernel, 32x32 channels per workgroup, when dense 3x3 stride 1),
-                                  1 force the per-tap kernel, 2 halo-patch with 64x64 channels per workgroup (bf16, channel
-                                  counts multiples of 64, LDS-DMA staged), 3 / 4 halo-patch with 32x64 / 64x32 (cin x cout)
-                                  channels per workgroup (bf16), 5 parity-plane halo kernel for 3x3 stride-2 launches (bf16),
-                                  6 first layer: src[0].ptr = planar f32 [B][3][IH][IW] image (src[0].C = 3), bf16 gout with 32
+                                  1 force the per-tap kernel, 3 / 4 halo-patch with 32x64 / 64x32 (cin x cout) channels per
+                                  workgroup (16-bit operands), 5 parity-plane halo kernel for 3x3 stride-2 launches (16-bit),
+                                  6 first layer: src[0].ptr = planar f32 [B][3][IH][IW] image (src[0].C = 3), 16-bit gout with 32
                                   channels, cin_total 32 (slab layout),
                                   7 row-streaming kernel (bf16 / f16, dense 3x3 stride 1, sources at the launch size or exactly
                                   half of it): 64 x 64 channels per workgroup, LDS-DMA row ring, gout fragments in a rolling

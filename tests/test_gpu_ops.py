@@ -14,6 +14,9 @@ from oracle import falnet_oracle as O  # noqa: E402
 DEV = "cuda"
 F32_TOL = 1e-4   # north_star gate for the exact-f32 path (relative, max-norm)
 BF16_TOL = 3e-2  # bf16 operands carry 8 significant bits; reported, not gated at 1e-4
+F16_TOL = 4e-3   # IEEE half operands: 11 significant bits (BASELINE configs[4])
+TOL = {torch.float32: F32_TOL, torch.bfloat16: BF16_TOL, torch.float16: F16_TOL}
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def rel(a, b):
@@ -45,11 +48,11 @@ def packed(w, b, groups, stride, dtype):
     return pc
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_roundtrip(dtype):
     x = torch.randn(2, 5, 7, 70)
     y = to_nchw(to_nhwc(x, dtype), 5)
-    assert rel(y, x) < (1e-7 if dtype == torch.float32 else 1e-2)
+    assert rel(y, x) < {torch.float32: 1e-7, torch.bfloat16: 1e-2, torch.float16: 1e-3}[dtype]
     t = to_nhwc(x, dtype)
     assert float(t[..., 5:].abs().max()) == 0.0  # padded channels are zero
 
@@ -115,7 +118,7 @@ def _ref_conv(case, xs, w, b, addend=None):
     return y
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES + PATCH_CASES)
 def test_conv_forward(case, dtype):
     B, groups, Cout, H, W, stride, k, bias, act, res = case
@@ -139,11 +142,11 @@ def test_conv_forward(case, dtype):
     if pc.cout_pad > Cout:
         assert float(out[..., Cout:].float().abs().max()) == 0.0
     got = to_nchw(out, Cout)
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     assert rel(got, ref) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [PATCH_CASES[0], PATCH_CASES[1], PATCH_CASES[3], PATCH_CASES[4],
                                   (2, [64], 128, 40, 70, 1, 3, True, L.ACT_ELU, True), (1, [32, 64], 64, 33, 64, 1, 3, False, L.ACT_ELU, False),
                                   (3, [32, 32], 49, 21, 75, 1, 3, True, L.ACT_NONE, True), (2, [64], 64, 64, 96, 1, 3, True, L.ACT_RELU, False)])
@@ -178,13 +181,13 @@ def test_conv_every_kernel_variant(case, dtype):
             continue
         assert rc == 0, (variant, L.lib().falnet_last_error())
         got = to_nchw(out, Cout)
-        assert rel(got, ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL), variant
+        assert rel(got, ref) < TOL[dtype], variant
         ran.append(variant)
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
-    assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (2 if dtype == torch.bfloat16 else 4) <= 128)
+    assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W,keep_full", [(2, 64, 64, 16, 64, True), (1, 64, 128, 24, 40, False), (2, 128, 128, 128, 256, True),
                                                      (1, 256, 256, 16, 32, False), (1, 64, 64, 11, 37, True)])
 def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
@@ -214,7 +217,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
         if rc == -2:
             continue
         assert rc == 0, (variant, L.lib().falnet_last_error())
-        tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+        tol = TOL[dtype]
         assert rel(to_nchw(pooled, cout), F.max_pool2d(ref, 2, 2)) < tol, variant
         if out is not None:
             assert rel(to_nchw(out, cout), ref) < tol, variant
@@ -224,7 +227,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     assert 1 not in ran and 4 in ran and len(ran) >= 3, ran
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 64), (1, 128, 64, 24, 96), (1, 32, 96, 128, 256)])
 def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     """pool_mode 1: the 2x2 block sums of the conv output times elu'(low-resolution activation) -- the adjoint of the exact 2x
@@ -254,12 +257,12 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
         if rc == -2:
             continue
         assert rc == 0, (variant, L.lib().falnet_last_error())
-        assert rel(to_nchw(pooled, cout), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL), variant
+        assert rel(to_nchw(pooled, cout), ref) < TOL[dtype], variant
         ran.append(variant)
     assert 4 in ran and len(ran) >= 2, ran
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,cout,act", [(2, 16, 64, 32, L.ACT_ELU), (1, 9, 13, 64, L.ACT_RELU), (2, 37, 70, 32, L.ACT_NONE),
                                             (1, 75, 250, 64, L.ACT_RELU)])
 def test_conv_first_layer_c3(B, H, W, cout, act, dtype):
@@ -273,10 +276,10 @@ def test_conv_first_layer_c3(B, H, W, cout, act, dtype):
     ops.conv_c3_call(dtype, x.to(DEV), pc, out, act)()
     ref = F.conv2d(x, w, b, padding=1)
     ref = F.elu(ref) if act == L.ACT_ELU else F.relu(ref) if act == L.ACT_RELU else ref
-    assert rel(to_nchw(out, cout), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+    assert rel(to_nchw(out, cout), ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_planar_output(dtype):
     case = (2, [49], 49, 6, 40, 1, 1, True, L.ACT_NONE, False)
     xs, w, b = _conv_inputs(case)
@@ -286,10 +289,10 @@ def test_conv_planar_output(dtype):
     out = torch.full((2, 49, 6, 40), float("nan"), device=DEV)
     ops.conv_call(dtype, [ops.nhwc_src(src)], 6, 40, pc.wf, pc.cin_pad, ops.fwd_taps(1), 1, pc.cout_pad, 1, 2, 6, 40, out,
                   6, 40, 49, 0, out_layout=L.OUT_PLANAR_F32, bias=pc.bias)()
-    assert rel(out, ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+    assert rel(out, ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fused_upsample(dtype):
     """deconv: nearest resize to an arbitrary size then conv (FAL_netB.py:57-60), incl. non-x2 ratio."""
     g = torch.Generator().manual_seed(3)
@@ -302,10 +305,10 @@ def test_conv_fused_upsample(dtype):
         out = torch.empty(2, IH, IW, 32, dtype=dtype, device=DEV)
         ops.conv_call(dtype, [ops.nhwc_src(src)], IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, 2, IH, IW,
                       out, IH, IW, 32, 32, act=L.ACT_ELU)()
-        assert rel(to_nchw(out, 32), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+        assert rel(to_nchw(out, 32), ref) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES[:7] + CONV_CASES[8:] + PATCH_CASES[:5] + PATCH_CASES[7:])
 def test_conv_backward(case, dtype):
     """dgrad (per concat group, stride 1 and the 4 stride-2 parity launches) and wgrad/bias-grad vs autograd."""
@@ -321,7 +324,7 @@ def test_conv_backward(case, dtype):
     OH, OW = y.shape[2], y.shape[3]
     pc = packed(w.detach(), None if b is None else b.detach(), groups, stride, dtype)
     g_t = to_nhwc(gy, dtype)
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     # dgrad per group
     for gi, x in enumerate(xs):
         cg = pc.groups_pad[gi]
@@ -354,7 +357,7 @@ def test_conv_backward(case, dtype):
     assert rel(gw, 2 * w.grad) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ksplit", [1, 4])
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 128, 12, 20), (1, 128, 256, 9, 15), (2, 32, 64, 16, 32)])
 def test_stride2_dgrad_fused_launch(B, cin, cout, H, W, ksplit, dtype):
@@ -386,33 +389,9 @@ def test_stride2_dgrad_fused_launch(B, cin, cout, H, W, ksplit, dtype):
         gin.fill_(float("nan"))
         call()
         torch.cuda.synchronize()
-        assert rel(to_nchw(gin, cin), ref.detach()) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+        assert rel(to_nchw(gin, cin), ref.detach()) < TOL[dtype]
     ws = ops._splitk_workspace(torch.device(DEV, torch.cuda.current_device()))
     assert float(ws.abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("case", [PATCH_CASES[2], PATCH_CASES[4], PATCH_CASES[8], (1, [64], 64, 9, 37, 1, 3, False, L.ACT_ELU, False)])
-def test_wgrad_big_tiles(case, monkeypatch):
-    """falnet_wgrad variant 2 (64x64 channels per workgroup, LDS-DMA staging, opt-in) against autograd: border patches
-    (clamped DMA + zero fix-up), ragged tiles, a 64-channel block straddling two concatenated sources."""
-    monkeypatch.setenv("FALNET_WGRAD_BIG", "1")
-    B, groups, Cout, H, W, stride, k, bias, act, res = case
-    dtype = torch.bfloat16
-    xs, w, b = _conv_inputs(case, seed=21)
-    xs = [x.requires_grad_(False) for x in xs]
-    wp = w.clone().requires_grad_(True)
-    g = torch.randn(B, Cout, H, W, generator=torch.Generator().manual_seed(22))
-    (F.conv2d(torch.cat(xs, 1), wp, None, padding=1) * g).sum().backward()
-    pc = packed(w, None, groups, 1, dtype)
-    srcs_t = [to_nhwc(x, dtype) for x in xs]
-    g_t = to_nhwc(g, dtype)
-    gw = torch.zeros_like(pc.weight.data)
-    ws = torch.empty(32 << 20, device=DEV)
-    call = ops.wgrad_calls(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, g_t, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 1, B, H, W,
-                           pc, gw, None, ws)
-    assert call.desc.variant == 2
-    call(0)
-    assert rel(gw, wp.grad) < BF16_TOL
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (1, 75, 250)])
@@ -441,7 +420,7 @@ def test_wgrad_first_layer_planar(B, H, W):
 
 def test_upsample_bwd_and_pool():
     g = torch.Generator().manual_seed(9)
-    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2), (torch.float16, 2e-3)):
         x = torch.randn(2, 32, 6, 12, generator=g, requires_grad=True)
         y = F.elu(x)
         up = F.interpolate(y, size=(11, 23), mode="nearest")
@@ -454,8 +433,8 @@ def test_upsample_bwd_and_pool():
         assert rel(to_nchw(gsrc, 32), x.grad) < tol * 5
         # relu -> maxpool fwd/bwd
         x = torch.randn(2, 64, 8, 12, generator=g)
-        if dtype == torch.bfloat16:  # argmax routing is discontinuous: compare on the bf16-rounded input
-            x = x.bfloat16().float()
+        if dtype != torch.float32:  # argmax routing is discontinuous: compare on the input rounded to the compute dtype
+            x = x.to(dtype).float()
         x.requires_grad_(True)
         r = F.relu(x)
         p = F.max_pool2d(r, 2)
@@ -504,14 +483,14 @@ def test_med_head(B, N, H, W, maxd):
                                     L.ptr(gd_d), L.ptr(gp_d), L.ptr(gl), B, N, H, W, L.stream_ptr()))
     assert rel(gl, dlog0.grad) < F32_TOL
     # the same gradient written pixel-major (what the logits conv's gradient launches consume); padding channels zero
-    for dt in (torch.float32, torch.bfloat16):
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
         cp = ops.pad_c(N)
         gn = torch.full((B, H, W, cp), float("nan"), dtype=dt, device=DEV)
         L.check(lib.falnet_med_head_bwd_nhwc(L.ptr(d0), L.ptr(lf), L.ptr(mnd), L.ptr(mxd), L.ptr(disp), L.ptr(pan), L.ptr(st),
                                              L.ptr(gd_d), L.ptr(gp_d), L.ptr(gn), cp, L.dtype_code(dt), B, N, H, W, L.stream_ptr()))
         # (the NHWC form is a different kernel -- LDS-staged plane rows -- so equal up to contraction order, not bitwise)
-        assert rel(gn[..., :N].float(), gl.permute(0, 2, 3, 1).float()) < (2e-6 if dt == torch.float32 else 1e-2)
-        assert rel(gn[..., :N].float().permute(0, 3, 1, 2), dlog0.grad) < (F32_TOL if dt == torch.float32 else 1e-2)
+        assert rel(gn[..., :N].float(), gl.permute(0, 2, 3, 1).float()) < {torch.float32: 2e-6, torch.bfloat16: 1e-2, torch.float16: 2e-3}[dt]
+        assert rel(gn[..., :N].float().permute(0, 3, 1, 2), dlog0.grad) < {torch.float32: F32_TOL, torch.bfloat16: 1e-2, torch.float16: 2e-3}[dt]
         assert cp == N or float(gn[..., N:].float().abs().max()) == 0.0
     # disparity-only backward
     dlog0.grad = None
@@ -578,7 +557,7 @@ def test_losses():
         L.check(lib.falnet_smooth_bwd(L.ptr(img_d), L.ptr(dsp_d), B, H, W, x0, x1, gamma, sc, L.ptr(None), L.ptr(gd), 0, L.stream_ptr()))
         assert rel(gd, dsp.grad) < 1e-5
     # mse on NHWC, flip, rowmax, mask mix
-    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
         x, y = torch.randn(2, 40, 5, 9, generator=g), torch.randn(2, 40, 5, 9, generator=g)
         xt, yt = to_nhwc(x, dtype), to_nhwc(y, dtype)
         sc = 1.0 / x.numel()
