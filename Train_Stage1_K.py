@@ -88,6 +88,7 @@ def main(step='stage1_step'):
     m_model = models.__dict__[args.m_model](network_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev)
     if rank == 0:
         print("=> Number of parameters m-model '{}'".format(utils.get_n_params(m_model)))
+    train.sync_parameters(m_model)  # N > 1: rank 0's weights to every rank, once (then one gradient all-reduce per step)
     opt = train.FlatAdam(m_model, lr=args.lr, betas=(args.momentum, args.beta))
 
     def lr_at(epoch):  # MultiStepLR(milestones, gamma=0.5), fast-forwarded like Train_Stage1_K.py:181-184

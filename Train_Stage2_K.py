@@ -55,6 +55,7 @@ def main():
     fix_model = models.__dict__[args.m_model](load(args.fix_model), no_levels=args.no_levels, compute_dtype=dtype).to(dev).eval()
     for p in fix_model.parameters():
         p.requires_grad_(False)
+    train.sync_parameters(m_model)  # N > 1: rank 0's weights to every rank, once (then one gradient all-reduce per step)
     opt = train.FlatAdam(m_model, lr=args.lr, betas=(args.momentum, args.beta))
     if not args.synthetic:
         raise SystemExit('only --synthetic input is wired in this build (data pipeline out of scope, SURVEY.md 8f-3)')

@@ -188,6 +188,7 @@ def main():
     LF.set_compute_dtype(dtype)
     model = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(args.levels)}, no_levels=args.levels,
                      compute_dtype=dtype).to(dev).train()
+    train.sync_parameters(model)  # world > 1: one broadcast of rank 0's flat parameters + checksum, before any timed step
     opt = train.FlatAdam(model, lr=1e-4, betas=(0.5, 0.999))
     left, right, mn, mx = synthetic.synthetic_pair(args.batch, args.height, args.width, seed=1234 + rank)
     left, right, mx = left.to(dev), right.to(dev), mx.to(dev)  # inputs resident in HBM before the timed region

@@ -71,7 +71,7 @@ SIGNATURES = {
     "falnet_version": [],
     "falnet_last_error": [],
     "falnet_channel_pad": [_I],
-    "falnet_debug_set": [_I, _I],
+    "falnet_set_device": [_I],
     "falnet_conv2d": [C.POINTER(Conv), _P],
     "falnet_conv3x3_c3": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_conv2d_multi": [C.POINTER(Conv), _I, _P],
@@ -110,6 +110,10 @@ SIGNATURES = {
     "falnet_resample_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "falnet_augment_normalize": [_P, _I, _I, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _F, _F, _F, _P, _P],
     "falnet_rowmax": [_P, _P, _I, _L, _P],
+    "falnet_gemm_f32_small": [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _P],
+    "falnet_resize_planar": [_P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "falnet_occlusion_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "falnet_mirror_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
 

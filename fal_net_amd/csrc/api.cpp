@@ -1,6 +1,7 @@
 // Diagnostics entry points of the C-ABI (include/falnet_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <hip/hip_runtime_api.h>
 #include "../../include/falnet_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +16,15 @@ void falnet_set_error(const char* fmt, ...) {
 extern "C" int falnet_version(void) { return 100; }
 extern "C" const char* falnet_last_error(void) { return g_err; }
 extern "C" int falnet_channel_pad(int dtype) { (void)dtype; return 32; }
+
+// Launch functions make the device of the caller's stream current themselves (common.h: falnet_enter_stream); this sets it
+// explicitly for callers that pass the NULL stream from a fresh thread.
+extern "C" int falnet_set_device(int device) {
+    const hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // the failure is reported HERE: do not leave it for the next launch's hipGetLastError
+        falnet_set_error("falnet_set_device(%d): %s", device, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}

@@ -15,6 +15,18 @@ void falnet_set_error(const char* fmt, ...);
         }                                           \
     } while (0)
 
+// Entry of every launch function: make the device that OWNS the caller's stream current on this thread (backward
+// runs on autograd's worker thread, whose current device need not be the forward thread's; a launch on a stream of another
+// device fails with hipErrorInvalidResourceHandle).  The device comes from the stream itself, so no entry point needs a
+// device argument; the NULL stream keeps the thread's current device (falnet_set_device sets it explicitly).
+static inline void falnet_enter_stream(void* stream) {
+    if (!stream) return;
+    hipDevice_t dev;
+    int cur = -1;
+    if (hipStreamGetDevice((hipStream_t)stream, &dev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)dev) (void)hipSetDevice((int)dev);
+}
+#define FALNET_ENTER(stream) falnet_enter_stream(stream)
+
 // kernel launches never synchronise; a launch-configuration error surfaces here
 #define FALNET_RETURN_LAUNCH()                                                   \
     do {                                                                         \

@@ -2463,6 +2463,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
 }
 
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9, 3 or 1, n <= 64)");
 #define PACK_B(T) hipLaunchKernelGGL(pack_weights_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
     FALNET_DISPATCH_DTYPE(dtype, PACK_B);
@@ -2477,12 +2478,14 @@ extern "C" int falnet_wgrad_reduce_blocks(int cout, int cin_total, int groups) {
 }
 
 extern "C" int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "wgrad_reduce_batched: bad argument");
     hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n, accumulate ? 1 : 0);
     FALNET_RETURN_LAUNCH();
 }
 
 extern "C" int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "bias_grad_batched: bad argument");
 #define BIAS_B(T) hipLaunchKernelGGL(bias_grad_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
     FALNET_DISPATCH_DTYPE(dtype, BIAS_B);
@@ -2538,14 +2541,6 @@ struct ConvChoice {
 static bool g_disable_patch = [] { const char* e = getenv("FALNET_DISABLE_PATCH"); return e && e[0] == '1'; }();
 // K bytes per chunk of the pipelined patch kernel: 128 (1 workgroup/CU), 64 (2 workgroups/CU), 0 = mode S only
 static int g_patch_kcb = [] { const char* e = getenv("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
-
-// tuning/profiling switches (tools/bench_conv.py); not part of the product path
-extern "C" int falnet_debug_set(int key, int value) {
-    if (key == 0) g_disable_patch = value != 0;
-    else if (key == 1) g_patch_kcb = value;
-    else return -1;
-    return 0;
-}
 
 
 static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
@@ -2661,6 +2656,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
 }
 
 extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(pp, "conv2d: null descriptor");
     const falnet_conv_t& p = *pp;
     FALNET_CHECK_ARG(p.dtype == FALNET_F32 || p.dtype == FALNET_BF16 || p.dtype == FALNET_F16, "conv2d: bad dtype %d", p.dtype);
@@ -2753,6 +2749,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
 
 extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int Cout,
                                  int act, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(x_nchw && w_oihw && out && B > 0 && H > 0 && W > 0, "conv3x3_c3: bad argument");
     FALNET_CHECK_ARG(Cout == 32 || Cout == 64, "conv3x3_c3: Cout must be 32 or 64 (got %d)", Cout);
     falnet_conv_t p = {};
@@ -2776,6 +2773,7 @@ extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const
 }
 
 extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs && n >= 1 && n <= 4, "conv2d_multi: 1..4 descriptors");
     falnet_conv4_t pp;
     int64_t maxM = 0;
@@ -2908,6 +2906,7 @@ extern "C" int falnet_wgrad_fuses_bias(const falnet_wgrad_t* pp) {
 }
 
 extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(pp, "wgrad: null descriptor");
     falnet_wgrad_t p = *pp;
     if (int r = check_wgrad_desc(p)) return r;
@@ -2960,6 +2959,7 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
 
 extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, int cout_pad, int cin_total, float* grad,
                                    int cout, int cin, int c0_real, int c0_pad, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(partial && grad && nsplit >= 1 && ntaps >= 1 && ntaps <= 9 && cout > 0 && cin > 0 && cout <= cout_pad, "wgrad_reduce: bad argument");
     FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_total, "wgrad_reduce: channel groups do not fit");
     // slab groups: enough blocks to fill the chip when the weight tensor is small and the slab count large
@@ -2979,6 +2979,7 @@ extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, 
 
 extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, float* db, int accumulate, int dtype,
                                 void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(g && db && npix > 0 && cout > 0 && cout <= gC, "bias_grad: bad argument");
     FALNET_CHECK_ARG(gC % 32 == 0 && gC <= 2048, "bias_grad: unsupported channel count %d", gC);
     if (!accumulate) {
@@ -2997,6 +2998,7 @@ extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, f
 
 extern "C" int falnet_pack_weights(const float* w_oihw, int cout, int cin, int taps, int c0_real, int c0_pad,
                                    int cin_pad_total, int cout_pad, void* wf, void* wd, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(w_oihw && (wf || wd) && cout > 0 && cin > 0 && taps >= 1, "pack_weights: bad argument");
     FALNET_CHECK_ARG(cout_pad >= cout && cout_pad % 32 == 0 && cin_pad_total % 32 == 0, "pack_weights: pads must be multiples of 32");
     FALNET_CHECK_ARG(c0_real <= cin && c0_real <= c0_pad && c0_pad + (cin - c0_real) <= cin_pad_total, "pack_weights: channel groups do not fit");

@@ -78,6 +78,7 @@ static inline int data_grid(int64_t n) {
 
 extern "C" int falnet_resample_u8(const uint8_t* src, uint8_t* dst, int H, int W, int C, int out_size, int horizontal, const int32_t* bounds,
                                   const int32_t* kk, int ksize, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && dst && bounds && kk && H > 0 && W > 0 && C > 0 && out_size > 0 && ksize > 0, "resample_u8: bad argument");
     const int64_t total = (int64_t)(horizontal ? H : out_size) * (horizontal ? out_size : W) * C;
     hipLaunchKernelGGL(resample_u8_kernel, dim3(data_grid(total)), dim3(DATA_THREADS), 0, (hipStream_t)stream, src, dst, H, W, C, out_size,
@@ -87,6 +88,7 @@ extern "C" int falnet_resample_u8(const uint8_t* src, uint8_t* dst, int H, int W
 
 extern "C" int falnet_augment_normalize(const uint8_t* src, int H, int W, int x1, int y1, int th, int tw, int flip, double gamma, double bright,
                                         double cb0, double cb1, double cb2, float mean0, float mean1, float mean2, float* dst, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && dst && th > 0 && tw > 0 && x1 >= 0 && y1 >= 0 && x1 + tw <= W && y1 + th <= H, "augment_normalize: crop outside the image");
     AugArgs a{H, W, x1, y1, th, tw, flip ? 1 : 0, gamma, bright, {cb0, cb1, cb2}, {mean0, mean1, mean2}};
     hipLaunchKernelGGL(augment_normalize_kernel, dim3(data_grid((int64_t)3 * th * tw)), dim3(DATA_THREADS), 0, (hipStream_t)stream, src, dst, a);

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(const T* __restrict
 
 extern "C" int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cpad, int dtype,
                                    void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad <= 512, "nchw_to_nhwc: bad argument");
     const int64_t HW = (int64_t)H * W;
     const dim3 grid((unsigned)((HW + 63) / 64), B);
@@ -228,6 +229,7 @@ extern "C" int falnet_nchw_to_nhwc(const float* src, void* dst, int B, int C, in
 
 extern "C" int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cpad, int dtype,
                                    void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad <= 512, "nhwc_to_nchw: bad argument");
     const int64_t HW = (int64_t)H * W;
     const dim3 grid((unsigned)((HW + 63) / 64), B);
@@ -240,6 +242,7 @@ extern "C" int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, in
 
 extern "C" int falnet_upsample_bwd(const void* gup, void* gsrc, const void* actout, int B, int IH, int IW, int H, int W,
                                    int C, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(gup && gsrc && B > 0 && IH >= H && IW >= W && H > 0 && W > 0 && C % 8 == 0, "upsample_bwd: bad argument");
     const int64_t total = (int64_t)B * H * W * (C / 8);
 #define EW_L(T) hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)gup, (T*)gsrc, (const T*)actout, B, IH, IW, H, W, C)
@@ -249,6 +252,7 @@ extern "C" int falnet_upsample_bwd(const void* gup, void* gsrc, const void* acto
 }
 
 extern "C" int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2_fwd: bad argument");
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
 #define EW_L(T) hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C)
@@ -259,6 +263,7 @@ extern "C" int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, 
 
 extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy, void* gx, int B, int H, int W, int C,
                                    int dtype, void* stream) {
+    FALNET_ENTER(stream);
     (void)y;
     FALNET_CHECK_ARG(x && gy && gx && B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && C > 0,
                      "maxpool2_bwd: bad argument (even H, W required)");
@@ -277,9 +282,69 @@ extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy,
 }
 
 extern "C" int falnet_act_bwd(const void* g, const void* y, void* gx, int64_t n, int kind, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(g && y && gx && n > 0, "act_bwd: bad argument");
 #define EW_L(T) hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)g, (const T*)y, (T*)gx, n, kind)
     FALNET_DISPATCH_DTYPE(dtype, EW_L);
 #undef EW_L
+    FALNET_RETURN_LAUNCH();
+}
+
+// ---- small f32 matrix products (composed logits conv, FAL_netB.py:127,190: Wc = W1x1 . W3x3 per update, and the split of
+// dWc back into dW3x3 = W1x1^T dWc, dW1x1 = dWc W3x3^T): N x N by N x 864 with N = 49..96 -- a few MFLOP, one thread per
+// output element (the dtype of the parameters, exact f32 like the rest of the optimiser path)
+__global__ __launch_bounds__(EW_THREADS) void gemm_f32_small_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                                                    const float* __restrict__ Bm, int64_t sbk, int64_t sbn,
+                                                                    float* __restrict__ C, int M, int N, int K, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)M * N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float* a = A + m * sam;
+        const float* b = Bm + n * sbn;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(a[k * sak], b[k * sbk], acc);
+        C[i] = accumulate ? C[i] + acc : acc;
+    }
+}
+
+extern "C" int falnet_gemm_f32_small(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                                     int M, int N, int K, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (int64_t)M * N * K <= (1ll << 32), "gemm_f32_small: bad argument (small products only)");
+    hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(ew_grid((int64_t)M * N)), dim3(EW_THREADS), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C,
+                       M, N, K, accumulate);
+    FALNET_RETURN_LAUNCH();
+}
+
+// ---- planar f32 resampling of Test_KITTI.py:287-300 (ms_pp): bilinear with align_corners=True (F.interpolate semantics:
+// src = dst * (in - 1) / (out - 1)) and nearest (src = floor(dst * in / out)), one thread per output element
+__global__ __launch_bounds__(EW_THREADS) void resize_planar_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                                   int OH, int OW, int bilinear, float scale, int64_t total) {
+    const float ry = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f, rx = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const float ny = (float)H / (float)OH, nx = (float)W / (float)OW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+        const float* pl = src + (i / ((int64_t)OW * OH)) * ((int64_t)H * W);
+        float v;
+        if (bilinear) {
+            const float fy = ry * oy, fx = rx * ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+            const float wy = fy - y0, wx = fx - x0;
+            v = (1.f - wy) * ((1.f - wx) * pl[(int64_t)y0 * W + x0] + wx * pl[(int64_t)y0 * W + x1]) +
+                wy * ((1.f - wx) * pl[(int64_t)y1 * W + x0] + wx * pl[(int64_t)y1 * W + x1]);
+        } else {
+            const int sy = min((int)floorf(oy * ny), H - 1), sx = min((int)floorf(ox * nx), W - 1);
+            v = pl[(int64_t)sy * W + sx];
+        }
+        dst[i] = v * scale;
+    }
+}
+
+extern "C" int falnet_resize_planar(const float* src, float* dst, int64_t planes, int H, int W, int OH, int OW, int bilinear, float scale,
+                                    void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(src && dst && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "resize_planar: bad argument");
+    const int64_t total = planes * OH * OW;
+    hipLaunchKernelGGL(resize_planar_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, bilinear, scale, total);
     FALNET_RETURN_LAUNCH();
 }

@@ -214,6 +214,26 @@ __global__ __launch_bounds__(RED_THREADS) void mask_mix_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------ Stage-2 occlusion masks and mirror-loss weights
+// (Train_Stage2_K.py:296-302, :316-324): single-channel planar maps, no gradient.
+//   occlusion: O = a * b, forced to 1 in the column window [x0, x1)   (O_L[:, :, :, 0:0.2W] = 1 / O_R[:, :, :, 0.8W:] = 1)
+//   weight   : w = (1 - O) / max_b(teacher disparity) inside [x0, x1), 0 outside -- the mirror loss is then the masked L1
+//              sum(w |d - d_teacher|) / (B H (x1 - x0)) of falnet_l1_fwd / _bwd
+__global__ __launch_bounds__(RED_THREADS) void occlusion_mask_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                     float* __restrict__ out, int W, int x0, int x1, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        out[i] = (x >= x0 && x < x1) ? 1.f : a[i] * b[i];
+    }
+}
+__global__ __launch_bounds__(RED_THREADS) void mirror_weight_kernel(const float* __restrict__ occ, const float* __restrict__ rowmax,
+                                                                    float* __restrict__ out, int64_t HW, int W, int x0, int x1, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        out[i] = (x >= x0 && x < x1) ? (1.f - occ[i]) * (1.f / rowmax[i / HW]) : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------ fused flat Adam (torch.optim.Adam, Train_Stage1_K.py:180)
 // 7 f32 streams per element (read p,g,m,v; write p,m,v): 28 B/param, pure HBM streaming, float4 lanes.
 __global__ __launch_bounds__(RED_THREADS) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(RED_THREADS) void rowmax_kernel(const float* __rest
 // ------------------------------------------------------------------ C-ABI
 extern "C" int falnet_l1_fwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW, float scale,
                              float* out, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(a && b && out && B > 0 && C > 0 && HW > 0, "l1_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = (int64_t)B * C * HW;
@@ -319,6 +340,7 @@ extern "C" int falnet_l1_fwd(const float* a, const float* b, const float* mask, 
 
 extern "C" int falnet_l1_bwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW, float scale,
                              const float* gscale, float* ga, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(a && b && ga && B > 0 && C > 0 && HW > 0, "l1_bwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, mask, C,
@@ -328,6 +350,7 @@ extern "C" int falnet_l1_bwd(const float* a, const float* b, const float* mask, 
 
 extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, float* out,
                               int accumulate, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(a && b && out && npix > 0 && Cpad > 0, "mse_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = npix * Cpad;
@@ -343,6 +366,7 @@ extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cp
 
 extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, const float* gscale,
                               void* ga, int dtype, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(a && b && ga && npix > 0 && Cpad > 0, "mse_bwd: bad argument");
     const int64_t total = npix * Cpad;
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
@@ -357,6 +381,7 @@ extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cp
 
 extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma,
                                  float scale, float* out, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(img && disp && out && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
@@ -367,6 +392,7 @@ extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int
 
 extern "C" int falnet_smooth_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma,
                                  float scale, const float* gscale, float* gdisp, int accumulate, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(img && disp && gdisp && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_bwd: bad argument");
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3(red_grid((int64_t)B * H * W) * 4), dim3(RED_THREADS), 0,
@@ -376,6 +402,7 @@ extern "C" int falnet_smooth_bwd(const float* img, const float* disp, int B, int
 
 extern "C" int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, int B, int C, int64_t HW,
                                void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(a && b && m && out && B > 0 && C > 0 && HW > 0, "mask_mix: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(mask_mix_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, m, out,
@@ -383,8 +410,26 @@ extern "C" int falnet_mask_mix(const float* a, const float* b, const float* m, f
     FALNET_RETURN_LAUNCH();
 }
 
+extern "C" int falnet_occlusion_mask(const float* a, const float* b, float* out, int B, int H, int W, int x0, int x1, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(a && b && out && B > 0 && H > 0 && W > 0 && 0 <= x0 && x0 <= x1 && x1 <= W, "occlusion_mask: bad argument");
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(occlusion_mask_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, out, W, x0, x1, total);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mirror_weight(const float* occ, const float* rowmax, float* out, int B, int H, int W, int x0, int x1, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(occ && rowmax && out && B > 0 && H > 0 && W > 0 && 0 <= x0 && x0 <= x1 && x1 <= W, "mirror_weight: bad argument");
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(mirror_weight_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, occ, rowmax, out, (int64_t)H * W, W,
+                       x0, x1, total);
+    FALNET_RETURN_LAUNCH();
+}
+
 extern "C" int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                                 float eps, int step, float grad_scale, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
     FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-B aligned");
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
@@ -396,6 +441,7 @@ extern "C" int falnet_adam_step(float* p, const float* g, float* m, float* v, in
 
 extern "C" int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
                                     float eps, float grad_scale, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(p && g && m && v && state && n > 0 && (n & 3) == 0, "adam_step_dev: bad argument (n must be a multiple of 4)");
     FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_dev: buffers must be 16-B aligned");
     hipLaunchKernelGGL(adam_dev_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps, grad_scale);
@@ -404,6 +450,7 @@ extern "C" int falnet_adam_step_dev(float* p, const float* g, float* m, float* v
 }
 
 extern "C" int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && dst && src != dst && n_rows > 0 && W > 0, "hflip: bad argument (in-place not supported)");
     const int64_t total = n_rows * W;
     hipLaunchKernelGGL(hflip_kernel, dim3(red_grid(total) * 4), dim3(RED_THREADS), 0, (hipStream_t)stream, src, dst, total, W);
@@ -411,6 +458,7 @@ extern "C" int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W,
 }
 
 extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream) {
+    FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && out && B > 0 && n > 0, "rowmax: bad argument");
     hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(RED_THREADS), 0, (hipStream_t)stream, src, out, n);
     FALNET_RETURN_LAUNCH();

@@ -679,6 +679,7 @@ static int check_head(int B, int N, int H, int W) {
 extern "C" int falnet_med_head_fwd(const float* dlog0, const float* left, const float* min_disp,
                                    const float* max_disp, float* disp, float* p_im0, float* stats, int B, int N,
                                    int H, int W, void* stream) {
+    FALNET_ENTER(stream);
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp, "med_head_fwd: null input");
     FALNET_CHECK_ARG(!p_im0 || left, "med_head_fwd: p_im0 requested without left image");
@@ -712,6 +713,7 @@ extern "C" int falnet_med_head_bwd(const float* dlog0, const float* left, const 
                                    const float* max_disp, const float* disp, const float* p_im0,
                                    const float* stats, const float* grad_disp, const float* grad_p_im0,
                                    float* grad_dlog0, int B, int N, int H, int W, void* stream) {
+    FALNET_ENTER(stream);
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && grad_dlog0, "med_head_bwd: null input");
     FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd: grad_p_im0 needs left and p_im0");
@@ -726,6 +728,7 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
                                         const float* max_disp, const float* disp, const float* p_im0,
                                         const float* stats, const float* grad_disp, const float* grad_p_im0,
                                         void* grad_dlog0_nhwc, int cpad, int dtype, int B, int N, int H, int W, void* stream) {
+    FALNET_ENTER(stream);
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && grad_dlog0_nhwc, "med_head_bwd_nhwc: null input");
     FALNET_CHECK_ARG(!grad_p_im0 || (left && p_im0), "med_head_bwd_nhwc: grad_p_im0 needs left and p_im0");
@@ -756,6 +759,7 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
 extern "C" int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp,
                                     const float* stats, float* maskL, float* maskR, int B, int N, int H, int W,
                                     void* stream) {
+    FALNET_ENTER(stream);
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && maskL && maskR, "med_masks_fwd: null input");
     const size_t lds = sizeof(PlaneTab) + (size_t)4 * (W + 3) * sizeof(float);
@@ -766,6 +770,7 @@ extern "C" int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, c
 
 extern "C" int falnet_med_maskr_acfalse_fwd(const float* dlog0, const float* min_disp, const float* max_disp,
                                             const float* stats, float* maskR, int B, int N, int H, int W, void* stream) {
+    FALNET_ENTER(stream);
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp && stats && maskR, "med_maskr_acfalse_fwd: null input");
     hipLaunchKernelGGL(med_maskr_acfalse_kernel, dim3(B * H), dim3(HEAD_THREADS), sizeof(PlaneTab), (hipStream_t)stream, dlog0,

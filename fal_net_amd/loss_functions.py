@@ -251,13 +251,15 @@ vgg = _LazyVgg()
 
 # ------------------------------------------------------------------------------------------ scalar losses
 class _L1Mean(torch.autograd.Function):
+    """scale * sum(mask * |synth - label|); scale defaults to 1 / numel (the mean of loss_functions.py:53)."""
+
     @staticmethod
-    def forward(ctx, synth, label, mask):
+    def forward(ctx, synth, label, mask, scale=None):
         B, C, H, W = synth.shape
         a, b = synth.contiguous(), label.contiguous()
         m = None if mask is None else mask.expand(B, 1, H, W).contiguous()
         out = torch.empty(1, device=synth.device)
-        sc = 1.0 / (B * C * H * W)
+        sc = 1.0 / (B * C * H * W) if scale is None else float(scale)
         L.check(L.lib().falnet_l1_fwd(L.ptr(a), L.ptr(b), L.ptr(m), B, C, H * W, sc, L.ptr(out), 0, L.stream_ptr()), "l1_fwd")
         ctx.save_for_backward(a, b, m if m is not None else torch.empty(0))
         ctx.has_mask, ctx.sc = m is not None, sc
@@ -271,7 +273,29 @@ class _L1Mean(torch.autograd.Function):
         gs = g.reshape(1).contiguous().float()
         L.check(L.lib().falnet_l1_bwd(L.ptr(a), L.ptr(b), L.ptr(m if ctx.has_mask else None), B, C, H * W, ctx.sc, L.ptr(gs),
                                       L.ptr(ga), 0, L.stream_ptr()), "l1_bwd")
-        return ga, None, None
+        return ga, None, None, None
+
+
+def occlusion_mask(a, b, x0, x1):
+    """Stage-2 occlusion mask (Train_Stage2_K.py:296-302): a * b with the column window [x0, x1) forced to 1; no gradient."""
+    B, _, H, W = a.shape
+    a, b = a.detach().contiguous(), b.detach().contiguous()
+    out = torch.empty_like(a)
+    L.check(L.lib().falnet_occlusion_mask(L.ptr(a), L.ptr(b), L.ptr(out), B, H, W, int(x0), int(x1), L.stream_ptr()), "occlusion_mask")
+    return out
+
+
+def mirror_loss_fnc(disp, teacher_disp, occ, x0, x1):
+    """Mirror loss of one view (Train_Stage2_K.py:319-324): mean over the window [x0, x1) of
+    (1 / max teacher disparity of the sample) * (1 - occ) * |disp - teacher_disp|; gradient wrt `disp` only."""
+    B, _, H, W = disp.shape
+    t = teacher_disp.detach().contiguous()
+    rmax = torch.empty(B, device=disp.device)
+    L.check(L.lib().falnet_rowmax(L.ptr(t), L.ptr(rmax), B, H * W, L.stream_ptr()), "rowmax")  # F.max_pool2d(kernel=(H, W)), :319
+    w = torch.empty_like(t)
+    occ = occ.detach().contiguous()
+    L.check(L.lib().falnet_mirror_weight(L.ptr(occ), L.ptr(rmax), L.ptr(w), B, H, W, int(x0), int(x1), L.stream_ptr()), "mirror_weight")
+    return _L1Mean.apply(disp, t, w, 1.0 / (B * H * (x1 - x0)))
 
 
 class _MaskMix(torch.autograd.Function):

@@ -251,8 +251,9 @@ class FalnetPlan:
             w3_2d = m._bb.iconv1.weight.detach().view(m._bb.iconv1.weight.shape[0], -1)
             wc_2d = m._wc.view(m._wc.shape[0], -1)
 
-            def compose_call():
-                torch.mm(w1_2d, w3_2d, out=wc_2d)
+            n1, k3 = w1_2d.shape[0], w3_2d.shape[1]
+            compose_call = ops.simple_call("falnet_gemm_f32_small", L.ptr(w1_2d), w1_2d.shape[1], 1, L.ptr(w3_2d), k3, 1, L.ptr(wc_2d),
+                                           n1, k3, w1_2d.shape[1], 0, name="compose logits weights")
             self.pack.append(compose_call)  # before the re-pack below: the composed f32 master changes with every update
         packed_now = [pc for k, pc in pcs.items() if not (compose and k in ("iconv1", "conv0_1x1"))]
         for pc in packed_now:
@@ -480,11 +481,15 @@ class FalnetPlan:
 
     def _split_logits_grad(self):
         """dWc (composed 3x3 logits conv) -> dW3x3 = W1x1^T dWc and dW1x1 = dWc W3x3^T, added into the flat gradient buffer."""
-        m = self.model
+        m, lib = self.model, L.lib()
         w1, w3 = m.conv0.weight.detach(), m._bb.iconv1.weight.detach()
-        g = m._gwc.view(w1.shape[0], -1)
-        m._grad_view(m._bb.iconv1.weight).view(w3.shape[0], -1).addmm_(w1.view(w1.shape[0], -1).t(), g)
-        m._grad_view(m.conv0.weight).view(w1.shape[0], -1).addmm_(g, w3.view(w3.shape[0], -1).t())
+        n, k = w1.shape[0], w3.numel() // w3.shape[0]  # N planes, 9 * 96
+        g, g3, g1 = m._gwc, m._grad_view(m._bb.iconv1.weight), m._grad_view(m.conv0.weight)
+        st = L.stream_ptr()
+        # dW3x3[n x k] += W1x1^T[n x n] dWc[n x k]   (A = W1x1 read transposed: strides (1, n))
+        L.check(lib.falnet_gemm_f32_small(L.ptr(w1), 1, n, L.ptr(g), k, 1, L.ptr(g3), n, k, n, 1, st), "split logits grad (3x3)")
+        # dW1x1[n x n] += dWc[n x k] W3x3^T[k x n]   (B = W3x3 read transposed: strides (1, k))
+        L.check(lib.falnet_gemm_f32_small(L.ptr(g), k, 1, L.ptr(w3), 1, k, L.ptr(g1), n, n, k, 1, st), "split logits grad (1x1)")
 
     # ---- execution ----
     def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
@@ -519,6 +524,7 @@ class FalnetPlan:
             b["g_pan"].copy_(g_pan)
         self._accumulate = self.model._begin_grad_accumulation()
         self.wbatch.accumulate = 1 if self._accumulate else 0
+        self.model._accumulating = bool(self._accumulate)
         if not self._accumulate:
             self.model._flat_grad.zero_()  # the batched reduce / bias kernels ADD into the flat gradient buffer
         if getattr(self.model, "_compose_logits", False):
@@ -666,9 +672,18 @@ class FAL_net(nn.Module):
         total = self._flat.numel()
         return [(first["dec"], total), (first["enc4"], first["dec"]), (first["enc1"], first["enc4"]), (0, first["enc1"])]
 
+    def ensure_flat(self, device=None):
+        """Move the trainable parameters into ONE flat f32 buffer (and create the flat gradient buffer) now instead of at the
+        first forward: the start-up parameter broadcast of a multi-GPU run and the gradient-bucket tests need it.  Works on any
+        device (no kernels involved)."""
+        self._ensure_flat(torch.device(device) if device is not None else next(self.parameters()).device)
+        return self._flat
+
     def _bucket_ready(self, bucket):
         hook = getattr(self, "bucket_hook", None)
-        if hook is not None:
+        # an ACCUMULATING backward (p.grad kept from the previous micro-batch) must not start the all-reduce: the running sum
+        # would be reduced once per micro-batch; train.allreduce_gradients then falls back to ONE sum over the whole buffer
+        if hook is not None and not getattr(self, "_accumulating", False):
             lo, hi = self.gradient_buckets()[bucket]
             hook(bucket, self._flat_grad[lo:hi])
 

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
-from .loss_functions import rec_loss_fnc, smoothness, vgg
+from .loss_functions import mirror_loss_fnc, occlusion_mask, rec_loss_fnc, smoothness, vgg
 
 
 import os as _os
@@ -74,6 +74,30 @@ def scaled_backward(loss, model):
         return 1.0
     (loss * s).backward()
     return 1.0 / s
+
+
+def sync_parameters(model, check=True):
+    """Start-up rank consistency of a data-parallel run: ONE broadcast of rank 0's flat parameter buffer (the reference's
+    nn.DataParallel re-broadcasts the parameters every step, Train_Stage1_K.py:172; here once, outside every timed region --
+    the per-step collective stays the single gradient all-reduce), then an all-reduced checksum that every rank holds the same
+    bytes.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DIST):
+        return False
+    flat = model.ensure_flat()
+    dist.broadcast(flat, 0)
+    for n, p in model.named_parameters():  # amask_conv never trains (FAL_netB.py:128) and lives outside the flat buffer
+        if "amask_conv" in n:
+            dist.broadcast(p.data, 0)
+    model.mark_weights_changed()
+    if check:
+        d = flat.double()
+        mine = torch.stack([d.sum(), (d * d).sum()])
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("sync_parameters: ranks hold different parameters after the broadcast")
+    return True
 
 
 def enable_overlapped_allreduce(model):
@@ -278,21 +302,16 @@ def stage2_step(model, fix_model, opt, left, right, max_disp, a_p=0.01, a_sm=0.4
     if a_mr == 0:
         O_L = O_R = 1  # :300-302
     else:
-        O_L = lmask * lrmask
-        O_L[:, :, :, 0:c2] = 1
-        O_R = rmask * rlmask
-        O_R[:, :, :, c8:] = 1
+        O_L = occlusion_mask(lmask, lrmask, 0, c2)   # lmask * lrmask; O_L[:, :, :, 0:c2] = 1
+        O_R = occlusion_mask(rmask, rlmask, c8, W)   # rmask * rlmask; O_R[:, :, :, c8:] = 1
     rec_loss = (rec_loss_fnc(O_R, rpan, right, vgg_right, a_p) + rec_loss_fnc(O_L, lpan, left, vgg_left, a_p)) / 2
     sm_loss = 0
     if a_sm > 0:
         sm_loss = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
                    smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
     mirror_loss = 0
-    if a_mr > 0:  # :316-324 (small 1-channel maps; masked means stay in torch)
-        nmaxl = 1 / mldisp.reshape(B, -1).max(1).values.view(B, 1, 1, 1)
-        nmaxr = 1 / mrdisp.reshape(B, -1).max(1).values.view(B, 1, 1, 1)
-        mirror_loss = (torch.mean(nmaxl * (1 - O_L)[:, :, :, c2:] * torch.abs(ldisp - mldisp)[:, :, :, c2:]) +
-                       torch.mean(nmaxr * (1 - O_R)[:, :, :, 0:c8] * torch.abs(rdisp - mrdisp)[:, :, :, 0:c8])) / 2
+    if a_mr > 0:  # :316-324: per-sample 1 / max(teacher disparity), (1 - O) weight, windowed masked L1 -- three launches per view
+        mirror_loss = (mirror_loss_fnc(ldisp, mldisp, O_L, c2, W) + mirror_loss_fnc(rdisp, mrdisp, O_R, 0, c8)) / 2
     loss = rec_loss + a_sm * sm_loss + a_mr * mirror_loss
     unscale = scaled_backward(loss, model)
     scale = allreduce_gradients(model)

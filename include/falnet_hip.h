@@ -10,8 +10,10 @@
  * Conventions
  *   - plain `extern "C"`, raw device pointers, explicit sizes; no torch types.
  *   - every launch function takes the HIP stream (as void*) and enqueues only on it; it never
- *     allocates, never synchronises and never touches the default stream.  Workspaces are
- *     caller-owned (`*_workspace_bytes` queries).
+ *     allocates, never synchronises and never touches the default stream; on entry it makes the
+ *     stream's device current (hipStreamGetDevice + hipSetDevice).  Workspaces are caller-owned:
+ *     falnet_wgrad_workspace_bytes (split-K slabs), falnet_conv_t::splitk_ws (+ _bytes, M * w_rows
+ *     floats for a split-K launch); no other entry point needs scratch memory.
  *   - return value: 0 ok, <0 bad argument (see falnet_last_error()), >0 hipError_t.
  *   - re-entrant: forward runs on the Python main thread, backward on autograd's thread.
  *   - dtype enum: activations/weights are FALNET_F32 (exact-f32 MFMA, parity path), FALNET_BF16
@@ -39,9 +41,10 @@ int falnet_version(void);
 const char* falnet_last_error(void);
 /* channel padding granule (elements) of NHWC tensors and packed weights: 32 for every dtype */
 int falnet_channel_pad(int dtype);
-/* tuning switches for tools/bench_conv.py (kernel A/B inside one process): key 0 = force the gather conv
- * kernel, key 1 = K bytes per chunk of the halo-patch kernel (128 / 64 / 0) */
-int falnet_debug_set(int key, int value);
+/* Every launch function makes the device that owns its `stream` argument current on the calling thread before it enqueues
+ * (forward runs on the Python main thread, backward on autograd's worker thread: no thread-local HIP state is assumed).
+ * falnet_set_device is for callers that use the NULL stream from a thread whose current device is not the tensors'. */
+int falnet_set_device(int device);
 
 /* One input of a convolution: NHWC tensor (or a per-sample constant when sy = sx = 0). */
 typedef struct {
@@ -289,10 +292,26 @@ int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
                          float eps, float grad_scale, void* stream);
 
+/* Stage-2 occlusion mask (Train_Stage2_K.py:296-302): out = a * b, forced to 1 in the column window [x0, x1); planar f32
+ * [B][1][H][W], no gradient */
+int falnet_occlusion_mask(const float* a, const float* b, float* out, int B, int H, int W, int x0, int x1, void* stream);
+/* mirror-loss weight (Train_Stage2_K.py:319-324): out = (1 - occ) / rowmax[b] inside [x0, x1), 0 outside; with it the mirror
+ * loss is falnet_l1_fwd(disp, teacher_disp, mask = out, scale = 1 / (B H (x1 - x0))) */
+int falnet_mirror_weight(const float* occ, const float* rowmax, float* out, int B, int H, int W, int x0, int x1, void* stream);
 /* horizontal flip of planar f32 [n_rows][W] (Train_Stage2_K.py:248-253 flip grid) */
 int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W, void* stream);
 /* per-sample max of planar f32 [B][n] -> out[B]  (F.max_pool2d(kernel=(H,W)), Train_Stage2_K.py:319) */
 int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream);
+
+/* Small f32 matrix product C (+)= A B with element strides (A[m * sam + k * sak], B[k * sbk + n * sbn], C row-major M x N):
+ * the composed logits conv Wc = W1x1 . W3x3 (FAL_netB.py:127,190; once per weight update) and the split of its gradient,
+ * dW3x3 = W1x1^T dWc, dW1x1 = dWc W3x3^T.  M * N * K <= 2^32. */
+int falnet_gemm_f32_small(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                          int M, int N, int K, int accumulate, void* stream);
+/* Resampling of planar f32 maps [planes][H][W] -> [planes][OH][OW] times `scale` (Test_KITTI.py:287-300 ms_pp): bilinear != 0 ->
+ * F.interpolate(mode='bilinear', align_corners=True), else mode='nearest' */
+int falnet_resize_planar(const float* src, float* dst, int64_t planes, int H, int W, int OH, int OW, int bilinear, float scale,
+                         void* stream);
 
 /* ---- training-data augmentation (data_transforms.py:46-157, Train_Stage1_K.py:116-128) ---- */
 /* One pass of Pillow's 8-bit bicubic resampling (Image.resize(size, BICUBIC), data_transforms.py:68) over an interleaved uint8

@@ -77,3 +77,67 @@ def test_bucketed_allreduce_covers_the_flat_buffer_once(tmp_path):
     got = torch.load(out)
     assert got["scale"] == 0.5 and got["pending"] == 0
     assert torch.equal(got["g"], torch.arange(1000, dtype=torch.float32) * 3)  # rank0 (x1) + rank1 (x2), every element exactly once
+
+
+# ---- the REAL module on CPU: flat parameter / gradient buffers and their bucket ranges need no GPU (FAL_net.ensure_flat) ----
+def _real_model(arch, levels=7, seed=0):
+    from fal_net_amd import models as M
+    torch.manual_seed(seed)
+    return getattr(M, "FAL_net" + arch)(None, no_levels=levels)
+
+
+def test_gradient_buckets_of_the_real_models_tile_the_flat_buffer():
+    """FAL_netB / A / C: gradient_buckets() are contiguous, disjoint, cover [0, total) and come in the order backward finalises
+    them (decoder + logits conv, encoder levels 4-6, 1-3, level 0); every trainable parameter lies inside exactly one bucket."""
+    for arch in ("B", "A", "C"):
+        m = _real_model(arch)
+        flat = m.ensure_flat("cpu")
+        buckets = m.gradient_buckets()
+        total = flat.numel()
+        assert len(buckets) == 4 and buckets[0][1] == total and buckets[-1][0] == 0
+        for (lo, hi), (lo2, hi2) in zip(buckets[:-1], buckets[1:]):
+            assert lo < hi and hi2 == lo  # back to front, touching, no overlap
+        named = m._trainable_named()
+        pre = "backbone." if arch == "B" else ("BackBone." if arch == "A" else "synth.")
+        want = {0: ("deconv", "iconv", "conv0."), 1: ("conv4", "conv5", "conv6"), 2: ("conv1", "conv2", "conv3"), 3: ("conv0",)}
+        for (n, p), off in zip(named, m._offsets):
+            inside = [i for i, (lo, hi) in enumerate(buckets) if lo <= off and off + p.numel() <= hi]
+            assert len(inside) == 1, (arch, n)
+            short = n[len(pre):] if n.startswith(pre) else n
+            assert short.startswith(want[inside[0]]), (arch, n, inside[0])
+        assert all("amask_conv" not in n for n, _ in named)
+
+
+def _worker_real(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _real_model("B", seed=100 + rank)  # every rank starts from DIFFERENT random weights ...
+    before = m.ensure_flat("cpu").clone()
+    assert train.sync_parameters(m)        # ... and holds rank 0's after the start-up broadcast
+    flat = m.flat_parameters()
+    g = m.flat_gradients()
+    g.copy_(torch.arange(g.numel(), dtype=torch.float32) % 97 * (rank + 1))
+    train.enable_overlapped_allreduce(m)
+    for i in range(4):                     # backward finalises the four real buckets in this order
+        m._bucket_ready(i)
+    n_async = len(m._pending_reduces)
+    scale = train.allreduce_gradients(m)
+    # an accumulating backward must not fire the per-bucket all-reduce again (the running sum would be reduced twice)
+    m._accumulating = True
+    m._bucket_ready(0)
+    n_acc = len(m._pending_reduces)
+    if rank == 0:
+        torch.save({"flat": flat.clone(), "g": g.clone(), "scale": scale, "n_async": n_async, "n_acc": n_acc, "changed": bool((before != flat).any())}, out)
+    else:
+        torch.save({"flat": flat.clone(), "changed": bool((before != flat).any())}, out + ".1")
+    dist.destroy_process_group()
+
+
+def test_real_model_broadcast_and_bucketed_allreduce(tmp_path):
+    world, out = 2, str(tmp_path / "real.pt")
+    mp.spawn(_worker_real, args=(world, 29535, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out), torch.load(out + ".1")
+    assert torch.equal(r0["flat"], r1["flat"]) and not r0["changed"] and r1["changed"]  # rank 1 took rank 0's parameters
+    assert r0["n_async"] == 4 and r0["n_acc"] == 0 and r0["scale"] == 0.5
+    n = r0["g"].numel()
+    assert torch.equal(r0["g"], torch.arange(n, dtype=torch.float32) % 97 * 3)  # every element summed over both ranks exactly once

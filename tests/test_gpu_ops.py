@@ -684,3 +684,79 @@ def test_wgrad_rows(case, dtype):
         assert rel(gw, w.grad) < 2e-5, (nsplit, rel(gw, w.grad))
         if bias:
             assert rel(gb, b.grad) < 2e-5
+
+
+def test_launch_from_a_fresh_thread_and_side_stream():
+    """SURVEY 8b threading contract: launches are issued from autograd's worker thread too.  Every entry point makes the device of
+    the stream it is given current on the calling thread (hipStreamGetDevice + hipSetDevice), so a brand-new thread works."""
+    import threading
+    x = torch.randn(4, 37, device=DEV)
+    out = torch.empty_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    err = []
+
+    def work():
+        try:
+            import ctypes
+            L.check(L.lib().falnet_set_device(torch.cuda.current_device()))
+            L.check(L.lib().falnet_hflip(L.ptr(x), L.ptr(out), 4, 37, ctypes.c_void_p(side.cuda_stream)))
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    side.synchronize()
+    assert not err and torch.equal(out, x.flip(1))
+    assert L.lib().falnet_set_device(10 ** 6) != 0  # errors are reported, not swallowed
+
+
+def test_stage2_mask_and_mirror_kernels():
+    """falnet_occlusion_mask / falnet_rowmax / falnet_mirror_weight + the masked L1: Train_Stage2_K.py:296-302, :316-324."""
+    from fal_net_amd import loss_functions as LF
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 3, 9, 40
+    a, b = torch.rand(B, 1, H, W, generator=g), torch.rand(B, 1, H, W, generator=g)
+    c2, c8 = int(0.2 * W), int(0.8 * W)
+    ref = a * b
+    ref[:, :, :, 0:c2] = 1
+    O_L = LF.occlusion_mask(a.to(DEV), b.to(DEV), 0, c2)
+    assert torch.equal(O_L.cpu(), ref)
+    ref_r = a * b
+    ref_r[:, :, :, c8:] = 1
+    assert torch.equal(LF.occlusion_mask(a.to(DEV), b.to(DEV), c8, W).cpu(), ref_r)
+    disp = (torch.rand(B, 1, H, W, generator=g) * 50).requires_grad_(True)
+    tdisp = torch.rand(B, 1, H, W, generator=g) * 60
+    nmax = 1 / F.max_pool2d(tdisp, kernel_size=(H, W))
+    want = torch.mean(nmax * (1 - ref)[:, :, :, c2:] * torch.abs(disp - tdisp)[:, :, :, c2:])
+    want.backward()
+    d = disp.detach().to(DEV).requires_grad_(True)
+    got = LF.mirror_loss_fnc(d, tdisp.to(DEV), O_L, c2, W)
+    got.backward()
+    assert abs(float(got) - float(want)) < 1e-5 * abs(float(want))
+    assert rel(d.grad, disp.grad) < 1e-5
+
+
+def test_small_gemm_and_resize():
+    """falnet_gemm_f32_small (composed logits weights and their gradient split) and falnet_resize_planar (ms_pp resampling)."""
+    from fal_net_amd import inference
+    g = torch.Generator().manual_seed(4)
+    n, k = 49, 864
+    w1, w3, gc = torch.randn(n, n, generator=g), torch.randn(n, k, generator=g), torch.randn(n, k, generator=g)
+    w1d, w3d, gcd = w1.to(DEV), w3.to(DEV), gc.to(DEV)
+    lib, st = L.lib(), L.stream_ptr()
+    wc = torch.empty(n, k, device=DEV)
+    L.check(lib.falnet_gemm_f32_small(L.ptr(w1d), n, 1, L.ptr(w3d), k, 1, L.ptr(wc), n, k, n, 0, st))
+    assert rel(wc, w1 @ w3) < 1e-5
+    g3 = torch.ones(n, k, device=DEV)
+    L.check(lib.falnet_gemm_f32_small(L.ptr(w1d), 1, n, L.ptr(gcd), k, 1, L.ptr(g3), n, k, n, 1, st))
+    assert rel(g3, 1 + w1.t() @ gc) < 1e-5
+    g1 = torch.zeros(n, n, device=DEV)
+    L.check(lib.falnet_gemm_f32_small(L.ptr(gcd), k, 1, L.ptr(w3d), 1, k, L.ptr(g1), n, n, k, 1, st))
+    assert rel(g1, gc @ w3.t()) < 1e-5
+    x = torch.randn(2, 3, 37, 124, generator=g)
+    up = F.interpolate(x, scale_factor=2 / 3, mode="bilinear", align_corners=True)
+    got = inference.resize_planar(x.to(DEV), up.shape[2:], bilinear=True)
+    assert got.shape == up.shape and rel(got, up) < 1e-5
+    dn = 1.5 * F.interpolate(up, size=(37, 124), mode="nearest")
+    assert torch.equal(inference.resize_planar(up.to(DEV), (37, 124), bilinear=False, scale=1.5).cpu(), dn)
