@@ -3,9 +3,11 @@
 
 Same flag names and defaults as the reference (Train_Stage1_K.py:30-70), with types added (the reference's
 untyped flags only work at their defaults).  Differences, all outside the hot path:
-  * `--synthetic` (default when no dataset loader is available): seeded random stereo pairs of the crop size,
-    so the script runs with no KITTI files -- the data pipeline (Datasets/, data_transforms.py) is out of scope
-    for this round (SURVEY.md section 8f, rank 3);
+  * real data (`-d <root>`): the pairs of `--train_list` are decoded by `--workers` loader processes (fal_net_amd.datasets),
+    uploaded as uint8 and augmented ON THE GPU (fal_net_amd.data_transforms.StereoAugment: the reference's co_transform +
+    input_transform chain, Train_Stage1_K.py:116-128); every epoch ends with validate() on KITTI 2015 (:279-347) when
+    `<root>/<vdataName>` holds it, and the best RMSE keeps `model_best.pth.tar` (:199-207);
+  * `--synthetic`: seeded random stereo pairs of the crop size, so the script also runs with no KITTI files;
   * data parallelism is one process per GPU (`torchrun --nproc-per-node N Train_Stage1_K.py ...`) with ONE RCCL
     all-reduce of the flat gradient buffer per step, instead of nn.DataParallel (Train_Stage1_K.py:172);
   * logging is stdout / JSON lines; losses are read back every `--print-freq` steps only (the reference syncs twice
@@ -53,7 +55,10 @@ parser.add_argument('--synthetic', action='store_true', help='seeded random pair
 parser.add_argument('--gpu-augment', action='store_true',
                     help='synthetic mode: start from KITTI-sized uint8 "decoded" pairs and run the reference augmentation chain on '
                          'the GPU every step (fal_net_amd.data_transforms.StereoAugment) instead of cycling pre-made float batches')
-parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='compute dtype (f32 = exact-f32 MFMA parity path)')
+parser.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'], help='compute dtype (f32 = exact-f32 MFMA parity path)')
+parser.add_argument('--train_list', default=os.path.join('Datasets', 'kitti_eigen_train.txt'),
+                    help="training pairs, one 'left right' pair of paths relative to <data>/<dataName0> per line (the reference opens this "
+                         "file relative to the working directory, Datasets/Kitti.py:37)")
 parser.add_argument('--save-path', default=None)
 
 
@@ -74,10 +79,11 @@ def main(step='stage1_step'):
         dist.init_process_group('nccl', device_id=dev)
     if args.weight_decay or args.bias_decay:
         raise SystemExit('weight decay is 0 in the reference defaults; the fused flat Adam implements wd=0 only')
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     LF.set_compute_dtype(dtype)
 
-    save_path = args.save_path or os.path.join(args.dataName0 + '_stage1', datetime.datetime.now().strftime('%m-%d-%H_%M'),
+    stage2 = step == 'stage2_step'
+    save_path = args.save_path or os.path.join(args.dataName0 + ('_stage2' if stage2 else '_stage1'), datetime.datetime.now().strftime('%m-%d-%H_%M'),
                                                '{},e{}es{},b{},lr{}'.format(args.m_model, args.epochs, args.epoch_size or '', args.batch_size, args.lr))
     if rank == 0:
         os.makedirs(save_path, exist_ok=True)
@@ -85,7 +91,15 @@ def main(step='stage1_step'):
             f.write(''.join('%15s: %s\n' % (k, v) for k, v in vars(args).items()))
 
     network_data = torch.load(args.pretrained, map_location='cpu') if args.pretrained else None
+    if stage2 and network_data is None:  # Stage 2 fine-tunes a Stage-1 model (Train_Stage2_K.py:66-71); without one: seeded weights
+        network_data = {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
     m_model = models.__dict__[args.m_model](network_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev)
+    fix_model = None
+    if stage2:  # frozen Stage-1 teacher (Train_Stage2_K.py:190-198)
+        fix_data = torch.load(args.fix_model, map_location='cpu') if args.fix_model else {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
+        fix_model = models.__dict__[args.m_model](fix_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev).eval()
+        for q in fix_model.parameters():
+            q.requires_grad_(False)
     if rank == 0:
         print("=> Number of parameters m-model '{}'".format(utils.get_n_params(m_model)))
     train.sync_parameters(m_model)  # N > 1: rank 0's weights to every rank, once (then one gradient all-reduce per step)
@@ -94,10 +108,26 @@ def main(step='stage1_step'):
     def lr_at(epoch):  # MultiStepLR(milestones, gamma=0.5), fast-forwarded like Train_Stage1_K.py:181-184
         return args.lr * (0.5 ** sum(1 for m in args.milestones if epoch >= m))
 
+    train_loader = val_loader = None
     if not args.synthetic:
-        raise SystemExit('only --synthetic input is wired in this build: the KITTI file lists / image decoding (Datasets/) need the '
-                         'dataset; the augmentation chain itself runs on the GPU (--gpu-augment, SURVEY.md 8f-3).')
-    steps_per_epoch = args.epoch_size or 100
+        if not args.data:
+            raise SystemExit('give the dataset root with -d/--data (or run with --synthetic)')
+        from fal_net_amd import data_transforms as DT
+        from fal_net_amd import datasets as DS
+        root = os.path.join(args.data, args.dataName0)
+        pairs = DS.read_pair_list(args.train_list, root)
+        if not pairs:
+            raise SystemExit('no training pair of {} exists under {}'.format(args.train_list, root))
+        train_loader = DS.make_loader(DS.StereoPairDataset(root, pairs, max_pix=args.max_disp, fix=True), args.batch_size, args.workers,
+                                      shuffle=True, rank=rank, world=world)
+        vroot = os.path.join(args.data, args.vdataName)
+        vtriples = DS.kitti2015_pairs(vroot) if os.path.isdir(vroot) else []
+        if vtriples:
+            val_loader = DS.make_loader(DS.StereoValDataset(vroot, vtriples), args.tbatch_size, args.workers, shuffle=False, drop_last=False)
+        real_augment = DT.StereoAugment(args.crop_height, args.crop_width)
+        if rank == 0:
+            print('=> {} training pairs, {} validation pairs'.format(len(pairs), len(vtriples)))
+    steps_per_epoch = args.epoch_size or (len(train_loader) if train_loader is not None else 100)
     best = -1
     # synthetic mode: a small pool of seeded batches resident in HBM, cycled (generating 25 MB of noise on the CPU every
     # step would make the script loader-bound; a real loader prefetches asynchronously)
@@ -120,24 +150,58 @@ def main(step='stage1_step'):
         import torch as _t
         views = [augment(raw[(i * args.batch_size + b) % len(raw)]) for b in range(args.batch_size)]
         return _t.stack([v[0] for v in views]), _t.stack([v[1] for v in views]), mx_aug
+    def real_batches():
+        """Decoded uint8 pairs -> GPU -> augmented (B, 3, ch, cw) tensors; the upload of the next list overlaps the current step
+        (pinned memory, non_blocking)."""
+        import torch as _t
+        for batch in train_loader:
+            views = [real_augment([l.to(dev, non_blocking=True), r.to(dev, non_blocking=True)]) for l, r, _ in batch]
+            mxs = _t.tensor([abs(x) for _, _, x in batch], device=dev).view(-1, 1, 1)
+            yield _t.stack([v[0] for v in views]), _t.stack([v[1] for v in views]), mxs
+
     for epoch in range(args.start_epoch, args.epochs):
         opt.param_groups[0]['lr'] = lr_at(epoch)
         m_model.train()
         losses, rec_losses = utils.AverageMeter(), utils.AverageMeter()
         end = time.time()
+        if train_loader is not None and getattr(train_loader, 'sampler', None) is not None and hasattr(train_loader.sampler, 'set_epoch'):
+            train_loader.sampler.set_epoch(epoch)
+        stream = real_batches() if train_loader is not None else None
         for i in range(steps_per_epoch):
-            left, right, mx = next_batch(i)
-            out = getattr(train, step)(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
-                                       min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
+            if stream is not None:
+                try:
+                    left, right, mx = next(stream)
+                except StopIteration:
+                    break
+            else:
+                left, right, mx = next_batch(i)
+            if stage2:
+                out = train.stage2_step(m_model, fix_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm, a_mr=args.a_mr,
+                                        min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
+            else:
+                out = getattr(train, step)(m_model, opt, left, right, mx, a_p=args.a_p, a_sm=args.a_sm,
+                                           min_disp_arg=args.min_disp, max_disp_arg=args.max_disp)
             if i % args.print_freq == 0:
                 losses.update(float(out['loss']), args.batch_size)
                 rec_losses.update(float(out['rec']), args.batch_size)
                 if rank == 0:
-                    print(json.dumps({'epoch': epoch, 'iter': i, 'of': steps_per_epoch, 'loss': losses.val, 'rec_loss': rec_losses.val,
-                                      'pairs_per_s': world * args.batch_size * (i + 1) / (time.time() - end)}), flush=True)
+                    rec = {'epoch': epoch, 'iter': i, 'of': steps_per_epoch, 'loss': losses.val, 'rec_loss': rec_losses.val,
+                           'pairs_per_s': world * args.batch_size * (i + 1) / (time.time() - end)}
+                    if stage2:
+                        rec['mirror'] = float(out['mirror'])
+                    print(json.dumps(rec), flush=True)
+        is_best = False
+        if val_loader is not None and rank == 0:  # :190-207: validate, keep the best RMSE
+            res = train.validate(m_model, val_loader, max_disp=args.max_disp, min_disp=args.min_disp, rel_baset=args.rel_baset,
+                                 sparse=args.sparse, print_freq=args.print_freq)
+            print(json.dumps({'epoch': epoch, 'val_rmse': res['rmse'], 'val_epe': res['epe'], 'kitti': res['kitti']}), flush=True)
+            if best < 0:
+                best = res['rmse']
+            is_best = res['rmse'] <= best
+            best = min(res['rmse'], best)
         if rank == 0:
             utils.save_checkpoint({'epoch': epoch + 1, 'm_model': args.m_model, 'state_dict': m_model.state_dict(), 'best_rmse': best},
-                                  False, save_path)
+                                  is_best, save_path)
     if world > 1:
         dist.destroy_process_group()
 

@@ -60,6 +60,14 @@ class multiAverageMeter(object):
         return "".join("{:>10}".format(l) for l in self.labels) + "\n" + "".join("{:10.4f}".format(a) for a in self.avg)
 
 
+def get_rmse(output_right, label_right, mean=(0.411, 0.432, 0.45)):
+    """RMSE of the synthesised view in 8-bit units, prediction clamped to [0, 255] (myUtils.py:138-150); device follows the input."""
+    shift = torch.tensor(mean, device=output_right.device, dtype=output_right.dtype).view(1, 3, 1, 1)
+    out = ((output_right + shift) * 255).clamp(0, 255)
+    lab = (label_right + shift) * 255
+    return torch.mean((out - lab) ** 2) ** 0.5
+
+
 def get_n_params(model):
     return sum(p.numel() for p in model.parameters())
 

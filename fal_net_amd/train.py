@@ -256,6 +256,38 @@ class GraphedStage1Step:
         return self.out
 
 
+def validate(model, val_loader, max_disp=300.0, min_disp=2.0, rel_baset=1.0, sparse=True, print_freq=100, log=print):
+    """Train_Stage1_K.py:279-347 / Train_Stage2_K.py validate(): full-size forward (disp + synthesised right view + masks), RMSE of
+    the synthesised view, EPE and the KITTI depth errors against the ground-truth disparity.  `val_loader` yields lists of
+    (left_u8, right_u8, disp) from fal_net_amd.datasets.StereoValDataset (batch size 1 in the reference, :152).
+    Returns {'rmse', 'epe', 'kitti': {name: value}} (the reference returns the RMSE, :345)."""
+    import numpy as np
+    from . import datasets as DS
+    from . import myUtils as utils
+    from .loss_functions import realEPE
+    dev = next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    rmses, epes, kitti = utils.AverageMeter(), utils.AverageMeter(), utils.multiAverageMeter(utils.kitti_error_names)
+    with torch.no_grad():
+        for i, batch in enumerate(val_loader):
+            for left_u8, right_u8, disp_gt in batch:
+                left, right = DS.to_model_input(left_u8, dev), DS.to_model_input(right_u8, dev)
+                mx = torch.full((1, 1, 1), float(max_disp) * rel_baset, device=dev)
+                mn = mx * min_disp / max_disp
+                p_im, disp, maskL, maskRL = model(left, mn, mx, ret_disp=True, ret_pan=True, ret_subocc=True)
+                rmses.update(float(utils.get_rmse(p_im, right)))
+                if disp_gt is not None:
+                    target = disp_gt.to(dev).view(1, 1, *disp_gt.shape)
+                    epes.update(float(realEPE(disp, target, sparse=sparse)), 1)
+                    gt_depth, pred_depth = utils.disps_to_depths_kitti2015(target.squeeze(1).cpu().numpy(), disp.squeeze(1).cpu().numpy())
+                    kitti.update(utils.compute_kitti_errors(gt_depth[0], pred_depth[0]), 1)
+            if log is not None and i % print_freq == 0:
+                log('Test: [{0}/{1}]\t RMSE {2:.3f}'.format(i, len(val_loader), rmses.avg))
+    model.train(was_training)
+    return {"rmse": rmses.avg, "epe": epes.avg, "kitti": dict(zip(utils.kitti_error_names, [float(a) for a in kitti.avg]))}
+
+
 def hflip(x):
     """Flip via index reversal; the reference's affine_grid + grid_sample flip equals it to <=8.4e-7
     (Train_Stage2_K.py:248-253)."""

@@ -66,3 +66,43 @@ def test_entry_scripts_synthetic(cmd, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "{" in r.stdout
+
+
+def test_kitti_native_size_forward_and_ms_pp_vs_oracle():
+    """Test_KITTI.py's default input, 375 x 1242 (B = 1, f32): odd sizes at every level -- 188 -> 94 -> 47 -> 24 -> 12 -> 6, so
+    every decoder stage resamples with a non-integer nearest ratio (FAL_netB.py:58) -- and the ms_pp second forward at
+    250 x 828.  Forward disparity and the post-processed map against the CPU oracle (pinned by goldens G5 / G7 at small sizes)."""
+    from oracle import falnet_oracle as O
+    left, right, mn, mx = synthetic.synthetic_pair(1, 375, 1242, seed=77)
+    sd = synthetic.seeded_falnetb_state_dict(49)
+    m = FAL_netB({"state_dict": sd}, 49).to(DEV).eval()
+    with torch.no_grad():
+        disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV))
+        pp = inference.ms_pp(left.to(DEV), m, disp, mn.to(DEV), mx.to(DEV))
+        ref = O.falnet_forward(sd, left, mn, mx)
+        ref_pp = O.ms_pp(sd, left, ref, mn, mx)
+    assert rel(disp, ref) < 1e-4
+    assert rel(pp, ref_pp) < 2e-4
+
+
+@pytest.mark.parametrize("script,extra", [("Train_Stage1_K.py", []), ("Train_Stage2_K.py", ["-no_levels", "7"])])
+def test_entry_scripts_train_and_validate_on_generated_pngs(script, extra, tmp_path):
+    """The real-data path end to end without KITTI: generated PNG tree + pair list -> loader workers decode -> uint8 upload ->
+    GPU augmentation -> two optimiser steps -> validate() on two 375 x 1242 KITTI-2015-shaped pairs (RMSE, EPE, KITTI errors) ->
+    checkpoint + model_best (Train_Stage1_K.py:137-160, :190-207, :279-347)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_logic import _write_png_fixture
+    root, lst = _write_png_fixture(tmp_path)
+    save = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, script), "-d", str(root), "--train_list", str(lst), "--epochs", "1", "-b", "2", "-ch", "64", "-cw", "128",
+           "-p", "1", "-w", "2", "--dtype", "f32", "--save-path", str(save)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    steps = [x for x in recs if "iter" in x]
+    val = [x for x in recs if "val_rmse" in x]
+    assert len(steps) == 2 and all(np.isfinite(x["loss"]) for x in steps)  # 4 pairs / batch 2
+    assert len(val) == 1 and 0 < val[0]["val_rmse"] < 255 and np.isfinite(val[0]["val_epe"]) and set(val[0]["kitti"]) == set(utils.kitti_error_names)
+    assert os.path.isfile(save / "checkpoint.pth.tar") and os.path.isfile(save / "model_best.pth.tar")
+    assert "=> 4 training pairs, 2 validation pairs" in r.stdout

@@ -342,3 +342,25 @@ def test_reduced_precision_trains_like_f32():
         assert r[k]["finite"] and r[k]["loss_last"] < r[k]["loss_first"]
         assert abs(r[k]["loss_last_rel_to_f32"]) < 0.02, (k, r[k])
         assert r[k]["depth_abs_rel_vs_f32_model"] < max(0.25, 4 * ctrl), (k, r[k], ctrl)
+
+
+def test_stage2_step_256x512_vs_oracle():
+    """Stage-2 step at the benchmark resolution (BASELINE configs[3]: 256 x 512, N = 49; B = 2 here, f32) against the CPU oracle:
+    loss scalars, both occlusion masks and every parameter's gradient norm (the 64 x 128 case is pinned by golden G3)."""
+    LF.set_compute_dtype(torch.float32)
+    sd = synthetic.seeded_falnetb_state_dict(49)
+    left, right, mn, mx = synthetic.synthetic_pair(2, 256, 512, seed=41, distinct=True)
+    m, fix = build(49).train(), build(49).eval()
+    out = train.stage2_step(m, fix, train.FlatAdam(m, lr=5e-5), left.to(DEV), right.to(DEV), mx.to(DEV))
+    params = O.leaf_params(sd)
+    ref = O.stage2_losses(params, sd, synthetic.seeded_vgg19_state_dict(), left, right, mn, mx)
+    for k in ("loss", "rec", "sm", "mirror"):
+        assert abs(float(out[k]) - float(ref[k])) / abs(float(ref[k])) < TOL, (k, float(out[k]), float(ref[k]))
+    for k in ("O_L", "O_R"):
+        assert rel(out[k], ref[k]) < 2e-4, k
+    ref["loss"].backward()
+    for k, p in m.named_parameters():
+        if params[k].grad is None:
+            continue
+        gn = float(params[k].grad.norm())
+        assert abs(float(p.grad.norm()) - gn) / gn < 2e-3, (k, float(p.grad.norm()), gn)  # (the reference itself needs 1e-3 here: f32 sums over 131k pixels)

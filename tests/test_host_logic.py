@@ -99,3 +99,62 @@ def test_kitti_metrics_against_golden(golden_dir):
     assert np.allclose(U.compute_kitti_errors(g["gt"], g["pr"]), g["kitti_errors"], rtol=1e-6)
     td, pd = U.disps_to_depths_kitti2015(g["gd"], g["pd"])
     assert np.allclose(np.asarray(td), g["gt_depth"], rtol=1e-6) and np.allclose(np.asarray(pd), g["pred_depth"], rtol=1e-6)
+
+
+def _write_png_fixture(tmp_path, n_train=4, n_val=2, val_size=(375, 1242)):
+    """A KITTI-shaped tree of generated PNGs (no dataset needed): <root>/Kitti/<drive>/image_0{2,3}/data/*.png + a pair list in the
+    format of the reference's Datasets/kitti_eigen_train.txt, and <root>/Kitti2015/training/{image_2,image_3,disp_occ_0}."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    root = tmp_path / "data"
+    lines = []
+    for i in range(n_train):
+        for cam in ("image_02", "image_03"):
+            d = root / "Kitti" / "2011_09_26" / "drive_0001_sync" / cam / "data"
+            d.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (110 + i, 330 - 2 * i, 3), dtype=np.uint8)).save(d / f"{i:010d}.png")
+        lines.append(f"2011_09_26/drive_0001_sync/image_02/data/{i:010d}.png 2011_09_26/drive_0001_sync/image_03/data/{i:010d}.png")
+    lines.append("2011_09_26/drive_0001_sync/image_02/data/9999999999.png 2011_09_26/drive_0001_sync/image_03/data/9999999999.png")  # absent: skipped
+    lst = tmp_path / "train_pairs.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    for i in range(n_val):
+        for sub in ("image_2", "image_3"):
+            d = root / "Kitti2015" / "training" / sub
+            d.mkdir(parents=True, exist_ok=True)
+            Image.fromarray(rng.integers(0, 256, (*val_size, 3), dtype=np.uint8)).save(d / f"{i:06d}_10.png")
+        d = root / "Kitti2015" / "training" / "disp_occ_0"
+        d.mkdir(parents=True, exist_ok=True)
+        disp = (rng.random(val_size) * 80 * 256).astype(np.uint16)
+        disp[rng.random(val_size) < 0.5] = 0  # sparse ground truth
+        Image.fromarray(disp).save(d / f"{i:06d}_10.png")
+    return root, lst
+
+
+def test_real_data_loader_on_generated_pngs(tmp_path):
+    """File list -> decode in loader workers -> lists of uint8 pairs (frames of different sizes), KITTI-2015 validation triples with
+    the uint16 / 256 disparity decoding (reference: Datasets/Kitti.py:37-41, listdataset_train.py:70-98, listdataset_test.py:43-46)."""
+    from fal_net_amd import datasets as DS
+    root, lst = _write_png_fixture(tmp_path)
+    kroot = str(root / "Kitti")
+    pairs = DS.read_pair_list(str(lst), kroot)
+    assert len(pairs) == 4  # the absent pair is dropped like Kitti.py:40-41 does
+    ds = DS.StereoPairDataset(kroot, pairs, max_pix=300, fix=True)
+    seen = 0
+    for batch in DS.make_loader(ds, batch_size=2, workers=2, shuffle=True):
+        assert isinstance(batch, list) and len(batch) == 2
+        for left, right, x_pix in batch:
+            assert left.dtype == torch.uint8 and left.dim() == 3 and left.shape[2] == 3 and left.shape == right.shape and x_pix == 300.0
+            seen += 1
+    assert seen == 4
+    swapped = {DS.StereoPairDataset(kroot, pairs, max_pix=300, fix=False)[0][2] for _ in range(40)}
+    assert swapped == {300.0, -300.0}  # random view order with the sign of the disparity range (listdataset_train.py:70-79)
+    tr = DS.kitti2015_pairs(str(root / "Kitti2015"))
+    assert len(tr) == 2
+    left, right, disp = DS.StereoValDataset(str(root / "Kitti2015"), tr)[1]
+    assert left.shape == (375, 1242, 3) and disp.shape == (375, 1242) and disp.dtype == torch.float32
+    assert 0.0 <= float(disp.min()) and float(disp.max()) < 80.0 and float((disp == 0).float().mean()) > 0.3
+    x = DS.to_model_input(left, "cpu")
+    assert x.shape == (1, 3, 375, 1242) and abs(float(x[0, 1].mean()) - (float(left[..., 1].float().mean()) / 255 - 0.432)) < 1e-5
+    with pytest.raises(FileNotFoundError):
+        DS.read_pair_list(str(tmp_path / "nope.txt"), kroot)
