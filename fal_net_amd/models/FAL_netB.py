@@ -202,7 +202,8 @@ class FalnetPlan:
                 for c in calls:
                     c()
             import os as _os
-            chosen = ops.best_of(*multis, separate) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
+            s2key = f"s2dgrad|t{L.dtype_code(self.dtype)}|B{B}|{IH}x{IW}|{pc.cout_pad}>{cg}|a{int(addend is not None)}{int(actout is not None)}|n{len(multis)}"
+            chosen = ops.best_of(*multis, separate, key=s2key) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
             if chosen is separate:
                 self.bwd_body.extend(singles)
             else:
@@ -351,133 +352,144 @@ class FalnetPlan:
                 fix_r()
             self.head_masks = masks_a
 
-        # =========================== backward plan ===========================
-        g_disp, g_pan = self._f32("g_disp", B, 1, H, W), self._f32("g_pan", B, 3, H, W)
-        G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, written NHWC by the head backward itself
+        # The backward half (activation-gradient buffers, ~40 data-gradient and ~34 weight-gradient launches with their slab
+        # arena, their autotuning) is built on the FIRST run_backward: inference models, every extra ms_pp shape and the frozen
+        # Stage-2 teacher never pay for it (gigabytes of HBM and seconds of first-call latency per input shape).
+        def build_backward():
+            # =========================== backward plan ===========================
+            g_disp, g_pan = self._f32("g_disp", B, 1, H, W), self._f32("g_pan", B, 3, H, W)
+            G0 = self._act("G0", H, W, pad_c(N))  # grad wrt conv0(1x1) output, written NHWC by the head backward itself
 
-        def head_bwd(has_disp, has_pan):
-            return ops.simple_call("falnet_med_head_bwd_nhwc", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
-                                   L.ptr(pan), L.ptr(stats), L.ptr(g_disp if has_disp else None),
-                                   L.ptr(g_pan if has_pan else None), L.ptr(G0), pad_c(N), code, B, N, H, W,
-                                   name="falnet_med_head_bwd", nbytes=(N + 7) * H * W * 4 * B + B * H * W * pad_c(N) * G0.element_size())
-        self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
-        # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
-        # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: levels 1-3, 3: level 0.  After a bucket's
-        # last wgrad its slab reduce / bias-gradient launches run and model._bucket_ready(i) lets the trainer start that
-        # bucket's share of the step's all-reduce while backward continues.
-        self._bucket = 0
-        self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
-        # NHWC copy of the image for conv0's weight gradient: converted on the side stream; that weight gradient runs on the MAIN
-        # stream at the tail (tail balancing), so it waits for this event
-        self._x0_event = torch.cuda.Event()
+            def head_bwd(has_disp, has_pan):
+                return ops.simple_call("falnet_med_head_bwd_nhwc", L.ptr(dlog0), L.ptr(left), L.ptr(mn), L.ptr(mx), L.ptr(disp),
+                                       L.ptr(pan), L.ptr(stats), L.ptr(g_disp if has_disp else None),
+                                       L.ptr(g_pan if has_pan else None), L.ptr(G0), pad_c(N), code, B, N, H, W,
+                                       name="falnet_med_head_bwd", nbytes=(N + 7) * H * W * 4 * B + B * H * W * pad_c(N) * G0.element_size())
+            self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
+            # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
+            # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: levels 1-3, 3: level 0.  After a bucket's
+            # last wgrad its slab reduce / bias-gradient launches run and model._bucket_ready(i) lets the trainer start that
+            # bucket's share of the step's all-reduce while backward continues.
+            self._bucket = 0
+            self._finish = []  # placeholders in bwd_body, patched after WgradBatch.finalize()
+            # NHWC copy of the image for conv0's weight gradient: converted on the side stream; that weight gradient runs on the MAIN
+            # stream at the tail (tail balancing), so it waits for this event
+            self._x0_event = torch.cuda.Event()
 
-        def x0_convert_and_mark():
-            if not self._c3_wgrad:
-                self._x0_convert()
-            self._x0_event.record()  # on the stream the conversion was launched on
-        self._side_call(x0_convert_and_mark)
-        if compose:
-            g_dlog = G0  # the composed conv's output gradient IS the head's gradient
-        else:
-            self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
-            g_dlog = self._act("g_dlog", H, W, pad_c(N))
-            self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
-
-        gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], self._enc[i][2]) for i in range(7)}
-        # decoder, top (level 1) to bottom (level 6)
-        g_ipre = {1: g_dlog}  # gradient wrt the pre-activation of iconv{lvl} (iconv1 has no activation)
-        for lvl in range(1, 7):
-            dname, dch, iname, ich = self._dec[lvl]
-            hh, ww = sizes[lvl - 1]
-            below = ic[lvl + 1]
-            bh, bw = below.shape[1], below.shape[2]
-            pci, pcd = pcs[iname], pcs[dname]
-            if compose and lvl == 1:
-                pci = pcs["logits"]  # weight gradient lands in model._gwc and is split back after the bucket's slab reduce
-                iname = "logits"
-            skip = c[lvl - 1]
-            gi = g_ipre[lvl]
-            self._wgrad(pci, [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, gi, name=iname)
-            g_dpre = self._act(f"g_d{lvl}", hh, ww, dch)
-            self._dgrad(pci, 0, gi, g_dpre, hh, ww, actout=d[lvl], name=iname + "[deconv]")
-            self._dgrad(pci, 1, gi, gc[lvl - 1], hh, ww, name=iname + "[skip]")  # first writer of g_c{lvl-1}
-            self._wgrad(pcd, [ops.nhwc_src(below)], hh, ww, g_dpre, name=dname)
-            below_ch = below.shape[3]
-            if (bh, bw) == (hh, ww):  # degenerate: no resize
-                tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
-                self._dgrad(pcd, 0, g_dpre, tgt, hh, ww, actout=below, name=dname)
+            def x0_convert_and_mark():
+                if not self._c3_wgrad:
+                    self._x0_convert()
+                self._x0_event.record()  # on the stream the conversion was launched on
+            self._side_call(x0_convert_and_mark)
+            if compose:
+                g_dlog = G0  # the composed conv's output gradient IS the head's gradient
             else:
-                tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
-                fused = False
-                if (2 * bh, 2 * bw) == (hh, ww) and os.environ.get("FALNET_FUSED_UPSUM", "1") == "1":
-                    try:  # exact 2x: the 2x2 block sum and elu'(below) ride in the data-gradient epilogue (no full-res g_up)
-                        self._dgrad(pcd, 0, g_dpre, None, hh, ww, name=dname, sum2x2_into=tgt, sum2x2_actout=below)
-                        fused = True
-                    except ValueError:
-                        pass
-                if not fused:
-                    g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
-                    self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
-                    self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
-                                                         ww, bh, bw, below_ch, code))
-            if lvl < 6:
-                g_ipre[lvl + 1] = tgt
-        # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)
-        self._finish.append((0, len(self.bwd_body)))
-        # encoder, bottom (level 6) to top (level 0)
-        for i in range(6, -1, -1):
-            if i == 3:
-                self._finish.append((1, len(self.bwd_body)))
-            if i == 0:
-                self._finish.append((2, len(self.bwd_body)))
-            self._bucket = 1 if i >= 4 else (2 if i >= 1 else 3)
-            tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
-            cname, rname, ch = self._enc[i]
-            hh, ww = sizes[i]
-            gz = gc[i]
-            pr1, pr2, pcc = pcs[rname + ".conv1"], pcs[rname + ".conv2"], pcs[cname]
-            self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2")
-            g_h = self._act(f"g_h{i}", hh, ww, ch)
-            self._dgrad(pr2, 0, gz, g_h, hh, ww, actout=h_[i], name=rname + ".conv2")
-            self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1", on_main=tail)
-            g_a = self._act(f"g_a{i}", hh, ww, ch)
-            self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
-            srcs, ih, iw = self._enc_srcs[i]
-            if tail:
-                self._main_tail = getattr(self, "_main_tail", [])
-                self._main_tail.append(lambda: torch.cuda.current_stream().wait_event(self._x0_event))
-            self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
-            if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
-                self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
-        self.bwd_body.extend(getattr(self, "_main_tail", []))
-        self._finish.append((3, len(self.bwd_body)))
-        # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
-        # trainer's hook (asynchronous all-reduce of that range of the flat gradient buffer)
-        finals = self.wbatch.finalize()
-        body, self.bwd_body = self.bwd_body, []
-        pos = 0
-        for bucket, at in self._finish:
-            self.bwd_body.extend(body[pos:at])
-            pos = at
-            if bucket in finals:
-                red, bias = finals[bucket]
+                self._wgrad(pc0, [ops.nhwc_src(dlog)], H, W, G0, name="conv0(1x1)")
+                g_dlog = self._act("g_dlog", H, W, pad_c(N))
+                self._dgrad(pc0, 0, G0, g_dlog, H, W, name="conv0(1x1)")
 
-                if bucket == 3 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1":
-                    # last bucket: the bias gradients only need the data gradients -> main stream (idle by now), beside the
-                    # side stream's last weight gradients and slab reduce; run_backward fires the bucket hook after the join
-                    self.bwd_body.append(bias)
-                    self._side_call(red)
-                    self._deferred_ready = bucket
-                    continue
+            gc = {i: self._act(f"g_c{i}", sizes[i][0], sizes[i][1], self._enc[i][2]) for i in range(7)}
+            # decoder, top (level 1) to bottom (level 6)
+            g_ipre = {1: g_dlog}  # gradient wrt the pre-activation of iconv{lvl} (iconv1 has no activation)
+            for lvl in range(1, 7):
+                dname, dch, iname, ich = self._dec[lvl]
+                hh, ww = sizes[lvl - 1]
+                below = ic[lvl + 1]
+                bh, bw = below.shape[1], below.shape[2]
+                pci, pcd = pcs[iname], pcs[dname]
+                if compose and lvl == 1:
+                    pci = pcs["logits"]  # weight gradient lands in model._gwc and is split back after the bucket's slab reduce
+                    iname = "logits"
+                skip = c[lvl - 1]
+                gi = g_ipre[lvl]
+                self._wgrad(pci, [ops.nhwc_src(d[lvl]), ops.nhwc_src(skip)], hh, ww, gi, name=iname)
+                g_dpre = self._act(f"g_d{lvl}", hh, ww, dch)
+                self._dgrad(pci, 0, gi, g_dpre, hh, ww, actout=d[lvl], name=iname + "[deconv]")
+                self._dgrad(pci, 1, gi, gc[lvl - 1], hh, ww, name=iname + "[skip]")  # first writer of g_c{lvl-1}
+                self._wgrad(pcd, [ops.nhwc_src(below)], hh, ww, g_dpre, name=dname)
+                below_ch = below.shape[3]
+                if (bh, bw) == (hh, ww):  # degenerate: no resize
+                    tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
+                    self._dgrad(pcd, 0, g_dpre, tgt, hh, ww, actout=below, name=dname)
+                else:
+                    tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
+                    fused = False
+                    if (2 * bh, 2 * bw) == (hh, ww) and os.environ.get("FALNET_FUSED_UPSUM", "1") == "1":
+                        try:  # exact 2x: the 2x2 block sum and elu'(below) ride in the data-gradient epilogue (no full-res g_up)
+                            self._dgrad(pcd, 0, g_dpre, None, hh, ww, name=dname, sum2x2_into=tgt, sum2x2_actout=below)
+                            fused = True
+                        except ValueError:
+                            pass
+                    if not fused:
+                        g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
+                        self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
+                        self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
+                                                             ww, bh, bw, below_ch, code))
+                if lvl < 6:
+                    g_ipre[lvl + 1] = tgt
+            # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)
+            self._finish.append((0, len(self.bwd_body)))
+            # encoder, bottom (level 6) to top (level 0)
+            for i in range(6, -1, -1):
+                if i == 3:
+                    self._finish.append((1, len(self.bwd_body)))
+                if i == 0:
+                    self._finish.append((2, len(self.bwd_body)))
+                self._bucket = 1 if i >= 4 else (2 if i >= 1 else 3)
+                tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
+                cname, rname, ch = self._enc[i]
+                hh, ww = sizes[i]
+                gz = gc[i]
+                pr1, pr2, pcc = pcs[rname + ".conv1"], pcs[rname + ".conv2"], pcs[cname]
+                self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2")
+                g_h = self._act(f"g_h{i}", hh, ww, ch)
+                self._dgrad(pr2, 0, gz, g_h, hh, ww, actout=h_[i], name=rname + ".conv2")
+                self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1", on_main=tail)
+                g_a = self._act(f"g_a{i}", hh, ww, ch)
+                self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
+                srcs, ih, iw = self._enc_srcs[i]
+                if tail:
+                    self._main_tail = getattr(self, "_main_tail", [])
+                    self._main_tail.append(lambda: torch.cuda.current_stream().wait_event(self._x0_event))
+                self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
+                if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
+                    self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
+            self.bwd_body.extend(getattr(self, "_main_tail", []))
+            self._finish.append((3, len(self.bwd_body)))
+            # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
+            # trainer's hook (asynchronous all-reduce of that range of the flat gradient buffer)
+            finals = self.wbatch.finalize()
+            body, self.bwd_body = self.bwd_body, []
+            pos = 0
+            for bucket, at in self._finish:
+                self.bwd_body.extend(body[pos:at])
+                pos = at
+                if bucket in finals:
+                    red, bias = finals[bucket]
 
-                def finish(red=red, bias=bias, bucket=bucket):
-                    red()
-                    bias()
-                    if bucket == 0 and getattr(self.model, "_compose_logits", False):
-                        self._split_logits_grad()
-                    self.model._bucket_ready(bucket)
-                self._side_call(finish)
-        self.bwd_body.extend(body[pos:])
+                    if bucket == 3 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1":
+                        # last bucket: the bias gradients only need the data gradients -> main stream (idle by now), beside the
+                        # side stream's last weight gradients and slab reduce; run_backward fires the bucket hook after the join
+                        self.bwd_body.append(bias)
+                        self._side_call(red)
+                        self._deferred_ready = bucket
+                        continue
+
+                    def finish(red=red, bias=bias, bucket=bucket):
+                        red()
+                        bias()
+                        if bucket == 0 and getattr(self.model, "_compose_logits", False):
+                            self._split_logits_grad()
+                        self.model._bucket_ready(bucket)
+                    self._side_call(finish)
+            self.bwd_body.extend(body[pos:])
+
+        self._backward_builder = build_backward
+
+    def _ensure_backward(self):
+        if self._backward_builder is not None:
+            builder, self._backward_builder = self._backward_builder, None
+            builder()
 
     def _split_logits_grad(self):
         """dWc (composed 3x3 logits conv) -> dW3x3 = W1x1^T dWc and dW1x1 = dWc W3x3^T, added into the flat gradient buffer."""
@@ -517,6 +529,7 @@ class FalnetPlan:
         return self.generation
 
     def run_backward(self, g_disp, g_pan):
+        self._ensure_backward()
         b = self.buf
         if g_disp is not None:
             b["g_disp"].copy_(g_disp)

@@ -25,6 +25,71 @@ TIMER = None
 AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 
 
+# ---- persistent autotune choices --------------------------------------------------------------------------------------
+# Every plan-build-time choice (conv variant / split-K factor, fused vs separate stride-2 data gradients) is remembered in a JSON
+# file next to the library, keyed by the launch's shape signature: a later process replays the same variants WITHOUT timing
+# launches -- bench, profile and test runs then execute the same kernels (reproducible traces, no autotune launches inside a
+# rocprofv3 collection, two ranks of one job on the same choices).  FALNET_AUTOTUNE_CACHE=<path> moves the file, =0 disables
+# it; a miss is autotuned as before and appended (best effort: a read-only tree just keeps autotuning).
+_CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_cache.json"))
+_CACHE = None
+_CACHE_DIRTY = False
+
+
+def _cache():
+    global _CACHE
+    if _CACHE is None:
+        _CACHE = {}
+        if _CACHE_PATH != "0" and os.path.isfile(_CACHE_PATH):
+            try:
+                import json
+                with open(_CACHE_PATH) as f:
+                    _CACHE = json.load(f)
+            except (OSError, ValueError):
+                _CACHE = {}
+    return _CACHE
+
+
+def cache_get(key):
+    return _cache().get(key) if _CACHE_PATH != "0" else None
+
+
+def cache_put(key, value):
+    global _CACHE_DIRTY
+    if _CACHE_PATH != "0":
+        _cache()[key] = value
+        _CACHE_DIRTY = True
+
+
+def cache_flush():
+    """Write new choices back (atomic rename; silently skipped when the tree is read-only)."""
+    global _CACHE_DIRTY
+    if not _CACHE_DIRTY or _CACHE_PATH == "0":
+        return
+    try:
+        import json
+        tmp = _CACHE_PATH + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(dict(sorted(_cache().items())), f, indent=0)
+        os.replace(tmp, _CACHE_PATH)
+        _CACHE_DIRTY = False
+    except OSError:
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(cache_flush)
+
+
+def conv_signature(d):
+    """Shape signature of a falnet_conv_t: everything kernel selection and speed depend on, nothing run-specific (no pointers)."""
+    srcs = ";".join(f"{d.src[i].C},{d.src[i].H},{d.src[i].W},{int(d.src[i].sy == 0)}" for i in range(d.nsrc))
+    taps = ",".join(f"{d.tap_dy[t]}:{d.tap_dx[t]}:{d.tap_w[t]}" for t in range(d.ntaps))
+    flags = f"{int(bool(d.bias))}{int(bool(d.addend))}{d.act}{int(bool(d.actout))}{d.actout_kind}{int(bool(d.pool_out))}{d.pool_mode}{int(bool(d.pool_actout))}{int(bool(d.out))}"
+    return (f"conv|t{d.dtype}|{srcs}|{d.IH}x{d.IW}|k{d.cin_total}|{taps}|w{d.w_taps}x{d.w_rows}|s{d.isy}|B{d.B}|{d.TH}x{d.TW}|"
+            f"o{d.osy},{d.ooy},{d.oox}|{d.OH}x{d.OW}|c{d.Cout},{d.out_cstride},{d.out_layout}|f{flags}|ws{int(d.splitk_ws_bytes > 0)}")
+
+
 def _timed(tag, flops, nbytes, launch, name=""):
     def call(*a):
         t = TIMER
@@ -237,7 +302,15 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout)
     if AUTOTUNE and autotune and dev_t.is_cuda:
-        d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
+        key = conv_signature(d)
+        hit = cache_get(key)
+        if hit is not None:
+            d.variant, d.ksplit = int(hit[0]), int(hit[1])
+            if lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:  # stale entry (kernel table changed): re-tune
+                hit = None
+        if hit is None:
+            d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
+            cache_put(key, [int(d.variant), int(d.ksplit)])
     if pool_out is not None and lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:
         raise ValueError("no fused-pool kernel applies to this launch")  # the caller falls back to falnet_maxpool2_fwd
 
@@ -264,8 +337,14 @@ def _splitk_workspace(device, owner=None, nbytes=32 << 20):
     return _SPLITK_WS[key]
 
 
-def best_of(*calls, reps=5):
-    """Plan-build-time choice between equivalent launch sequences (zero-argument callables); ties go to the earlier one."""
+def best_of(*calls, reps=5, key=None):
+    """Plan-build-time choice between equivalent launch sequences (zero-argument callables); ties go to the earlier one.
+    `key`: remember the winner's index in the autotune cache (and replay it without timing when it is there)."""
+    if key is not None:
+        hit = cache_get(key)
+        if hit is not None and 0 <= int(hit) < len(calls):
+            return calls[int(hit)]
+
     def t(c):
         c()
         best = None
@@ -279,6 +358,8 @@ def best_of(*calls, reps=5):
             best = e0.elapsed_time(e1) if best is None else min(best, e0.elapsed_time(e1))
         return best
     times = [t(c) for c in calls]
+    if key is not None:
+        cache_put(key, times.index(min(times)))
     return calls[times.index(min(times))]
 
 
