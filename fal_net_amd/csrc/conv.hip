@@ -16,8 +16,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
-
-typedef f32x16_t f32x16;
+#include "conv_epilogue.h"
 
 #define CONV_THREADS 256
 #define CONV_BM 128
@@ -28,18 +27,6 @@ template <typename T> struct KC;
 template <> struct KC<float> { static constexpr int value = 16; };
 template <> struct KC<bf16_t> { static constexpr int value = 32; };
 template <> struct KC<f16_t> { static constexpr int value = 32; };
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == FALNET_ACT_ELU) return v > 0.f ? v : (__expf(v) - 1.f);
-    if (act == FALNET_ACT_RELU) return fmaxf(v, 0.f);
-    return v;
-}
-__device__ __forceinline__ float act_grad_from_out(float y, int kind) {
-    if (kind == FALNET_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
-    if (kind == FALNET_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-    return 1.f;
-}
-
 
 // ---- vectorised epilogue ------------------------------------------------------------------------------
 // The MFMA C/D layout puts one channel on each lane, so a direct store is 2 B (bf16) per lane: store-issue
@@ -74,7 +61,6 @@ template <> struct Vec8<float> {
 // PoolOff (optional, MT even): slabs are consecutive image rows and slab rows consecutive columns; called for odd mt /
 // even row, returns the element offset of the 2x2-pooled pixel in p.pool_out or -1.  The horizontal neighbour lives in
 // lane^CS (one shuffle), the vertical one in the previous slab (kept in registers).
-struct NoPool { static constexpr bool enabled = false; __device__ int64_t operator()(int, int) const { return -1; } };
 template <typename T, int MT, int NT, typename RowOff, typename PoolOff = NoPool>
 __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], float* stage, int nbase, int lane,
                                               RowOff rowoff, PoolOff pooloff = PoolOff()) {
@@ -180,191 +166,6 @@ __device__ __forceinline__ void epilogue_nhwc(const falnet_conv_t& p, f32x16 (&a
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (NBUF == 1 && mt + 1 < MT && (addend || actout)) prefetch(mt + 1, 0);
-    }
-}
-
-// ---- direct epilogue (halo-patch and first-layer kernels) ---------------------------------------------------------
-// With the MFMA operands exchanged (A = weights, B = pixels) the 32x32 C/D tile puts one PIXEL on each lane and sixteen
-// channels in its accumulators: acc[j] = channel 8*(j>>2) + 4*h + (j&3) of the tile, i.e. four groups of four consecutive
-// channels, lane halves h = 0/1 interleaved.  f32: every group is one 16-B store.  bf16: a group is 8 B; one
-// v_permlane32_swap per dword exchanges the upper half's group k with the lower half's group k+1, after which lanes 0-31
-// hold channels 8k..8k+7 and lanes 32-63 channels 8k+8..8k+15 of their pixel: one 16-B store per group pair
-// (cdna_hip_programming.md T21).  No LDS staging, no wave barriers; residual / activation-output operands are read in
-// the same 16-B chunks and un-swapped with the same (involutive) exchange.
-__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {  // lanes 32-63 of a <-> lanes 0-31 of b
-    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
-}
-// this lane's 16 channels (accumulator order) of pixel offset o (-1: none) from an NHWC tensor; cbase = first channel of the tile
-template <typename T>
-__device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o, int cbase, int h, int Cout, float (&v)[16]) {
-    if constexpr (sizeof(T) == 2) {
-        uint4 c[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int cb = cbase + 16 * q + 8 * h;
-            c[q] = (o >= 0 && cb < Cout) ? *reinterpret_cast<const uint4*>(base + o + cb) : make_uint4(0, 0, 0, 0);
-            half_swap(c[q].x, c[q].z);
-            half_swap(c[q].y, c[q].w);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned w0 = (k & 1) ? c[k >> 1].z : c[k >> 1].x, w1 = (k & 1) ? c[k >> 1].w : c[k >> 1].y;
-            v[4 * k + 0] = H16<T>::lo(w0);
-            v[4 * k + 1] = H16<T>::hi(w0);
-            v[4 * k + 2] = H16<T>::lo(w1);
-            v[4 * k + 3] = H16<T>::hi(w1);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cb = cbase + 8 * k + 4 * h;
-            const float4 f = (o >= 0 && cb < Cout) ? *reinterpret_cast<const float4*>(base + o + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[4 * k + 0] = f.x;
-            v[4 * k + 1] = f.y;
-            v[4 * k + 2] = f.z;
-            v[4 * k + 3] = f.w;
-        }
-    }
-}
-template <typename T>
-__device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int cbase, int h, int Cout, const float (&v)[16]) {
-    if constexpr (sizeof(T) == 2) {
-        unsigned w[4][2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            w[k][0] = pack16x2<T>(v[4 * k + 0], v[4 * k + 1]);
-            w[k][1] = pack16x2<T>(v[4 * k + 2], v[4 * k + 3]);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            half_swap(w[2 * q][0], w[2 * q + 1][0]);
-            half_swap(w[2 * q][1], w[2 * q + 1][1]);
-            const int cb = cbase + 16 * q + 8 * h;
-            if (o >= 0 && cb < Cout) *reinterpret_cast<uint4*>(base + o + cb) = make_uint4(w[2 * q][0], w[2 * q][1], w[2 * q + 1][0], w[2 * q + 1][1]);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cb = cbase + 8 * k + 4 * h;
-            if (o >= 0 && cb < Cout) *reinterpret_cast<float4*>(base + o + cb) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-        }
-    }
-}
-// activation / activation-gradient on one 16-value tile: the (workgroup-uniform) kind is switched ONCE per tile
-__device__ __forceinline__ void act16(float (&v)[16], int act) {
-    if (act == FALNET_ACT_ELU) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = v[j] > 0.f ? v[j] : (__expf(v[j]) - 1.f);
-    } else if (act == FALNET_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-}
-__device__ __forceinline__ void actgrad16(float (&v)[16], const float (&y)[16], int kind) {
-    if (kind == FALNET_ACT_ELU) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] *= y[j] > 0.f ? 1.f : y[j] + 1.f;
-    } else if (kind == FALNET_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
-    }
-}
-// bias of this lane's 16 channels per 32-channel tile (accumulator order)
-template <int NT>
-__device__ __forceinline__ void load_bias16(const falnet_conv_t& p, int nbase, int h, float (&bias)[NT][16]) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int c = nbase + nt * 32 + 8 * (j >> 2) + 4 * h + (j & 3);
-            bias[nt][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
-        }
-}
-__device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-// PixOff(mt) -> element offset of channel 0 of this lane's pixel in slab mt (or -1); PoolOff(mt) (odd mt, even column)
-// -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
-template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool>
-__device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
-                                                PixOff pixoff, PoolOff pooloff = PoolOff()) {
-    constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
-    const int h = lane >> 5;
-    const T* addend = reinterpret_cast<const T*>(p.addend);
-    const T* actout = reinterpret_cast<const T*>(p.actout);
-    T* out = reinterpret_cast<T*>(p.out);
-    T* pool_out = reinterpret_cast<T*>(p.pool_out);
-    const bool pooling = POOL && pool_out != nullptr;
-    const bool psum = p.pool_mode == 1;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int cbase = nbase + nt * 32;
-        float hp[16];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int64_t o = pixoff(mt);
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
-            if (addend) {  // workgroup-uniform branches: the half swaps inside need every lane
-                float a[16];
-                tile_load<T>(addend, o, cbase, h, p.Cout, a);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] += a[j];
-            }
-            act16(v, p.act);
-            if (actout) {
-                float a[16];
-                tile_load<T>(actout, o, cbase, h, p.Cout, a);
-                actgrad16(v, a, p.actout_kind);
-            }
-            if (p.out_layout == FALNET_OUT_PLANAR_F32) {
-                // planar f32 [B][Cout][OH][OW] (the MED logits): o = offset of channel 0 of this lane's pixel, channel stride
-                // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
-                float* po = reinterpret_cast<float*>(p.out);
-                const int64_t cs = (int64_t)p.OH * p.OW;
-                if (o >= 0) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
-                        if (c < p.Cout) po[o + c * cs] = v[j];
-                    }
-                }
-            } else if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
-            if constexpr (POOL) {
-                if (pooling) {
-                    float m[16];
-                    if (psum) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) m[j] = v[j] + lane_xor1(v[j]);  // column neighbour (same half, same row)
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) m[j] = fmaxf(v[j], lane_xor1(v[j]));
-                    }
-                    if ((mt & 1) == 0) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) hp[j] = m[j];
-                    } else {
-                        if (psum) {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) m[j] += hp[j];
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) m[j] = fmaxf(m[j], hp[j]);
-                        }
-                        const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
-                        if (p.pool_actout) {
-                            float a[16];
-                            tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
-                            actgrad16(m, a, p.pool_actout_kind);
-                        }
-                        tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
-                    }
-                }
-            }
-        }
     }
 }
 
@@ -2543,6 +2344,9 @@ static bool g_disable_patch = [] { const char* e = getenv("FALNET_DISABLE_PATCH"
 static int g_patch_kcb = [] { const char* e = getenv("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
 
 
+bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // conv_dma.hip
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st);
+
 static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     int ctot = 0;
@@ -2579,7 +2383,18 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG(variant >= 0 && variant <= 10, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13, "conv2d: unknown variant %d", variant);
+    if (variant == 13) {  // LDS-DMA, double-buffered, persistent: 16x32 positions x 64 channels per workgroup (conv_dma.hip)
+        if (!(dense3x3 && falnet_conv_dma_applicable(p))) {
+            falnet_set_error("conv2d: variant 13 needs a 16-bit dense 3x3 stride-1 launch (>= 16 x 32 positions) with sources at the launch size or half of it");
+            return -2;
+        }
+        c.flip = flip;
+        c.swap = 0;
+        c.patch = 3;
+        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = 16; c.nwaves = 8;
+        return 0;
+    }
     if (variant == 10) {
         // weight-stationary persistent kernel: every K chunk of a BN-channel weight slice stays in LDS
         bool ok = dense3x3 && ctot * esz <= 128 && ctot * esz % 64 == 0 && p.src[0].C * esz % 64 == 0;
@@ -2646,7 +2461,9 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 2)
+    if (c.patch == 3)
+        snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
+    else if (c.patch == 2)
         snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb);
     else if (c.patch)
         snprintf(buf, len, "_Z20conv3x3_patch_kernelI%sLi%dELi%dELi%dELb%dELi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, c.tps, c.adb, c.th, c.nwaves);
@@ -2680,6 +2497,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st);
     if (c.patch == 2) {
         const int ws_th = c.bn == 64 ? 8 : 16;
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;

@@ -1,0 +1,276 @@
+// Dense 3x3 / stride-1 convolution (forward, stride-1 data gradient; fused nearest-2x upsample and two-source concat), 16-bit
+// operands, 64 output channels per workgroup -- LDS-DMA, double-buffered, persistent.
+//
+// Replaces, where the plan's autotuner finds it faster, the single-stage halo-patch kernel (conv3x3_patch_kernel<.., 64, 64, 9, ..>)
+// of the cuDNN call sites models/FAL_netB.py:38-58,145-173 and loss_functions.py:21-29.  That kernel stages a K chunk
+// (32 input channels: the (TH+2) x 34 halo patch and the nine 64 x 32 weight tiles, 59-76 KB) through REGISTERS with one
+// exposed memory round trip per chunk, and relies on a second resident workgroup to cover it: the matrix pipe idles half the
+// time (585 TFLOP/s).  Here
+//   * a chunk arrives by LDS-DMA (global_load_lds_dwordx4, 1-KiB pieces, no VGPR staging, no ds_write) into one of TWO LDS
+//     buffers: chunk i+1 is requested right after the barrier that publishes chunk i and lands behind chunk i's 72 MFMAs per
+//     wave; ONE barrier per chunk;
+//   * the workgroup is persistent (one per CU: 150 KB of LDS) and walks (tile, chunk) pairs as one flat sequence, so the
+//     first chunk of the next tile is in flight during the last chunk -- and the epilogue -- of the current one: no exposed
+//     prologue per 16x32 block;
+//   * 16 x 32 output positions x 64 channels per workgroup, 8 waves (two 32-position rows x two 32-channel tiles each): the
+//     nine weight tiles are fetched once per 512 positions.
+// LDS image: 64-B rows ([pixel][32 ch] / [tap][cout][32 ch]) exactly as the DMA writes them; the four 16-B segments of row r
+// are XOR-swizzled with (r >> 2) & 3 on the SOURCE address (the DMA destination is lane-linear), which makes every
+// ds_read_b128 fragment read conflict-free for any row base (its 16-lane groups cover all 16 residues of r mod 16).
+// MFMA operands are exchanged (A = weights, B = pixels): the pixel sits on the lane, epilogue_direct (conv_epilogue.h) writes
+// 16-B stores with bias / residual / activation / activation-gradient / 2x2 pooling fused.
+#include <stdlib.h>
+#include "conv_epilogue.h"
+
+// 32 KiB of zeros: the 'pixel' / 'weight row' every out-of-image or out-of-range 16-B piece is fetched from.  Invalid lanes carry
+// the OFFSET of this page relative to their tensor, so a piece's address is always base + offset (+ channel offset < 16 K
+// elements): no compare / select per piece and chunk.
+#define CD_ZERO_BYTES 32768
+__device__ uint4 g_cd_zero[CD_ZERO_BYTES / 16] = {};
+
+typedef __attribute__((address_space(3))) void* cd_lptr_t;
+
+// one 1-KiB LDS-DMA piece (inline asm: outside hipcc's LDS-DMA alias tracking, which would drain the prefetch with
+// s_waitcnt vmcnt(0) in front of every fragment read; see wgrad_rows.hip)
+__device__ __forceinline__ void cd_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+#define CD_PW 34  // patch columns: 32 + the +-1 halo
+
+template <typename T, int TH, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
+    constexpr int BN = 64, MT = TH / NWAVES, NT = BN / 32;
+    static_assert(MT == 2 && sizeof(T) == 2, "two 32-position rows per wave, 16-bit operands");
+    constexpr int KCV = 32;                                   // input channels per chunk (64 B per pixel / weight row)
+    constexpr int NPIX = (TH + 2) * CD_PW;
+    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+
+    // ---- K walk: chunks over (source, channel offset) ----
+    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
+    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
+    const int nchunks = (C0 + C1) / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    // ---- DMA geometry of this lane: (row of a 16-row piece, 16-B segment position); the segment it FETCHES is swizzled ----
+    // Patch pieces a = wave + NWAVES k and weight pieces w = wave + NWAVES k (k < KP) belong to this wave.  Everything
+    // lane-dependent is computed ONCE per tile (patch: element offset per source, -1 = zero fill) or once per kernel (weights):
+    // a chunk then costs one 64-bit add and one select per piece (PMC of the first version: 7 VALU + 5 SALU per MFMA, most of
+    // them address arithmetic of this loop).
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l4 = lane >> 2, segpos = lane & 3;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    int64_t w_off[KW];  // element offsets from the packed weight (rows beyond w_rows: the zero page)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int tap = wid >> 2, co = n0 + ((wid & 3) << 4) + l4;  // four 16-row pieces per tap tile
+        const int gseg = segpos ^ ((lane >> 4) & 3);                 // (row >> 2) & 3 = (l4 >> 2) & 3: pieces start at multiples of 16
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    int64_t a_off[KP];  // of the issue cursor's (tile, source), from the sample's base: recomputed when either changes (twice per tile at most)
+    const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
+    int64_t sbat[2] = {0, 0};  // sample offset of the issue cursor's tile, per source
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile, int s2) {  // patch offsets of the issue cursor's (tile, source)
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
+        sbat[s2] = (int64_t)b * S.sb;
+        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int pix = 16 * (wave + NWAVES * k) + l4;
+            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
+            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
+            a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8)
+                          : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+        }
+    };
+    struct Cur { int tile, c, s, c0, kofs; };      // issue cursor: tile, chunk, source, channel offset, weight-row offset
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            return;
+        }
+        q.c0 += KCV;
+        q.kofs += KCV;
+        if (q.s == 0 && q.c0 >= C0) {
+            q.s = 1;
+            q.c0 = 0;
+            tile_offsets(q.tile, 1);
+        }
+    };
+    auto issue = [&](const Cur& q, int buf) {
+        const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+        const T* wbase = wptr + q.kofs;
+        const unsigned dst0 = lds_base + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int id = wave + NWAVES * k;
+            if (id < A_PIECES) {  // wave-uniform
+                cd_glds16(sbase + a_off[k], dst0 + id * 1024);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int wid = wave + NWAVES * k;
+            if (wid < B_PIECES)
+                cd_glds16(wbase + w_off[k], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+
+    // ---- fragment read addresses (bytes inside a buffer): pixel rows  p = (2 wave + mt + dy) * 34 + dx + r ----
+    int a_addr[4][3];  // k-step 0; k-step 1 is the same address with bit 5 flipped (segment (2 ks + h) ^ q)
+#pragma unroll
+    for (int rs = 0; rs < 4; ++rs)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int pp = (wave * MT + rs) * CD_PW + dx + r;
+            a_addr[rs][dx] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
+        }
+    int b_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_lane[ks] = A_BYTES + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile, 0);
+        issue(qi, 0);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;  // compute cursor
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own pieces of chunk `it` landed; own reads of chunk it-1 done
+        __builtin_amdgcn_s_barrier();                                // chunk `it` complete for every wave; buffer (it+1)&1 is free
+        if (it + 1 < total) {
+            issue(qi, (it + 1) & 1);
+            advance(qi);
+        }
+        // fragment bases of this chunk's buffer: ONE add per lane address (hipcc otherwise keeps every (address + tap offset)
+        // of both buffers in registers -- ~70 VGPRs of loop-invariant sums -- and spills)
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[4][3], bb[2];
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) aa[rs][dx] = a_addr[rs][dx] + bo;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bb[ks] = b_lane[ks] + bo;
+        // 18 steps (tap, 16-channel half): the fragment reads of step i + 1 are issued in front of the four MFMAs of step i (two
+        // register sets); sched_group_barrier pins that order -- left alone, hipcc hoists a dozen steps of reads and spills
+        s16x8_t fa[2][MT], fb[2][NT];
+        auto load_step = [&](int st, int set) {
+            const int t = st >> 1, ks = st & 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const s16x8_t*>(Bf + (aa[mt + t / 3][t % 3] ^ (ks << 5)));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const s16x8_t*>(Bf + bb[ks] + (t * BN + nt * 32) * 64);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<T>::mma(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads of the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
+        }
+        if (++cc == nchunks) {  // tile finished: epilogue straight from the accumulators, then the next tile starts from zero
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            const int x = tx0 + r;
+            const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
+            auto pixoff = [&](int mt) -> int64_t {
+                const int y = ty0 + wave * MT + mt;
+                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+            };
+            auto pooloff = [&](int mt) -> int64_t {
+                const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+            };
+            float bias[NT][16];  // (loaded per tile: 32 registers that would otherwise stay live across the MFMA loop)
+            load_bias16<NT>(p, n0, h, bias);
+            epilogue_direct<T, MT, NT>(p, acc, bias, n0, lane, pixoff, pooloff);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+        }
+    }
+}
+
+// dense 3x3 stride-1 launch in bf16 / f16 with 32-channel-granular sources at the launch size or exactly half of it (the
+// caller has verified the canonical tap order and passes flip)
+bool falnet_conv_dma_applicable(const falnet_conv_t& p) {
+    // (32-bit element offsets inside a sample / the packed weight)
+    for (int s = 0; s < p.nsrc; ++s)
+        if ((int64_t)p.src[s].H * p.src[s].sy >= (1ll << 31)) return false;
+    if ((int64_t)p.w_rows * p.w_taps * p.cin_total >= (1ll << 31)) return false;
+    if ((p.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;  // the zero page must cover one row of channels
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.nsrc < 1 || p.nsrc > 2 || p.w_taps != 9 || p.OH < 16 || p.OW < 32) return false;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const falnet_src_t& S = p.src[s];
+        if (S.C % 32 || S.C <= 0) return false;
+        if (!((S.H == p.IH || 2 * S.H == p.IH) && (S.W == p.IW || 2 * S.W == p.IW))) return false;
+    }
+    return true;
+}
+
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
+    constexpr int TH = 16;
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + TH - 1) / TH;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 63) / 64;
+    int gx = 256 / ny;  // one persistent workgroup per CU (150 KB of LDS each)
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+    if (p.dtype == FALNET_F16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<f16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<bf16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+    FALNET_RETURN_LAUNCH();
+}

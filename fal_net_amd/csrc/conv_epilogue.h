@@ -1,0 +1,207 @@
+// Direct (register) epilogue of the kernels that keep the PIXEL on the lane (MFMA operands exchanged: A = weights, B = pixels):
+// shared by conv.hip (halo-patch, weight-stationary, first-layer kernels) and conv_dma.hip.
+#pragma once
+#include <type_traits>
+#include "common.h"
+
+typedef f32x16_t f32x16;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == FALNET_ACT_ELU) return v > 0.f ? v : (__expf(v) - 1.f);
+    if (act == FALNET_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+__device__ __forceinline__ float act_grad_from_out(float y, int kind) {
+    if (kind == FALNET_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (kind == FALNET_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+
+struct NoPool { static constexpr bool enabled = false; __device__ int64_t operator()(int, int) const { return -1; } };
+
+// ---- direct epilogue (halo-patch and first-layer kernels) ---------------------------------------------------------
+// With the MFMA operands exchanged (A = weights, B = pixels) the 32x32 C/D tile puts one PIXEL on each lane and sixteen
+// channels in its accumulators: acc[j] = channel 8*(j>>2) + 4*h + (j&3) of the tile, i.e. four groups of four consecutive
+// channels, lane halves h = 0/1 interleaved.  f32: every group is one 16-B store.  bf16: a group is 8 B; one
+// v_permlane32_swap per dword exchanges the upper half's group k with the lower half's group k+1, after which lanes 0-31
+// hold channels 8k..8k+7 and lanes 32-63 channels 8k+8..8k+15 of their pixel: one 16-B store per group pair
+// (cdna_hip_programming.md T21).  No LDS staging, no wave barriers; residual / activation-output operands are read in
+// the same 16-B chunks and un-swapped with the same (involutive) exchange.
+__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b) {  // lanes 32-63 of a <-> lanes 0-31 of b
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// this lane's 16 channels (accumulator order) of pixel offset o (-1: none) from an NHWC tensor; cbase = first channel of the tile
+template <typename T>
+__device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o, int cbase, int h, int Cout, float (&v)[16]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 c[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int cb = cbase + 16 * q + 8 * h;
+            c[q] = (o >= 0 && cb < Cout) ? *reinterpret_cast<const uint4*>(base + o + cb) : make_uint4(0, 0, 0, 0);
+            half_swap(c[q].x, c[q].z);
+            half_swap(c[q].y, c[q].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned w0 = (k & 1) ? c[k >> 1].z : c[k >> 1].x, w1 = (k & 1) ? c[k >> 1].w : c[k >> 1].y;
+            v[4 * k + 0] = H16<T>::lo(w0);
+            v[4 * k + 1] = H16<T>::hi(w0);
+            v[4 * k + 2] = H16<T>::lo(w1);
+            v[4 * k + 3] = H16<T>::hi(w1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cbase + 8 * k + 4 * h;
+            const float4 f = (o >= 0 && cb < Cout) ? *reinterpret_cast<const float4*>(base + o + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[4 * k + 0] = f.x;
+            v[4 * k + 1] = f.y;
+            v[4 * k + 2] = f.z;
+            v[4 * k + 3] = f.w;
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int cbase, int h, int Cout, const float (&v)[16]) {
+    if constexpr (sizeof(T) == 2) {
+        unsigned w[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[k][0] = pack16x2<T>(v[4 * k + 0], v[4 * k + 1]);
+            w[k][1] = pack16x2<T>(v[4 * k + 2], v[4 * k + 3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half_swap(w[2 * q][0], w[2 * q + 1][0]);
+            half_swap(w[2 * q][1], w[2 * q + 1][1]);
+            const int cb = cbase + 16 * q + 8 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<uint4*>(base + o + cb) = make_uint4(w[2 * q][0], w[2 * q][1], w[2 * q + 1][0], w[2 * q + 1][1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cbase + 8 * k + 4 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<float4*>(base + o + cb) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+    }
+}
+// activation / activation-gradient on one 16-value tile: the (workgroup-uniform) kind is switched ONCE per tile
+__device__ __forceinline__ void act16(float (&v)[16], int act) {
+    if (act == FALNET_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = v[j] > 0.f ? v[j] : (__expf(v[j]) - 1.f);
+    } else if (act == FALNET_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+}
+__device__ __forceinline__ void actgrad16(float (&v)[16], const float (&y)[16], int kind) {
+    if (kind == FALNET_ACT_ELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= y[j] > 0.f ? 1.f : y[j] + 1.f;
+    } else if (kind == FALNET_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+    }
+}
+// bias of this lane's 16 channels per 32-channel tile (accumulator order)
+template <int NT>
+__device__ __forceinline__ void load_bias16(const falnet_conv_t& p, int nbase, int h, float (&bias)[NT][16]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c = nbase + nt * 32 + 8 * (j >> 2) + 4 * h + (j & 3);
+            bias[nt][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+        }
+}
+__device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// PixOff(mt) -> element offset of channel 0 of this lane's pixel in slab mt (or -1); PoolOff(mt) (odd mt, even column)
+// -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool>
+__device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
+                                                PixOff pixoff, PoolOff pooloff = PoolOff()) {
+    constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
+    const int h = lane >> 5;
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    T* out = reinterpret_cast<T*>(p.out);
+    T* pool_out = reinterpret_cast<T*>(p.pool_out);
+    const bool pooling = POOL && pool_out != nullptr;
+    const bool psum = p.pool_mode == 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cbase = nbase + nt * 32;
+        float hp[16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t o = pixoff(mt);
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
+            if (addend) {  // workgroup-uniform branches: the half swaps inside need every lane
+                float a[16];
+                tile_load<T>(addend, o, cbase, h, p.Cout, a);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] += a[j];
+            }
+            act16(v, p.act);
+            if (actout) {
+                float a[16];
+                tile_load<T>(actout, o, cbase, h, p.Cout, a);
+                actgrad16(v, a, p.actout_kind);
+            }
+            if (p.out_layout == FALNET_OUT_PLANAR_F32) {
+                // planar f32 [B][Cout][OH][OW] (the MED logits): o = offset of channel 0 of this lane's pixel, channel stride
+                // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
+                float* po = reinterpret_cast<float*>(p.out);
+                const int64_t cs = (int64_t)p.OH * p.OW;
+                if (o >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
+                        if (c < p.Cout) po[o + c * cs] = v[j];
+                    }
+                }
+            } else if (!POOL || out) tile_store<T>(out, o, cbase, h, p.Cout, v);
+            if constexpr (POOL) {
+                if (pooling) {
+                    float m[16];
+                    if (psum) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) m[j] = v[j] + lane_xor1(v[j]);  // column neighbour (same half, same row)
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) m[j] = fmaxf(v[j], lane_xor1(v[j]));
+                    }
+                    if ((mt & 1) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) hp[j] = m[j];
+                    } else {
+                        if (psum) {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m[j] += hp[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) m[j] = fmaxf(m[j], hp[j]);
+                        }
+                        const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
+                        if (p.pool_actout) {
+                            float a[16];
+                            tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
+                            actgrad16(m, a, p.pool_actout_kind);
+                        }
+                        tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
+                    }
+                }
+            }
+        }
+    }
+}
+

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
 
 struct Wr8Item { int u, n, T, t, b, x0, y0; };  // rows [y0, y0+n) of strip x0 of sample b; t = step inside it (two rows per step)
 
-template <typename T, int D, int ABL = 0, bool STAGGER = true>
+template <typename T, int D, int ABL = 0, bool STAGGER = true, bool ILV = true>
 __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
     constexpr int NS = D + 1;
     static_assert(D >= 1 && D <= 3, "prefetch distance");
@@ -411,17 +411,28 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
         x4ptr = x4_ok ? reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)(xb >> l_ws) * l_sx) : zero_page;
         x4_inc = x4_ok ? xi : 0u;
     };
-    auto issue = [&](const Wr8Item& c, int slot) {
+    auto issue_piece = [&](const Wr8Item& c, int slot, int k) {  // k = 0 gout row, 1 input row, 2 the input row's two halo pixels
         const unsigned base = lds_base + slot * WR8_SLOT;
-        const bool gv = 2 * c.t + rsel < c.n;                    // gout row inside the item
+        if (k == 0) {
+            const bool gv = 2 * c.t + rsel < c.n;                    // gout row inside the item
+            wr_glds16(gv ? gptr : zero_page, base + rsel * WR_GROW + pw * 1024);
+            gptr += g_inc;
+            return;
+        }
         const int i = c.y0 - 1 + 2 * c.t + rsel;
-        const bool xv = i >= 0 && i < IH;                         // input row inside the image
-        wr_glds16(gv ? gptr : zero_page, base + rsel * WR_GROW + pw * 1024);
-        wr_glds16(xv ? xptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + pw * 1024);
-        if (pw == 0) wr_glds16(xv ? x4ptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + 4 * 1024);
-        gptr += g_inc;
-        xptr += x_inc;
-        x4ptr += x4_inc;
+        const bool xv = i >= 0 && i < IH;                             // input row inside the image
+        if (k == 1) {
+            wr_glds16(xv ? xptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + pw * 1024);
+            xptr += x_inc;
+        } else if (pw == 0) {
+            wr_glds16(xv ? x4ptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + 4 * 1024);
+            x4ptr += x4_inc;
+        }
+    };
+    auto issue = [&](const Wr8Item& c, int slot) {
+        issue_piece(c, slot, 0);
+        issue_piece(c, slot, 1);
+        issue_piece(c, slot, 2);
     };
 
     // ---- fragment read geometry ----
@@ -497,15 +508,14 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
     bool m_vx0 = false, m_vx1 = false, m_have = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) n_a[j] = n_b[j] = 0;
-    auto issue_and_read = [&](int g) {  // DMA pieces of step g + D, then this wave's fragments of step g
-        if (ABL != 1 && g + D < nst) {
-            issue(ci_, islot);
-            if (g + D + 1 < nst && ++ci_.t == ci_.T) {
-                load_item(ci_, ci_.u + ci_.n);
-                item_pointers(ci_);
-            }
+    auto advance_issue = [&](int g) {  // the issue cursor moves to step g + D + 1
+        if (g + D + 1 < nst && ++ci_.t == ci_.T) {
+            load_item(ci_, ci_.u + ci_.n);
+            item_pointers(ci_);
         }
-        stamp(2);
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    };
+    auto read_frags = [&](int g) {  // this wave's fragments of step g (and the flags its MFMAs need)
         const char* sb = lds + slot * WR8_SLOT;
         m_t2 = 2 * cc_.t;
         m_n = cc_.n;
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
         m_vx0 = i0 >= 0 && i0 < IH;
         m_vx1 = i0 + 1 >= 0 && i0 + 1 < IH;
         m_have = true;
-        if (ABL == 3) {
+        if (ABL == 3 || ABL == 4) {
             n_a = w_a; n_b = w_b;
             xa[0] = xa[1] = xa[2] = xb[0] = xb[1] = xb[2] = w_a;
         } else {
@@ -528,14 +538,14 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
         }
         if (g + 1 < nst && ++cc_.t == cc_.T) load_item(cc_, cc_.u + cc_.n);
         slot = slot + 1 == NS ? 0 : slot + 1;
-        islot = islot + 1 == NS ? 0 : islot + 1;
         stamp(3);
     };
     for (int g = 0; g <= nst; ++g) {
+        const bool do_issue = ABL != 1 && ABL != 4 && ABL != 5 && g + D < nst;
         if (g < nst) {
             // this wave's pieces of step g have landed once at most k steps' worth of younger pieces are outstanding
             const int k = min(D - 1, nst - 1 - g);
-            if (ABL == 1) {
+            if (ABL == 1 || ABL == 4 || ABL == 5) {
             } else if (pw == 0) {
                 if (k >= 2) wr_vmcnt<(D >= 3 ? 6 : 0)>();
                 else if (k == 1) wr_vmcnt<(D >= 2 ? 3 : 0)>();
@@ -549,51 +559,72 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
             stamp(0);
             __builtin_amdgcn_s_barrier();
             stamp(1);
-            if (!lag) issue_and_read(g);
+            if (!ILV && do_issue && !lag) {  // un-interleaved order: every piece of step g + D before the fragment reads
+                issue(ci_, islot);
+                advance_issue(g);
+            }
+            stamp(2);
+            if (!lag) read_frags(g);
         }
-        if (m_have) {  // the step whose fragments are in registers: g for waves 0-3, g - 1 for the lagging waves 4-7
+        // DMA pieces of step g + D go BETWEEN the MFMA groups (ILV): a piece holds its wave ~150 cycles in issue, which the
+        // matrix pipe spends on the MFMAs issued just before it instead of waiting behind three pieces in a row
+        auto piece = [&](int kk) {
+            if (ILV && do_issue) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(ci_, islot, kk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {  // the step whose fragments are in registers: g for waves 0-3, g - 1 for the lagging waves 4-7
             const int t2 = m_t2;
-            auto vr = [&](int r) { return (unsigned)r < (unsigned)m_n; };
-            if ((ABL < 2 || ABL == 9) && a_live) {  // wave-uniform branches around groups of three MFMAs
-                if (m_vx0) {  // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
-                    if (vr(t2)) {
+            auto vr = [&](int r) { return m_have && (unsigned)r < (unsigned)m_n; };
+            const bool live = (ABL < 2 || ABL == 9 || ABL == 4) && a_live;
+            if (live && m_vx0 && vr(t2)) {  // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_a, xa[dx], acc[0][dx]);
-                    }
-                    if (vr(t2 - 1)) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(w_b, xa[dx], acc[1][dx]);
-                    }
-                    if (vr(t2 - 2)) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_a, xa[dx], acc[2][dx]);
-                    }
-                }
-                if (m_vx1) {  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
-                    if (vr(t2 + 1)) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_b, xb[dx], acc[0][dx]);
-                    }
-                    if (vr(t2)) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(n_a, xb[dx], acc[1][dx]);
-                    }
-                    if (vr(t2 - 1)) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_b, xb[dx], acc[2][dx]);
-                    }
-                }
+                for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_a, xa[dx], acc[0][dx]);
             }
-            if (do_bias) {  // rows outside the item arrive as zeros
+            piece(0);
+            if (live && m_vx0 && vr(t2 - 1)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += Mma16<T>::f32(n_a[j]) + Mma16<T>::f32(n_b[j]);
+                for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(w_b, xa[dx], acc[1][dx]);
             }
-            w_a = n_a;
-            w_b = n_b;
-            m_have = false;
+            if (live && m_vx0 && vr(t2 - 2)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_a, xa[dx], acc[2][dx]);
+            }
+            piece(1);
+            if (live && m_vx1 && vr(t2 + 1)) {  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_b, xb[dx], acc[0][dx]);
+            }
+            if (live && m_vx1 && vr(t2)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(n_a, xb[dx], acc[1][dx]);
+            }
+            piece(2);
+            if (live && m_vx1 && vr(t2 - 1)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_b, xb[dx], acc[2][dx]);
+            }
+            if (ILV && do_issue) advance_issue(g);
+            if (m_have) {
+                if (do_bias) {  // rows outside the item arrive as zeros
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += Mma16<T>::f32(n_a[j]) + Mma16<T>::f32(n_b[j]);
+                }
+                w_a = n_a;
+                w_b = n_b;
+                m_have = false;
+            }
         }
         stamp(4);
-        if (lag && g < nst) issue_and_read(g);
+        if (lag && g < nst) {
+            if (!ILV && do_issue) {
+                issue(ci_, islot);
+                advance_issue(g);
+            }
+            read_frags(g);
+        }
     }
 
     // ---- the two halves' accumulators are summed through LDS: waves 4-7 deposit, waves 0-3 add and write the slab ----
@@ -687,9 +718,13 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
     else if (abl == 2) WR_LAUNCH8(bf16_t, 2, 2);
     else if (abl == 3) WR_LAUNCH8(bf16_t, 2, 3);
     else if (abl == 13) WR_LAUNCH8(bf16_t, 3, 0);
+    else if (abl == 4) WR_LAUNCH8(bf16_t, 2, 4);
+    else if (abl == 5) WR_LAUNCH8(bf16_t, 2, 5);
     else if (abl == 9) WR_LAUNCH8(bf16_t, 2, 9);
-    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else if (abl == 29) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 9, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else if (abl == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, true, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else if (abl == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, true>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else if (abl == 29) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 9, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
     else WR_LAUNCH8(bf16_t, 2, 0);
     FALNET_RETURN_LAUNCH();
 }

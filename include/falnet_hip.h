@@ -100,6 +100,8 @@ typedef struct {
                                   6/7 = 3/4 on a 16x32-position block with 8 waves, 8/9 = 3/4 on a 4x32 block;
                                   10 weight-stationary persistent kernel (<= 128 B of input channels per pixel);
                                   11 / 12 gather with 32 / 64 output channels per workgroup (more workgroups for small layers);
+                                  13 LDS-DMA double-buffered persistent kernel (16-bit operands, 16x32 positions x 64 channels per
+                                  workgroup, sources at the launch size or exactly half of it);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

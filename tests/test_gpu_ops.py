@@ -173,7 +173,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 13):  # 11 / 12: gather with 32 / 64 output channels per workgroup
+    for variant in range(1, 14):  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -184,6 +184,7 @@ def test_conv_every_kernel_variant(case, dtype):
         assert rel(got, ref) < TOL[dtype], variant
         ran.append(variant)
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
+    assert (13 in ran) == (dtype != torch.float32 and H >= 16)
     assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
 
 
@@ -208,7 +209,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 11):
+    for variant in list(range(1, 11)) + [13]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         if out is not None:
@@ -250,7 +251,7 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 11):
+    for variant in list(range(1, 11)) + [13]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
