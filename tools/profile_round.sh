@@ -11,3 +11,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $BENCH > $out/fe
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $BENCH > $out/write.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 tools/summarize_profile.py $out $tag
+mkdir -p gpurun_out/profiles && cp profiles/${tag}_* gpurun_out/profiles/
