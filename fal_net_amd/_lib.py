@@ -112,6 +112,7 @@ SIGNATURES = {
     "falnet_rowmax": [_P, _P, _I, _L, _P],
     "falnet_gemm_f32_small": [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _P],
     "falnet_resize_planar": [_P, _P, _L, _I, _I, _I, _I, _I, _F, _P],
+    "falnet_disp_prologue": [_P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
     "falnet_occlusion_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_mirror_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
 }

@@ -348,3 +348,27 @@ extern "C" int falnet_resize_planar(const float* src, float* dst, int64_t planes
     hipLaunchKernelGGL(resize_planar_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, bilinear, scale, total);
     FALNET_RETURN_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------- disparity-range prologue
+// Per-sample scalars of one step in ONE launch (Train_Stage1_K.py:237, FAL_netB.py:208-209): min_disp = max_disp * mul / div,
+// the plan's copies of both, and the constant `flow` input plane max_disp / 100 in the compute dtype.
+template <typename T>
+__global__ void disp_prologue_kernel(const float* __restrict__ max_disp, const float* __restrict__ min_disp, float mul, float div,
+                                     float* __restrict__ min_out, float* __restrict__ max_out, T* __restrict__ flow, int flow_stride, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float mx = max_disp[b];
+    min_out[b] = min_disp ? min_disp[b] : mx * mul / div;
+    max_out[b] = mx;
+    flow[(int64_t)b * flow_stride] = from_f32<T>(mx / 100.0f);
+}
+
+extern "C" int falnet_disp_prologue(const float* max_disp, const float* min_disp, float mul, float div, float* min_out, float* max_out,
+                                    void* flow, int flow_stride, int B, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(max_disp && min_out && max_out && flow && B > 0 && flow_stride > 0 && (min_disp || div != 0.0f), "disp_prologue: bad argument");
+#define EW_L(T) hipLaunchKernelGGL(disp_prologue_kernel<T>, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, max_disp, min_disp, mul, div, min_out, max_out, (T*)flow, flow_stride, B)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
+    FALNET_RETURN_LAUNCH();
+}

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
     const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
     const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
     const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,
-    OUT* __restrict__ gdlog0, int N, int H, int W, int cpad) {
+    OUT* __restrict__ gdlog0, int N, int H, int W, int cpad, int pair) {
     static_assert(CH == 8, "one chunk = one 8-channel store");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PlaneTab& tab = *reinterpret_cast<PlaneTab*>(smem);
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
         }
     };
     if (vec4) fetch(0);
+    uint4 held[PPT];
     for (int n0 = 0; n0 < cpad; n0 += CH) {
         __syncthreads();  // previous chunk fully consumed (and tab / rows ready)
         if (n0 < N) {
@@ -531,6 +532,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
             const int x = threadIdx.x + q * HEAD_THREADS;
             if (x >= W) continue;
             float gv[8];
+            // 16-bit output: a chunk is 16 B per pixel -- half a 32-B sector.  Stored chunk by chunk, the 8 pieces of a pixel's 128-B
+            // line reach L2 microseconds apart and many are evicted half-written (WRITE_SIZE was 2x the tensor).  Even chunks are
+            // therefore held (packed, 4 registers per pixel) and written together with the odd chunk that completes their sector.
+            constexpr bool PAIR = sizeof(OUT) == 2;
+            const bool second = ((n0 / CH) & 1) != 0;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const int n = n0 + j;
@@ -563,7 +569,20 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_head_bwd_lds_kernel(
                 }
                 gv[j] = g;
             }
-            store8(Grow + (int64_t)x * cpad + n0, gv);
+            if constexpr (PAIR) {
+                uint4 pk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) (&pk.x)[i] = pack16x2<OUT>(gv[2 * i], gv[2 * i + 1]);
+                if (!second && n0 + CH < cpad && pair) held[q] = pk;
+                else if (!second || !pair) *reinterpret_cast<uint4*>(Grow + (int64_t)x * cpad + n0) = pk;  // odd number of chunks: last one alone
+                else {
+                    uint4* dst = reinterpret_cast<uint4*>(Grow + (int64_t)x * cpad + n0 - CH);
+                    dst[0] = held[q];
+                    dst[1] = pk;
+                }
+            } else {
+                store8(Grow + (int64_t)x * cpad + n0, gv);
+            }
         }
     }
 }
@@ -669,6 +688,19 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_maskr_acfalse_kernel(
 // FALNET_HEAD_V1=1: first forward kernel (per-lane global taps) instead of the LDS-staged one (A/B, tests)
 static const bool g_head_v1 = [] { const char* e = getenv("FALNET_HEAD_V1"); return e && e[0] == '1'; }();
 
+// wave-neighbour kernels (med_head2.hip)
+bool falnet_head_wave_applicable(int W);
+void falnet_head_fwd_wave_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
+                               float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream);
+bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
+                                 float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream);
+bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, const float* disp,
+                                 const float* p_im0, const float* stats, const float* gdisp, const float* gpan, void* gdlog0, int cpad,
+                                 int dtype, int B, int N, int H, int W, hipStream_t stream);
+void falnet_head_bwd_wave_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, const float* disp,
+                               const float* p_im0, const float* stats, const float* gdisp, const float* gpan, void* gdlog0, int cpad,
+                               int dtype, int B, int N, int H, int W, hipStream_t stream);
+
 static int check_head(int B, int N, int H, int W) {
     FALNET_CHECK_ARG(B > 0 && H > 0 && W > 0, "med_head: empty shape B=%d H=%d W=%d", B, H, W);
     FALNET_CHECK_ARG(N >= 2 && N <= HEAD_MAXN, "med_head: N=%d outside [2,%d]", N, HEAD_MAXN);
@@ -683,6 +715,14 @@ extern "C" int falnet_med_head_fwd(const float* dlog0, const float* left, const 
     if (int r = check_head(B, N, H, W)) return r;
     FALNET_CHECK_ARG(dlog0 && min_disp && max_disp, "med_head_fwd: null input");
     FALNET_CHECK_ARG(!p_im0 || left, "med_head_fwd: p_im0 requested without left image");
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!g_head_v1 && al16(dlog0) && al16(left) &&
+        falnet_head_fwd_lds2_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, B, N, H, W, (hipStream_t)stream))
+        FALNET_RETURN_LAUNCH();
+    if (!g_head_v1 && W > 1024 && falnet_head_wave_applicable(W) && al16(dlog0) && al16(left) && al16(disp) && al16(p_im0) && al16(stats)) {
+        falnet_head_fwd_wave_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, B, N, H, W, (hipStream_t)stream);
+        FALNET_RETURN_LAUNCH();
+    }
     const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
     const size_t WP = (size_t)((W + 7) & ~3);
     const size_t lds2 = sizeof(PlaneTab) + (3 + CH) * WP * sizeof(float);
@@ -737,11 +777,23 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16 || dtype == FALNET_F16, "med_head_bwd_nhwc: bad dtype %d", dtype);
     const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
     static const bool v1 = [] { const char* e = getenv("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
+    static const int pair = [] { const char* e = getenv("FALNET_HEAD_PAIR"); return (e && e[0] == '0') ? 0 : 1; }();
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!v1 && al16(dlog0) && al16(grad_dlog0_nhwc) &&
+        falnet_head_bwd_lds2_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0_nhwc, cpad, dtype, B, N, H,
+                                    W, (hipStream_t)stream))
+        FALNET_RETURN_LAUNCH();
+    if (!v1 && W > 1024 && falnet_head_wave_applicable(W) && al16(dlog0) && al16(left) && al16(disp) && al16(p_im0) && al16(stats) && al16(grad_disp) &&
+        al16(grad_p_im0) && al16(grad_dlog0_nhwc)) {
+        falnet_head_bwd_wave_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0_nhwc, cpad, dtype, B, N,
+                                  H, W, (hipStream_t)stream);
+        FALNET_RETURN_LAUNCH();
+    }
     if (!v1 && W <= 4 * HEAD_THREADS) {  // LDS-staged plane rows
         const size_t lds2 = (lds + 15) / 16 * 16 + (size_t)CH * ((W + 11) & ~3) * sizeof(float);
 #define LAUNCH_BWD_LDS(T, P)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_lds_kernel<T, P>), dim3(B * H), dim3(HEAD_THREADS), lds2, (hipStream_t)stream, dlog0, left, \
-                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (T*)grad_dlog0_nhwc, N, H, W, cpad)
+                       min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, (T*)grad_dlog0_nhwc, N, H, W, cpad, pair)
         const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
 #define BWD_LDS_T(T) if (ppt <= 1) LAUNCH_BWD_LDS(T, 1); else if (ppt == 2) LAUNCH_BWD_LDS(T, 2); else LAUNCH_BWD_LDS(T, 4)
         FALNET_DISPATCH_DTYPE(dtype, BWD_LDS_T);

@@ -11,6 +11,7 @@ VGG feature maps are returned as logical NCHW tensors that are channels-last in 
 layout), in the compute dtype.  All reductions are f32.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -25,7 +26,18 @@ _MEAN = (0.411, 0.432, 0.45)
 _SLICES = ((0, 2), (5, 7), (10, 12, 14, 16))
 
 
-_GOUT_OF = {}  # data_ptr of a grad-plan's output map -> that plan's gradient buffer for it
+_GOUT_OF = {}  # data_ptr of a grad-plan's output map -> [that plan's gradient buffer for it, claimed-in-this-backward flag]
+_MAX_HELD_PLANS = 4  # grad-enabled VGG calls per shape whose backward has not run yet; beyond it the oldest plan is recycled
+
+
+def _forget_gouts(keys):
+    for k in keys:
+        _GOUT_OF.pop(k, None)
+
+
+def _release_plan(plan, gen):
+    if plan.gen == gen:
+        plan.busy = False
 
 
 class _VggPlan:
@@ -35,7 +47,7 @@ class _VggPlan:
         """need_grad=False (label features, Train_Stage1_K.py:241-244 under no_grad): the convs in front of a pool keep only
         their pooled map (fused pool, no full-resolution store) and no backward launches are built."""
         self.B, self.H, self.W, self.dtype, self.device = B, H, W, dtype, device
-        self.busy, self.need_grad = False, need_grad
+        self.busy, self.need_grad, self.gen = False, need_grad, 0
         code = L.dtype_code(dtype)
         self.fwd, self.bwd = [], []
         _conv = lambda *a, **kw: ops.conv_call(*a, ws_owner=("vgg", id(self)), **kw)  # own split-K scratch per plan instance
@@ -79,15 +91,16 @@ class _VggPlan:
         # ---- backward: gradients of the three pooled outputs -> gradient of the planar f32 input ----
         self.gouts = [torch.empty_like(o) for o in self.outs]
         for o, g in zip(self.outs, self.gouts):
-            _GOUT_OF[o.data_ptr()] = g  # lets the perceptual loss write d loss / d feature straight into the plan
+            _GOUT_OF[o.data_ptr()] = [g, False]  # lets the perceptual loss write d loss / d feature straight into the plan
+        weakref.finalize(self, _forget_gouts, [o.data_ptr() for o in self.outs])  # a dropped plan leaves no stale entries
         g_next = None  # gradient wrt `cur` of the step being undone (post-pool tensor of the slice below)
         slice_i = len(self.outs) - 1
         for entry in reversed(acts):
             if entry[0] == "pool":
                 _, x, pooled, h, w = entry
-                gy = self.gouts[slice_i]
-                if g_next is not None:  # deeper slices feed back into this pooled output: sum both
-                    self.bwd.append(_axpy_call(gy, g_next))
+                # deeper slices feed back into this pooled output: their data gradient already holds the sum (the conv below
+                # this pool took the slice's own gradient as its epilogue addend), the deepest slice has only its own
+                gy = self.gouts[slice_i] if g_next is None else g_next
                 gx = torch.empty_like(x)  # gradient wrt the pre-ReLU conv output feeding the pool (relu' fused)
                 self.bwd.append(ops.simple_call("falnet_maxpool2_bwd", L.ptr(x), L.ptr(pooled), L.ptr(gy), L.ptr(gx), B, h, w,
                                                 x.shape[3], code))
@@ -107,19 +120,14 @@ class _VggPlan:
                     # but a pooled map's gradient must NOT be masked -> only mask when x came from a conv)
                     from_pool = any(x is o for o in self.outs)
                     gin = torch.empty_like(x)
+                    own = next((g for o, g in zip(self.outs, self.gouts) if x is o), None)  # perceptual gradient of that slice
                     self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
-                                                  pc.cin_pad, 1, B, h, w, gin, h, w, pc.cin_pad, pc.cin_pad,
+                                                  pc.cin_pad, 1, B, h, w, gin, h, w, pc.cin_pad, pc.cin_pad, addend=own,
                                                   actout=None if from_pool else x,
                                                   actout_kind=L.ACT_NONE if from_pool else L.ACT_RELU, name="vgg dgrad",
                                                   flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.keep.append(gin)
                     g_next = gin
-
-
-def _axpy_call(dst, src):
-    def call():
-        dst.add_(src)
-    return call
 
 
 class _VggFunction(torch.autograd.Function):
@@ -128,13 +136,18 @@ class _VggFunction(torch.autograd.Function):
         plan.c3_call.set_input(x)  # the first conv reads the caller's image in place (it is only read during this forward)
         for c in plan.fwd:
             c()
-        ctx.plan, ctx.owner = plan, owner
-        # no clone: the plan (and its output buffers) stays reserved for this call until its backward has run
+        ctx.plan, ctx.owner, ctx.gen = plan, owner, plan.gen
+        # no clone: the plan (and its output buffers) stays reserved for this call until its backward has run -- or until the graph
+        # is dropped without one (validation under grad mode, an exception): the finalizer frees it then
+        weakref.finalize(ctx, _release_plan, plan, plan.gen)
         return tuple(o.permute(0, 3, 1, 2) for o in plan.outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         plan = ctx.plan
+        if plan.gen != ctx.gen:
+            raise RuntimeError(f"this VGG call's plan was recycled: more than {_MAX_HELD_PLANS} grad-enabled vgg() calls of one shape "
+                               "were alive without a backward")
         for buf, g in zip(plan.gouts, gouts):
             if g is None:
                 buf.zero_()
@@ -184,13 +197,17 @@ class Vgg19_pc(nn.Module):
 
     def _plan(self, B, H, W, dtype, device, hold):
         pool = self._plans.setdefault((B, H, W, hold), [])  # hold = the call needs a backward (plan busy until it ran)
-        for p in pool:
-            if not p.busy:
-                p.busy = hold
-                return p
-        p = _VggPlan(self, B, H, W, dtype, device, need_grad=hold)
-        p.busy = hold
-        pool.append(p)
+        p = next((q for q in pool if not q.busy), None)
+        if p is None and hold and len(pool) >= _MAX_HELD_PLANS:
+            p = min(pool, key=lambda q: q.gen)  # bounded HBM: recycle the oldest held plan (its backward, if it ever comes, raises)
+        if p is None:
+            p = _VggPlan(self, B, H, W, dtype, device, need_grad=hold)
+            pool.append(p)
+        self._gen = getattr(self, "_gen", 0) + 1
+        p.busy, p.gen = hold, self._gen
+        if hold:
+            for o in p.outs:
+                _GOUT_OF[o.data_ptr()][1] = False  # nobody has written this call's feature gradients yet
         return p
 
     def forward(self, x, full=False, borrow=False):
@@ -349,8 +366,11 @@ class _PerceptualMse(torch.autograd.Function):
         grads = []
         for i in range(ctx.n):
             an, bn = ctx.saved_tensors[2 * i], ctx.saved_tensors[2 * i + 1]
-            ga = _GOUT_OF.get(an.data_ptr())  # `an` is a VGG plan's output: write into the plan's own gradient buffer
-            if ga is None or ga.shape != an.shape or ga.dtype != an.dtype:
+            slot = _GOUT_OF.get(an.data_ptr())  # `an` is a VGG plan's output: write into the plan's own gradient buffer,
+            ga = None                            # once -- a second loss on the same map gets its own (autograd sums them)
+            if slot is not None and not slot[1] and slot[0].shape == an.shape and slot[0].dtype == an.dtype:
+                ga, slot[1] = slot[0], True
+            if ga is None:
                 ga = torch.empty_like(an)
             B, H, W, Cc = an.shape
             L.check(L.lib().falnet_mse_bwd(L.ptr(an), L.ptr(bn), B * H * W, Cc, ctx.scales[i], L.ptr(gs), L.ptr(ga),

@@ -97,6 +97,10 @@ class BackBone(nn.Module):
                     m.bias.data.zero_()
 
 
+_TAIL_MAIN = "conv1,conv1_1.conv1"  # default of FALNET_TAIL_MAIN (same-box A/B: +0.7 % over level 0 alone)
+_TAIL_LEVELS = int(os.environ.get("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
+
+
 class FalnetPlan:
     """Static launch plan of FAL_net.forward / backward for one (B, H, W, dtype, device)."""
 
@@ -367,7 +371,7 @@ class FalnetPlan:
                                        name="falnet_med_head_bwd", nbytes=(N + 7) * H * W * 4 * B + B * H * W * pad_c(N) * G0.element_size())
             self.head_bwd = {(hd, hp): head_bwd(hd, hp) for hd in (False, True) for hp in (False, True) if hd or hp}
             # Gradient buckets = contiguous ranges of the flat gradient buffer in the order backward completes them:
-            # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: levels 1-3, 3: level 0.  After a bucket's
+            # 0: decoder + logits conv (tail of the buffer), 1: encoder levels 4-6, 2: levels 2-3, 3: levels 0-1.  After a bucket's
             # last wgrad its slab reduce / bias-gradient launches run and model._bucket_ready(i) lets the trainer start that
             # bucket's share of the step's all-reduce while backward continues.
             self._bucket = 0
@@ -433,25 +437,27 @@ class FalnetPlan:
             for i in range(6, -1, -1):
                 if i == 3:
                     self._finish.append((1, len(self.bwd_body)))
-                if i == 0:
+                if i == _TAIL_LEVELS - 1:
                     self._finish.append((2, len(self.bwd_body)))
-                self._bucket = 1 if i >= 4 else (2 if i >= 1 else 3)
+                self._bucket = 1 if i >= 4 else (2 if i >= _TAIL_LEVELS else 3)
                 tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
+                # more weight gradients for the main stream's idle tail (names, comma separated): the side stream is the longer chain
+                extra = os.environ.get("FALNET_TAIL_MAIN", _TAIL_MAIN).split(",") if os.environ.get("FALNET_TAIL_BALANCE", "1") == "1" else []
                 cname, rname, ch = self._enc[i]
                 hh, ww = sizes[i]
                 gz = gc[i]
                 pr1, pr2, pcc = pcs[rname + ".conv1"], pcs[rname + ".conv2"], pcs[cname]
-                self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2")
+                self._wgrad(pr2, [ops.nhwc_src(h_[i])], hh, ww, gz, name=rname + ".conv2", on_main=(rname + ".conv2") in extra)
                 g_h = self._act(f"g_h{i}", hh, ww, ch)
                 self._dgrad(pr2, 0, gz, g_h, hh, ww, actout=h_[i], name=rname + ".conv2")
-                self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1", on_main=tail)
+                self._wgrad(pr1, [ops.nhwc_src(a[i])], hh, ww, g_h, name=rname + ".conv1", on_main=tail or (rname + ".conv1") in extra)
                 g_a = self._act(f"g_a{i}", hh, ww, ch)
                 self._dgrad(pr1, 0, g_h, g_a, hh, ww, addend=gz, actout=a[i], name=rname + ".conv1")
                 srcs, ih, iw = self._enc_srcs[i]
                 if tail:
                     self._main_tail = getattr(self, "_main_tail", [])
                     self._main_tail.append(lambda: torch.cuda.current_stream().wait_event(self._x0_event))
-                self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail)
+                self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail or cname in extra)
                 if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                     self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
             self.bwd_body.extend(getattr(self, "_main_tail", []))
@@ -504,13 +510,18 @@ class FalnetPlan:
         L.check(lib.falnet_gemm_f32_small(L.ptr(g), k, 1, L.ptr(w3), 1, k, L.ptr(g1), n, n, k, 1, st), "split logits grad (1x1)")
 
     # ---- execution ----
-    def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True):
+    def run_forward(self, left, min_disp, max_disp, ret_disp, ret_subocc, ret_pan, repack=True, min_from=None):
+        """min_disp=None: the plan's min_disp is max_disp * min_from[0] / min_from[1] (Train_Stage1_K.py:237), made by the same launch."""
         b = self.buf
         self.generation += 1
         b["left"].copy_(left)
-        b["min_disp"].copy_(min_disp.reshape(-1))
-        b["max_disp"].copy_(max_disp.reshape(-1))
-        b["flow"][:, 0] = (b["max_disp"] / 100.0).to(self.dtype)  # FAL_netB.py:208-209
+        mx = max_disp.reshape(-1)
+        mn = None if min_disp is None else min_disp.reshape(-1)
+        assert mx.is_contiguous() and mx.dtype == torch.float32 and mx.numel() == self.B and (mn is None or (mn.is_contiguous() and mn.dtype == torch.float32))
+        mul, div = min_from if mn is None else (0.0, 1.0)
+        flow = b["flow"]  # (B, Cpad) in the compute dtype, channel 0 = max_disp / 100 (FAL_netB.py:208-209)
+        L.check(L.lib().falnet_disp_prologue(L.ptr(mx), L.ptr(mn), float(mul), float(div), L.ptr(b["min_disp"]), L.ptr(b["max_disp"]),
+                                             L.ptr(flow), flow.stride(0), self.B, L.dtype_code(self.dtype), L.stream_ptr()), "disp_prologue")
         if repack and not self.model._packed_is_fresh():
             for call in self.pack:
                 call()
@@ -528,12 +539,13 @@ class FalnetPlan:
             self.head_masks()
         return self.generation
 
-    def run_backward(self, g_disp, g_pan):
+    def run_backward(self, g_disp, g_pan, in_place=False):
+        """in_place: the caller has written the upstream gradients into buf["g_disp"] / buf["g_pan"] itself (the fused step)."""
         self._ensure_backward()
         b = self.buf
-        if g_disp is not None:
+        if g_disp is not None and not in_place:
             b["g_disp"].copy_(g_disp)
-        if g_pan is not None:
+        if g_pan is not None and not in_place:
             b["g_pan"].copy_(g_pan)
         self._accumulate = self.model._begin_grad_accumulation()
         self.wbatch.accumulate = 1 if self._accumulate else 0
@@ -680,7 +692,7 @@ class FAL_net(nn.Module):
                 first.setdefault("dec", off)
             if n.startswith(pre + ".conv4."):
                 first.setdefault("enc4", off)
-            if n.startswith(pre + ".conv1."):
+            if n.startswith(pre + f".conv{_TAIL_LEVELS}."):
                 first.setdefault("enc1", off)
         total = self._flat.numel()
         return [(first["dec"], total), (first["enc4"], first["dec"]), (first["enc1"], first["enc4"]), (0, first["enc1"])]

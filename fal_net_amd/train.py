@@ -162,12 +162,108 @@ def vgg_label_async(label, borrow=True):
     return join
 
 
+_FUSED_STEP = _os.environ.get("FALNET_FUSED_STEP", "1") == "1"
+_SEEDS = {}
+
+
+def _seed(device, value):
+    """Cached 1-element device tensors (upstream-gradient scalars of the loss kernels)."""
+    key = (device, float(value))
+    if key not in _SEEDS:
+        _SEEDS[key] = torch.tensor([float(value)], device=device)
+    return _SEEDS[key]
+
+
+def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize):
+    """The same iteration as `stage1_step`'s autograd form, as a static launch sequence: the plan's forward, the loss kernels
+    accumulating into one device scalar pair, their adjoints seeded by cached device scalars and writing straight into the
+    plans' gradient buffers, the plan's backward.  No autograd graph, no scalar aten launches (the autograd form spends ~30
+    launches of 4-5 us on `l1 + a_p * perc`, `rec + a_sm * sm`, output clones, gradient sums and seed fills).  `rpan` /
+    `ldisp` in the result alias the plan's output buffers: valid until the model's next forward of this shape."""
+    from . import loss_functions as LF
+    lib = L.lib()
+    B, C, H, W = left.shape
+    dev = left.device
+    plan = model._plan(B, H, W, dev)
+    plan._ensure_backward()
+    b = plan.buf
+    s = loss_scale(model)
+    joins = []
+    if a_p > 0:
+        if _os.environ.get("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
+            model._mid_forward_hook = lambda: joins.append(vgg_label_async(right))
+        else:
+            joins.append(vgg_label_async(right))
+    lf = left.detach()
+    lf = lf if lf.dtype == torch.float32 else lf.float()
+    plan.run_forward(lf.contiguous(), None, max_disp.detach().float().contiguous(), True, False, True, min_from=(min_disp_arg, max_disp_arg))
+    if a_p > 0 and not joins:
+        model._mid_forward_hook = None
+        joins.append(vgg_label_async(right))
+    rpan, ldisp = b["p_im0"], b["disp"]
+    rt = right.detach().contiguous()
+    st = L.stream_ptr()
+    S = plan.buf.get("step_scalars")
+    if S is None:
+        S = plan.buf["step_scalars"] = torch.zeros(2, device=dev)
+    S.zero_()  # [rec = L1 + a_p * perceptual, sm]
+    n_img = B * C * H * W
+    L.check(lib.falnet_l1_fwd(L.ptr(rpan), L.ptr(rt), None, B, C, H * W, 1.0 / n_img, L.ptr(S), 1, st), "l1_fwd")  # loss_functions.py:53
+    vplan = None
+    if a_p > 0:
+        vm = LF.vgg._get()
+        vdt = vm.compute_dtype or LF._default_dtype()
+        vm._prepare(dev, vdt)
+        vplan = vm._plan(B, H, W, vdt, dev, hold=True)
+        vplan.c3_call.set_input(rpan)
+        for c in vplan.fwd:
+            c()
+        labels = joins[0]()
+        code = L.dtype_code(vdt)
+        feats = []
+        for o, lab in zip(vplan.outs, labels):  # loss_functions.py:61-65, a_p folded into the scale
+            ln = LF._nhwc(lab.to(o.dtype))
+            Bo, Ho, Wo, Co = o.shape
+            sc = 1.0 / o.numel()
+            L.check(lib.falnet_mse_fwd(L.ptr(o), L.ptr(ln), Bo * Ho * Wo, Co, a_p * sc, L.ptr(S), 1, code, st), "mse_fwd")
+            feats.append((o, ln, Bo * Ho * Wo, Co, sc))
+    x0 = int(0.20 * W)
+    sc_sm = 1.0 / (B * H * (W - x0))
+    if a_sm > 0:  # Train_Stage1_K.py:255
+        L.check(lib.falnet_smooth_fwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), 1, st), "smooth_fwd")
+    # ---- adjoints (every node is linear in its upstream scalar: s = loss scale) ----
+    g_pan, g_disp = b["g_pan"], b["g_disp"]
+    if vplan is not None:
+        for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
+            L.check(lib.falnet_mse_bwd(L.ptr(o), L.ptr(ln), npix, Co, sc, L.ptr(_seed(dev, s * a_p)), L.ptr(go), code, st), "mse_bwd")
+        for c in vplan.bwd:
+            c()
+        g_pan.copy_(vplan.g_in)
+        vplan.busy = False
+    L.check(lib.falnet_l1_bwd(L.ptr(rpan), L.ptr(rt), None, B, C, H * W, 1.0 / n_img, L.ptr(_seed(dev, s)), L.ptr(g_pan),
+                              1 if vplan is not None else 0, st), "l1_bwd")
+    if a_sm > 0:
+        L.check(lib.falnet_smooth_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(_seed(dev, s * a_sm)), L.ptr(g_disp), 0,
+                                      st), "smooth_bwd")
+    plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
+    unscale = 1.0 / s
+    Sc = S.clone()  # the accumulators are reused by the next step
+    out = {"loss": torch.add(Sc[0], Sc[1], alpha=a_sm), "rec": Sc[0], "sm": Sc[1] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp,
+           "grad_scale": unscale}
+    if optimize:
+        opt.step(allreduce_gradients(model) * unscale)
+    return out
+
+
 def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512, min_disp_arg=2.0, max_disp_arg=300.0,
                 optimize=True):
     """One iteration of Train_Stage1_K.py:233-262 (forward, VGG, losses, backward, all-reduce, Adam).
     Returns device scalars (no host sync)."""
     opt.zero_grad()
     enable_overlapped_allreduce(model)
+    if (_FUSED_STEP and left.is_cuda and torch.is_grad_enabled() and hasattr(model, "_plan")
+            and all(p.requires_grad for _, p in model._trainable_named())):
+        return _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize)
     W = left.shape[3]
     min_disp = max_disp * min_disp_arg / max_disp_arg  # :237
     # :241-244 label features, overlapped with the model forward: started from the plan's mid-forward hook, i.e. when the

@@ -315,6 +315,11 @@ int falnet_gemm_f32_small(const float* A, int64_t sam, int64_t sak, const float*
 int falnet_resize_planar(const float* src, float* dst, int64_t planes, int H, int W, int OH, int OW, int bilinear, float scale,
                          void* stream);
 
+/* Per-sample scalars of one step in one launch (Train_Stage1_K.py:237, FAL_netB.py:208-209): max_out = max_disp, min_out = min_disp
+ * (or max_disp * mul / div when min_disp is NULL), flow[b * flow_stride] = max_disp / 100 in `dtype` (the constant input plane). */
+int falnet_disp_prologue(const float* max_disp, const float* min_disp, float mul, float div, float* min_out, float* max_out,
+                         void* flow, int flow_stride, int B, int dtype, void* stream);
+
 /* ---- training-data augmentation (data_transforms.py:46-157, Train_Stage1_K.py:116-128) ---- */
 /* One pass of Pillow's 8-bit bicubic resampling (Image.resize(size, BICUBIC), data_transforms.py:68) over an interleaved uint8
  * image [H][W][C]: along x (horizontal != 0: dst [H][out_size][C]) or along y (dst [out_size][W][C]).  bounds [out_size][2] =

@@ -88,7 +88,7 @@ def _real_model(arch, levels=7, seed=0):
 
 def test_gradient_buckets_of_the_real_models_tile_the_flat_buffer():
     """FAL_netB / A / C: gradient_buckets() are contiguous, disjoint, cover [0, total) and come in the order backward finalises
-    them (decoder + logits conv, encoder levels 4-6, 1-3, level 0); every trainable parameter lies inside exactly one bucket."""
+    them (decoder + logits conv, encoder levels 4-6, 2-3, 0-1); every trainable parameter lies inside exactly one bucket."""
     for arch in ("B", "A", "C"):
         m = _real_model(arch)
         flat = m.ensure_flat("cpu")
@@ -99,7 +99,7 @@ def test_gradient_buckets_of_the_real_models_tile_the_flat_buffer():
             assert lo < hi and hi2 == lo  # back to front, touching, no overlap
         named = m._trainable_named()
         pre = "backbone." if arch == "B" else ("BackBone." if arch == "A" else "synth.")
-        want = {0: ("deconv", "iconv", "conv0."), 1: ("conv4", "conv5", "conv6"), 2: ("conv1", "conv2", "conv3"), 3: ("conv0",)}
+        want = {0: ("deconv", "iconv", "conv0."), 1: ("conv4", "conv5", "conv6"), 2: ("conv2", "conv3"), 3: ("conv0", "conv1")}
         for (n, p), off in zip(named, m._offsets):
             inside = [i for i, (lo, hi) in enumerate(buckets) if lo <= off and off + p.numel() <= hi]
             assert len(inside) == 1, (arch, n)

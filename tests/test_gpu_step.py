@@ -364,3 +364,70 @@ def test_stage2_step_256x512_vs_oracle():
             continue
         gn = float(params[k].grad.norm())
         assert abs(float(p.grad.norm()) - gn) / gn < 2e-3, (k, float(p.grad.norm()), gn)  # (the reference itself needs 1e-3 here: f32 sums over 131k pixels)
+
+
+def test_vgg_plans_are_released_and_shared_feature_gradients_sum():
+    """A grad-enabled vgg() whose graph is dropped without a backward gives its plan back (no HBM growth), and two perceptual
+    losses on the SAME feature maps backpropagate their sum (not twice the last one)."""
+    import gc
+    LF.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 64, 128, generator=g).to(DEV).requires_grad_(True)
+    label = LF.vgg(torch.rand(1, 3, 64, 128, generator=g).to(DEV))
+    label2 = tuple(2 * v for v in label)
+    for _ in range(12):
+        feats = LF.vgg(x)  # never backpropagated
+        del feats
+        gc.collect()
+    pool = LF.vgg._plans[(1, 64, 128, True)]
+    assert len(pool) == 1 and not pool[0].busy
+    held = [LF.vgg(x) for _ in range(7)]  # alive at once: the pool is capped, the oldest plans are recycled
+    assert len(pool) <= LF._MAX_HELD_PLANS
+    with pytest.raises(RuntimeError, match="recycled"):
+        LF.perceptual_loss(held[0], label).backward()
+    del held
+    gc.collect()
+
+    def grad_of(fn):
+        x.grad = None
+        fn(LF.vgg(x)).backward()
+        return x.grad.clone()
+
+    ga = grad_of(lambda f: LF.perceptual_loss(f, label))
+    gb = grad_of(lambda f: LF.perceptual_loss(f, label2))
+    gab = grad_of(lambda f: LF.perceptual_loss(f, label) + LF.perceptual_loss(f, label2))
+    assert rel(gab, ga + gb) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_step_matches_autograd_step(dt):
+    """train.stage1_step's static launch sequence (no autograd graph) against its autograd form: same losses, outputs and
+    parameter gradients (f32: to reordering of the f32 atomics; bf16: to a flipped rounding)."""
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=11, distinct=True)
+    left, right, mx = left.to(DEV), right.to(DEV), mx.to(DEV)
+    res = {}
+    for fused in (False, True):
+        m = build(49, dt).train()
+        opt = train.FlatAdam(m, lr=1e-4)
+        old = train._FUSED_STEP
+        train._FUSED_STEP = fused
+        try:
+            out = train.stage1_step(m, opt, left, right, mx, optimize=False)
+        finally:
+            train._FUSED_STEP = old
+        res[fused] = (float(out["loss"]), float(out["rec"]), float(out["sm"]), out["ldisp"].clone(), out["rpan"].clone(),
+                      m.flat_gradients().clone())
+    a, f = res[False], res[True]
+    tol = 1e-5 if dt == torch.float32 else 2e-3
+    for i in range(3):
+        assert abs(a[i] - f[i]) <= tol * abs(a[i]), i
+    # two module instances may autotune to different kernels / split-K factors: bf16 activations then round differently
+    # (same spread as two autograd-form instances, test_16bit_steps_run_and_track_f32)
+    otol = 1e-5 if dt == torch.float32 else 6e-2
+    assert rel(f[3], a[3]) < otol and rel(f[4], a[4]) < otol
+    ga, gf = a[5].double(), f[5].double()
+    if dt == torch.float32:
+        assert float((ga - gf).norm() / ga.norm()) < 1e-4
+    else:
+        assert float(torch.nn.functional.cosine_similarity(ga, gf, dim=0)) > 0.999
+    LF.set_compute_dtype(torch.float32)

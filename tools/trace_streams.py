@@ -3,7 +3,7 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_dev_kernel" in r["Kernel_Name"] or "adam_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adam_tick_kernel" in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
