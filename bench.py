@@ -59,11 +59,12 @@ def hbm_traffic_from_profiles(kernel_symbol):
     if not files:
         return None
     table = json.load(open(files[-1]))
+    meta = table.pop("_meta", {})
     for name, v in table.items():
         if name[:100] == kernel_symbol[:100]:
             return {"bytes_per_launch": v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"],
                     "fetch_bytes_corrected": v["fetch_bytes_per_launch_corrected"], "write_bytes": v["write_bytes_per_launch"],
-                    "source": os.path.basename(files[-1])}
+                    "source": os.path.basename(files[-1]), "collected_at_commit": meta.get("commit", "unknown")}
     return None
 
 

@@ -28,8 +28,11 @@ for k, d in traffic.items():
     res[k] = {"launches": d["launches"], "fetch_bytes_per_launch_corrected": 2 * d["FETCH_SIZE"] * 1024 / n,
               "write_bytes_per_launch": d["WRITE_SIZE"] * 1024 / n}
 top = dict(sorted(res.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch_corrected"] + kv[1]["write_bytes_per_launch"]) * kv[1]["launches"])[:25])
+top["_meta"] = {"commit": os.environ.get("FALNET_COMMIT", "unknown"),
+                "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 25 --warmup 3 --no-cpu-baseline --no-roofline",
+                "units": "bytes per launch; fetch = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"}
 json.dump(top, open(os.path.join(root, "profiles", f"{tag}_bench_bf16_hbm_traffic.json"), "w"), indent=1)
 for r in rows[:12]:
     print(f"{r['Name'][:80]:80s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:8.1f} pct={r['Percentage']}")
-for k, v in list(top.items())[:8]:
+for k, v in [kv for kv in top.items() if kv[0] != '_meta'][:8]:
     print(k[:70], {a: (round(b / 1e6, 1) if 'bytes' in a else b) for a, b in v.items()}, "MB")
