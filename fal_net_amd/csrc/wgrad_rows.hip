@@ -352,7 +352,9 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
         }
     }
     const int ci0 = (tile % ntci) * 64, co0 = (tile / ntci) * 64;
-    const int hf = wave >> 2, a_t = (wave >> 1) & 1, c_t = wave & 1;  // 16-pixel half, 32-channel sub-tiles (cin, cout)
+    // 16-pixel half, 32-channel sub-tiles (cin, cout).  (Measured and rejected: the cin sub-tile as the high bit, so that the two waves of
+    // a SIMD differ in cin and a half-empty block -- 96 input channels -- keeps every SIMD busy: 8-10 % slower on every layer.)
+    const int hf = wave >> 2, a_t = (wave >> 1) & 1, c_t = wave & 1;
     const int rsel = wave >> 2, pw = wave & 3;                        // DMA role: row of the step's pair, 8-pixel piece
     const int H = p.TH, TW = p.TW, gC = p.gC, IH = p.IH;
     const int R = p.B * nstrips * H;
