@@ -310,12 +310,28 @@ __global__ __launch_bounds__(RED_THREADS) void hflip_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(RED_THREADS) void rowmax_kernel(const float* __restrict__ src, float* __restrict__ out,
-                                                             int64_t n) {
+// One 1024-thread block per sample (no scratch, no second launch): 16-byte loads, four in flight per thread -- the first version walked the
+// sample with 256 scalar lanes (206 us for 8 x 131 072 floats, 2.5 % of a Stage-2 step; now ~10 us).
+__global__ __launch_bounds__(1024) void rowmax_kernel(const float* __restrict__ src, float* __restrict__ out, int64_t n) {
     __shared__ float red[16];
     const float* s = src + (int64_t)blockIdx.x * n;
     float m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, s[i]);
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        const int64_t n4 = n >> 2;
+        int64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024) {
+            const float4 a = s4[i], b = s4[i + 1024], c = s4[i + 2048], d = s4[i + 3072];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
+        }
+        for (; i < n4; i += 1024) {
+            const float4 a = s4[i];
+            m = fmaxf(m, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, s[i]);
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -460,6 +476,6 @@ extern "C" int falnet_hflip(const float* src, float* dst, int64_t n_rows, int W,
 extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && out && B > 0 && n > 0, "rowmax: bad argument");
-    hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(RED_THREADS), 0, (hipStream_t)stream, src, out, n);
+    hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, src, out, n);
     FALNET_RETURN_LAUNCH();
 }

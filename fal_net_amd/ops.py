@@ -573,6 +573,8 @@ def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         return False
     if any(not ((s.H == IH or 2 * s.H == IH) and (s.W == IW or 2 * s.W == IW)) or s.C % 32 for s in srcs):
         return False
+    if str(cin_pad) in os.environ.get("FALNET_WGRAD_ROWS_SKIP_CIN", "").split(","):  # A/B: leave layers of this input width on the patch kernel
+        return False
     return os.environ.get("FALNET_WGRAD_ROWS", "1") == "1"
 
 
