@@ -2346,6 +2346,8 @@ static int g_patch_kcb = [] { const char* e = getenv("FALNET_PATCH_KCB"); return
 
 bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // conv_dma.hip
 int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st);
+bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n);         // four parity classes of a stride-2 data gradient in one pass
+int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st);
 
 static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
@@ -2593,6 +2595,13 @@ extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const
 extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs && n >= 1 && n <= 4, "conv2d_multi: 1..4 descriptors");
+    if (descs[0].variant == 14) {  // fused LDS-DMA kernel for the canonical 3x3 stride-2 data gradient (conv_dma.hip)
+        for (int i = 0; i < n; ++i)
+            for (int s = 0; s < descs[i].nsrc && s < 2; ++s)
+                if (int r = check_src(descs[i].src[s], 32, "conv2d_multi")) return r;
+        FALNET_CHECK_ARG(falnet_conv_s2d_dma_applicable(descs, n), "conv2d_multi: variant 14 needs the four parity classes of one 16-bit 3x3 stride-2 data gradient");
+        return falnet_conv_s2d_dma_launch(descs, (hipStream_t)stream);
+    }
     falnet_conv4_t pp;
     int64_t maxM = 0;
     ConvChoice c0;

@@ -274,3 +274,235 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<bf16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
     FALNET_RETURN_LAUNCH();
 }
+
+// ============================================================================================================================
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (models/FAL_netB.py:101-111 conv1..conv6), all four output-parity
+// classes in ONE pass over the upstream gradient.
+//
+// Input-gradient pixel (2i + py, 2j + px) gets the taps (kh, kw) with kh = py + 1 (mod 2), kw = px + 1 (mod 2), read at gout
+// position (i + oy, j + ox), oy = (py + 1 - kh) / 2 in {0, 1}: class (0,0) one tap, (0,1) and (1,0) two, (1,1) four -- nine (tap, class)
+// pairs, i.e. exactly the MFMA work of a stride-1 3x3 convolution on the gout grid.  The gather kernel ran the classes as four
+// independent implicit GEMMs (conv_igemm_multi_kernel): every 128-position tile re-fetched its gout operand once per tap and per
+// 32-channel output slice -- PMC: 488 MB fetched for a 34 MB tensor on conv1, 107 TFLOP/s.  Here a (16+1) x (32+1) gout patch and the
+// nine 32 x 32 weight tiles of a K chunk arrive by LDS-DMA exactly as in conv3x3_dma_kernel (double buffer, one barrier per chunk,
+// persistent workgroups) and feed FOUR accumulator sets (class x 2 rows x 16 registers = 128 per wave); the epilogue (residual add,
+// ELU', store) runs once per class on the interleaved output positions.
+#define SD_PW 33  // patch columns: 32 + the +1 halo
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles, int GH, int GW) {
+    constexpr int TH = 16, NWAVES = 8, BN = 32, MT = 2;
+    constexpr int KCV = 32;
+    constexpr int NPIX = (TH + 1) * SD_PW;
+    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    const falnet_src_t& S = p.src[0];
+    const int nchunks = S.C / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l4 = lane >> 2, segpos = lane & 3;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const sptr = reinterpret_cast<const T*>(S.ptr);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    int64_t w_off[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int tap = wid >> 1, co = n0 + ((wid & 1) << 4) + l4;  // two 16-row pieces per tap tile
+        const int gseg = segpos ^ ((lane >> 4) & 3);
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + tap) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    int64_t a_off[KP];
+    int64_t sbat = 0;
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile) {
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        sbat = (int64_t)b * S.sb;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int pix = 16 * (wave + NWAVES * k) + l4;
+            const int pr = pix / SD_PW, pc = pix - pr * SD_PW;
+            const int vy = ty0 + pr, vx = tx0 + pc;
+            const bool ok = pix < NPIX && vy < GH && vx < GW;
+            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8) : (int64_t)(zero_t - (sptr + sbat));
+        }
+    };
+    struct Cur { int tile, c; };
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile);
+        }
+    };
+    auto issue = [&](const Cur& q, int buf) {
+        const T* sbase = sptr + sbat + q.c * KCV;
+        const T* wbase = wptr + q.c * KCV;
+        const unsigned dst0 = lds_base + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int id = wave + NWAVES * k;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[k], dst0 + id * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int wid = wave + NWAVES * k;
+            if (wid < B_PIECES) cd_glds16(wbase + w_off[k], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+    // fragment read addresses: gout position (2 wave + rs, ox + r) of the tile, rs = mt + oy in 0..2, ox in 0..1
+    int a_addr[3][2];
+#pragma unroll
+    for (int rs = 0; rs < 3; ++rs)
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox) {
+            const int pp = (wave * MT + rs) * SD_PW + ox + r;
+            a_addr[rs][ox] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
+        }
+    int b_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_lane[ks] = A_BYTES + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
+
+    f32x16 acc[4][MT][1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[c][mt][0][j] = 0.f;
+    Cur qi = {(int)blockIdx.x, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile);
+        issue(qi, 0);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 < total) {
+            issue(qi, (it + 1) & 1);
+            advance(qi);
+        }
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[3][2], bb[2];
+#pragma unroll
+        for (int rs = 0; rs < 3; ++rs)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) aa[rs][ox] = a_addr[rs][ox] + bo;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bb[ks] = b_lane[ks] + bo;
+        s16x8_t fa[2][MT], fb[2];
+        auto load_step = [&](int st, int set) {
+            const int t = st >> 1, ks = st & 1;
+            const int kh = t / 3, kw = t % 3;
+            const int oy = kh == 0 ? 1 : 0, ox = kw == 0 ? 1 : 0;  // (py + 1 - kh) / 2 with py = (kh + 1) & 1
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const s16x8_t*>(Bf + (aa[mt + oy][ox] ^ (ks << 5)));
+            fb[set] = *reinterpret_cast<const s16x8_t*>(Bf + bb[ks] + (t * BN) * 64);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
+            const int t = st >> 1;
+            const int cls = (((t / 3) + 1) & 1) * 2 + (((t % 3) + 1) & 1);  // (py, px) of this tap
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[cls][mt][0] = H16<T>::mma(fb[st & 1], fa[st & 1][mt], acc[cls][mt][0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+        }
+        if (++cc == nchunks) {
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            float bias[1][16];
+            load_bias16<1>(p, n0, h, bias);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int py = c >> 1, px = c & 1;
+                const int x = 2 * (tx0 + r) + px;
+                auto pixoff = [&](int mt) -> int64_t {
+                    const int y = 2 * (ty0 + wave * MT + mt) + py;
+                    if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                    return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                };
+                epilogue_direct<T, MT, 1>(p, acc[c], bias, n0, lane, pixoff);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[c][mt][0][j] = 0.f;
+            }
+        }
+    }
+}
+
+// The four members of a falnet_conv2d_multi launch are the canonical parity classes of one 3x3 stride-2 data gradient?
+bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n) {
+    if (n != 4) return false;
+    const falnet_conv_t& q = d[3];
+    if (q.dtype != FALNET_BF16 && q.dtype != FALNET_F16) return false;
+    if (q.nsrc != 1 || q.w_taps != 9 || q.ksplit > 1 || q.out_layout != FALNET_OUT_NHWC || q.bias || q.pool_out) return false;
+    const falnet_src_t& S = q.src[0];
+    if (S.C % 32 || S.C <= 0 || S.H != q.IH || S.W != q.IW) return false;
+    if ((q.OH & 1) || (q.OW & 1) || q.IH * 2 != q.OH || q.IW * 2 != q.OW || q.IH < 16 || q.IW < 32) return false;
+    if ((int64_t)S.H * S.sy >= (1ll << 31) || (int64_t)q.w_rows * 9 * q.cin_total >= (1ll << 31) || (q.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;
+    if (q.cin_total != S.C) return false;
+    for (int c = 0; c < 4; ++c) {
+        const falnet_conv_t& p = d[c];
+        const int py = c >> 1, px = c & 1;
+        if (p.src[0].ptr != S.ptr || p.weight != q.weight || p.out != q.out || p.addend != q.addend || p.actout != q.actout || p.act != q.act ||
+            p.actout_kind != q.actout_kind || p.Cout != q.Cout || p.w_rows != q.w_rows || p.osy != 2 || p.osx != 2 || p.ooy != py || p.oox != px ||
+            p.TH != q.OH / 2 || p.TW != q.OW / 2 || p.B != q.B || p.OH != q.OH || p.OW != q.OW || p.isy != 1 || p.isx != 1)
+            return false;
+        int k = 0;
+        for (int kh = 0; kh < 3; ++kh) {
+            if ((py + 1 - kh) % 2) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                if ((px + 1 - kw) % 2) continue;
+                if (k >= p.ntaps || p.tap_dy[k] != (py + 1 - kh) / 2 || p.tap_dx[k] != (px + 1 - kw) / 2 || p.tap_w[k] != kh * 3 + kw) return false;
+                ++k;
+            }
+        }
+        if (k != p.ntaps) return false;
+    }
+    return true;
+}
+
+int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
+    const falnet_conv_t& p = d[3];
+    const int GH = p.IH, GW = p.IW;  // the upstream-gradient grid
+    const int tiles_x = (GW + 31) / 32, tiles_y = (GH + 15) / 16;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 31) / 32;
+    int gx = 256 / ny;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+    if (p.dtype == FALNET_F16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+    FALNET_RETURN_LAUNCH();
+}

@@ -189,6 +189,10 @@ class FalnetPlan:
                     singles.append(self._conv_call(*args, **kw))
             multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
             multis = [multi]
+            if (len(members) == 4 and self.dtype in ops.H16 and IH % 2 == 0 and IW % 2 == 0 and OH >= 16 and OW >= 32
+                    and os.environ.get("FALNET_S2D_DMA", "1") == "1"):
+                # all four classes from ONE staged gout patch (conv_dma.hip): the gather form re-reads gout per tap and channel slice
+                multis.append(ops.conv_multi_call(members, name="dgrad(s2 x4, dma) " + name, s2d=True))
             if ops.AUTOTUNE and os.environ.get("FALNET_S2_SPLITK", "1") == "1":
                 # small levels: the four classes as ONE split-K launch + ONE epilogue instead of one long-K launch or 4 x (split-K + epilogue)
                 wgs = 4 * ((B * ((IH + 1) // 2) * ((IW + 1) // 2) + 127) // 128) * ((cg + ops.gather_bn(cg, cg) - 1) // ops.gather_bn(cg, cg))
@@ -206,7 +210,7 @@ class FalnetPlan:
                 for c in calls:
                     c()
             import os as _os
-            s2key = f"s2dgrad|t{L.dtype_code(self.dtype)}|B{B}|{IH}x{IW}|{pc.cout_pad}>{cg}|a{int(addend is not None)}{int(actout is not None)}|n{len(multis)}"
+            s2key = f"s2dgrad|t{L.dtype_code(self.dtype)}|B{B}|{IH}x{IW}|{pc.cout_pad}>{cg}|a{int(addend is not None)}{int(actout is not None)}|n{len(multis)}d"
             chosen = ops.best_of(*multis, separate, key=s2key) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
             if chosen is separate:
                 self.bwd_body.extend(singles)

@@ -371,7 +371,7 @@ def gather_bn(w_rows, Cout):
     return 128 if (w_rows % 128 == 0 and Cout > 64) else (64 if (w_rows % 64 == 0 and Cout > 32) else 32)
 
 
-def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1):
+def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1, s2d=False):
     """Fuse up to four conv_call launches (built with autotune off: gather kernel) into one falnet_conv2d_multi.
     bn = 32 / 64: narrower workgroups than the default (variants 11 / 12: more workgroups for small layers).
     ksplit > 1: split-K over blockIdx.z with one fused epilogue; the members share the plan's split-K workspace, each with its
@@ -382,7 +382,7 @@ def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1):
     off = 0
     for i, c in enumerate(calls):
         C.memmove(C.byref(arr[i]), C.byref(c.desc), C.sizeof(L.Conv))
-        arr[i].variant, arr[i].ksplit = {32: 11, 64: 12}.get(bn, 1), ksplit
+        arr[i].variant, arr[i].ksplit = (14 if s2d else {32: 11, 64: 12}.get(bn, 1)), ksplit
         if ksplit > 1:
             need = (arr[i].B * arr[i].TH * arr[i].TW * arr[i].w_rows * 4 + 255) // 256 * 256
             if not c.desc.splitk_ws or off + need > c.desc.splitk_ws_bytes or arr[i].Cout % 8:
@@ -396,7 +396,8 @@ def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1):
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d_multi(arr, n, L.stream_ptr()), name)
-    return _timed(f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t", sum(c.flops for c in calls), 0, launch, name)
+    sym = f"_Z22conv3x3_s2d_dma_kernelI{dn}Ev13falnet_conv_tiiiii" if s2d else f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t"
+    return _timed(sym, sum(c.flops for c in calls), 0, launch, name)
 
 
 _AUTOTUNE_LOG = os.environ.get("FALNET_AUTOTUNE_LOG") == "1"

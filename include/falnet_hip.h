@@ -125,6 +125,9 @@ int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const float* bia
 /* n <= 4 gather launches of one family (same dtype / Cout / packed rows / ksplit, NHWC output) in ONE grid: the four
  * output-parity classes of a stride-2 data gradient.  ksplit > 1: every member needs its OWN all-zero splitk_ws region
  * (B*TH*TW*w_rows floats, non-overlapping); one fused epilogue launch follows and leaves the regions zero. */
+/* variant 14 in descs[0]: the members must be the four output-parity classes (0,0) (0,1) (1,0) (1,1) of ONE 3x3 / stride-2 / pad-1
+ * data gradient in bf16 / f16 (same gout source, packed weight, output tensor; taps as fal_net_amd/ops.py:dgrad_taps_s2); they then
+ * run as one LDS-DMA halo kernel (csrc/conv_dma.hip: conv3x3_s2d_dma_kernel) instead of four gather GEMMs. */
 int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stream);
 /* symbol (as rocprofv3 reports it) of the kernel falnet_conv2d launches for this descriptor */
 int falnet_conv2d_kernel_name(const falnet_conv_t* p, char* buf, int len);

@@ -395,6 +395,43 @@ def test_stride2_dgrad_fused_launch(B, cin, cout, H, W, ksplit, dtype):
     assert float(ws.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 32, 64, 64, 128), (1, 64, 128, 40, 72), (2, 33, 64, 32, 64), (1, 256, 256, 32, 64)])
+def test_stride2_dgrad_dma_four_classes(B, cin, cout, H, W, dtype):
+    """falnet_conv2d_multi variant 14 (conv3x3_s2d_dma_kernel): the four parity classes of a stride-2 data gradient from ONE staged
+    gout patch, with addend and activation gradient -- vs autograd and vs the gather form; partial tiles (gout 20x36) included."""
+    g = torch.Generator().manual_seed(B * H + W + cin)
+    x = torch.randn(B, cin, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    y = F.conv2d(F.elu(x), w, None, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    skip = torch.randn(B, cin, H, W, generator=g)
+    ref = (F.conv_transpose2d(gy, w, stride=2, padding=1, output_padding=1) + skip) * torch.where(x > 0, torch.ones_like(x), F.elu(x) + 1.0)
+    pc = packed(w, None, [cin], 2, dtype)
+    OH, OW = y.shape[2], y.shape[3]
+    g_t, add_t, act_t = to_nhwc(gy, dtype), to_nhwc(skip, dtype), to_nhwc(F.elu(x.detach()), dtype)
+    cg = pc.groups_pad[0]
+    gin = torch.full((B, H, W, cg), float("nan"), dtype=dtype, device=DEV)
+    members = []
+    for py in range(2):
+        for px in range(2):
+            members.append(ops.conv_call(dtype, [ops.nhwc_src(g_t)], OH, OW, pc.wd, pc.cout_pad, ops.dgrad_taps_s2(py, px), pc.taps, cg, 1, B, H // 2,
+                                         W // 2, gin, H, W, cg, cg, out_step=(2, 2, py, px), addend=add_t, actout=act_t, actout_kind=L.ACT_ELU,
+                                         autotune=False))
+    ops.conv_multi_call(members, s2d=True)()
+    torch.cuda.synchronize()
+    got = gin.clone()
+    assert rel(to_nchw(got, cin), ref.detach()) < TOL[dtype]
+    assert cg == cin or float(got[..., cin:].float().abs().max()) == 0.0  # padding channels stay zero
+    gin.fill_(float("nan"))
+    ops.conv_multi_call(members)()
+    assert rel(got.float(), gin.float()) < 2 * TOL[dtype]
+    # not the canonical pattern (a member's tap table altered): rejected, not mis-computed
+    bad = ops.conv_multi_call(members[:3] + [members[2]], s2d=True)
+    with pytest.raises(RuntimeError):
+        bad()
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (1, 75, 250)])
 def test_wgrad_first_layer_planar(B, H, W):
     """falnet_wgrad variant 6: conv0's weight (+ fused bias) gradient straight from the planar f32 image (no NHWC copy), through
