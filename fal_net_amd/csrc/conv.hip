@@ -2348,6 +2348,8 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // c
 int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st);
 bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n);         // four parity classes of a stride-2 data gradient in one pass
 int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st);
+bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p);                // forward 3x3 stride-2
+int falnet_conv_s2f_dma_launch(const falnet_conv_t& p, hipStream_t st);
 
 static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
@@ -2385,7 +2387,18 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15, "conv2d: unknown variant %d", variant);
+    if (variant == 15) {  // LDS-DMA forward 3x3 stride-2 (conv_dma.hip)
+        if (!falnet_conv_s2f_dma_applicable(p)) {
+            falnet_set_error("conv2d: variant 15 needs a canonical 16-bit 3x3 stride-2 pad-1 NHWC launch (>= 8 x 32 outputs) with sources at the input size");
+            return -2;
+        }
+        c.flip = 0;
+        c.swap = 0;
+        c.patch = 4;
+        c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
+        return 0;
+    }
     if (variant == 13) {  // LDS-DMA, double-buffered, persistent: 16x32 positions x 64 channels per workgroup (conv_dma.hip)
         if (!(dense3x3 && falnet_conv_dma_applicable(p))) {
             falnet_set_error("conv2d: variant 13 needs a 16-bit dense 3x3 stride-1 launch (>= 16 x 32 positions) with sources at the launch size or half of it");
@@ -2463,7 +2476,9 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 3)
+    if (c.patch == 4)
+        snprintf(buf, len, "_Z22conv3x3_s2f_dma_kernelI%sLi%dEEv13falnet_conv_tiii", t, c.bn);
+    else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
     else if (c.patch == 2)
         snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb);
@@ -2499,6 +2514,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
     if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st);
     if (c.patch == 2) {
         const int ws_th = c.bn == 64 ? 8 : 16;

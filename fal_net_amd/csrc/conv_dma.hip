@@ -506,3 +506,225 @@ int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
     FALNET_RETURN_LAUNCH();
 }
+
+// ============================================================================================================================
+// Forward 3x3 / stride-2 / pad-1 convolution (models/FAL_netB.py:101-111 conv1..conv4), 16-bit operands, LDS-DMA double buffer.
+//
+// A stride-2 output tile reads (2 TH + 1) x 65 input pixels for TH x 32 outputs -- four times the footprint of a stride-1 tile -- so
+// the K chunk is 16 channels (32 B per pixel): 17 x 65 pixels (35 KB) + nine BN x 16 weight tiles per buffer, two buffers, one
+// persistent 8-wave workgroup per CU, wave w = output row w of the 8 x 32 tile.  The DMA de-interleaves the patch columns by parity
+// while it fetches (every lane names its own source pixel): LDS row = [even columns 0..32 | odd columns 0..31], so the 32 lanes of a
+// fragment read consecutive 32-B pixel rows for every tap (kw = 0, 2: even plane at i, i + 1; kw = 1: odd plane at i).  The two 16-B
+// halves of row R are exchanged when bit 3 of R is set (on the SOURCE address): lanes i and i + 8 of a ds_read_b128 then hit
+// different banks.  One MFMA K step (16 channels) per tap and chunk; the gather kernel this replaces ran these layers at 116-253 TFLOP/s.
+#define SF_COLS 65
+
+template <typename T, int BN>
+__global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TH = 8, NWAVES = 8, NT = BN / 32;
+    constexpr int KCV = 16;  // input channels per chunk (32 B per pixel / weight row)
+    constexpr int NPIX = (2 * TH + 1) * SF_COLS;
+    constexpr int A_PIECES = (NPIX + 31) / 32, B_PIECES = 9 * BN / 32, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
+    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
+    const int nchunks = (C0 + C1) / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    // ---- DMA geometry: a 1-KiB piece = 32 rows of 32 B; lane -> (row lane >> 1, physical half lane & 1) ----
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l2 = lane >> 1, half = lane & 1;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    int64_t w_off[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int R = 32 * wid + l2;  // row of the [tap][BN] weight image
+        const int tap = R / BN, co = n0 + R % BN;
+        const int lseg = half ^ ((R >> 3) & 1);
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + tap) * p.cin_total + lseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    int64_t a_off[KP];
+    const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
+    int64_t sbat[2] = {0, 0};
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile, int s2) {
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
+        sbat[s2] = (int64_t)b * S.sb;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int lp = 32 * (wave + NWAVES * k) + l2;  // LDS pixel row: [patch row][even cols 0..32 | odd cols 0..31]
+            const int pr = lp / SF_COLS, q = lp - pr * SF_COLS;
+            const int c = q < 33 ? 2 * q : 2 * (q - 33) + 1;  // patch column
+            const int vy = 2 * ty0 - 1 + pr, vx = 2 * tx0 - 1 + c;
+            const bool ok = lp < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
+            const int lseg = half ^ ((lp >> 3) & 1);
+            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + lseg * 8) : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+        }
+    };
+    struct Cur { int tile, c, s, c0, kofs; };
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            return;
+        }
+        q.c0 += KCV;
+        q.kofs += KCV;
+        if (q.s == 0 && q.c0 >= C0) {
+            q.s = 1;
+            q.c0 = 0;
+            tile_offsets(q.tile, 1);
+        }
+    };
+    auto issue = [&](const Cur& q, int buf) {
+        const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+        const T* wbase = wptr + q.kofs;
+        const unsigned dst0 = lds_base + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int id = wave + NWAVES * k;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[k], dst0 + id * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            const int wid = wave + NWAVES * k;
+            if (wid < B_PIECES) cd_glds16(wbase + w_off[k], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+    // fragment read addresses: tap (kh, kw) of output (wave, r) = patch row 2 wave + kh, plane kw & 1, entry r + (kw >> 1)
+    int a_addr[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int lp = (2 * wave + kh) * SF_COLS + ((kw & 1) ? 33 : 0) + r + (kw >> 1);
+            a_addr[kh][kw] = lp * 32 + ((h ^ ((lp >> 3) & 1)) << 4);
+        }
+    int b_lane[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int R = nt * 32 + r;
+        b_lane[nt] = A_BYTES + R * 32 + ((h ^ ((R >> 3) & 1)) << 4);  // + tap * BN * 32 (BN a multiple of 16: the swizzle bit is the same)
+    }
+
+    f32x16 acc[NT][1][1];  // [nt]: the epilogue runs per 32-channel slice (one slice's bias / operands in registers at a time)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile, 0);
+        issue(qi, 0);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 < total) {
+            issue(qi, (it + 1) & 1);
+            advance(qi);
+        }
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[3][3], bb[NT];  // ONE add per lane address and chunk (see conv3x3_dma_kernel); tap offsets of the weights are immediates
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) aa[kh][kw] = a_addr[kh][kw] + bo;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bb[nt] = b_lane[nt] + bo;
+        s16x8_t fa[2], fb[2][NT];
+        auto load_step = [&](int t, int set) {
+            fa[set] = *reinterpret_cast<const s16x8_t*>(Bf + aa[t / 3][t % 3]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const s16x8_t*>(Bf + bb[nt] + t * BN * 32);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_step(t + 1, (t + 1) & 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0][0] = H16<T>::mma(fb[t & 1][nt], fa[t & 1], acc[nt][0][0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        }
+        if (++cc == nchunks) {
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            const int x = tx0 + r, y = ty0 + wave;
+            auto pixoff = [&](int) -> int64_t {
+                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+            };
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bias[1][16];
+                load_bias16<1>(p, n0 + 32 * nt, h, bias);
+                epilogue_direct<T, 1, 1>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;
+            }
+        }
+    }
+}
+
+// canonical forward 3x3 stride-2 pad-1 launch (taps (kh - 1, kw - 1, kh * 3 + kw)), 16-bit, NHWC output, sources at the input size
+bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.ntaps != 9 || p.w_taps != 9 || p.isy != 2 || p.isx != 2 || p.osy != 1 || p.osx != 1 || p.ooy || p.oox) return false;
+    if (p.out_layout != FALNET_OUT_NHWC || p.pool_out || p.ksplit > 1 || p.nsrc < 1 || p.nsrc > 2) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1 || p.tap_w[t] != t) return false;
+    if (p.TH != p.OH || p.TW != p.OW || p.OH != (p.IH + 1) / 2 || p.OW != (p.IW + 1) / 2 || p.OH < 8 || p.OW < 32) return false;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const falnet_src_t& S = p.src[s];
+        if (S.C % 16 || S.C <= 0 || S.H != p.IH || S.W != p.IW) return false;
+        if ((int64_t)S.H * S.sy >= (1ll << 31)) return false;
+    }
+    if ((int64_t)p.w_rows * 9 * p.cin_total >= (1ll << 31) || (p.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;
+    return true;
+}
+
+int falnet_conv_s2f_dma_launch(const falnet_conv_t& p, hipStream_t st) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    static const bool allow128 = [] { const char* e = getenv("FALNET_S2F_BN128"); return e && e[0] == '1'; }();  // (128-channel form: 36-41 spilled VGPRs)
+    const bool wide = allow128 && p.w_rows % 128 == 0 && p.Cout > 64;
+    const int bn = wide ? 128 : 64;
+    const int ny = (p.Cout + bn - 1) / bn;
+    int gx = 256 / ny;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+#define SF_L(T) do { if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2f_dma_kernel<T, 128>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles); \
+                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2f_dma_kernel<T, 64>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles); } while (0)
+    FALNET_DISPATCH_16(p.dtype, SF_L);
+#undef SF_L
+    FALNET_RETURN_LAUNCH();
+}

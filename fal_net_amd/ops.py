@@ -422,6 +422,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1), (10, 1)]
     if os.environ.get("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
+        if d.isy == 2 and os.environ.get("FALNET_S2F_DMA", "1") == "1":
+            cands += [(15, 1)]  # LDS-DMA forward 3x3 stride-2
     if wgs < 512:
         cands += [(8, 1), (9, 1)]
     best, best_t = (1, 1), None

@@ -149,7 +149,11 @@ def test_conv_forward(case, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [PATCH_CASES[0], PATCH_CASES[1], PATCH_CASES[3], PATCH_CASES[4],
                                   (2, [64], 128, 40, 70, 1, 3, True, L.ACT_ELU, True), (1, [32, 64], 64, 33, 64, 1, 3, False, L.ACT_ELU, False),
-                                  (3, [32, 32], 49, 21, 75, 1, 3, True, L.ACT_NONE, True), (2, [64], 64, 64, 96, 1, 3, True, L.ACT_RELU, False)])
+                                  (3, [32, 32], 49, 21, 75, 1, 3, True, L.ACT_NONE, True), (2, [64], 64, 64, 96, 1, 3, True, L.ACT_RELU, False),
+                                  # stride 2 (variant 15 = LDS-DMA form): ragged tiles / odd sizes, two sources, 8x32 minimum, Cout 96 and 256
+                                  (2, [32, 32], 64, 48, 142, 2, 3, True, L.ACT_ELU, False), (1, [64], 128, 16, 64, 2, 3, True, L.ACT_ELU, False),
+                                  (1, [128], 96, 33, 130, 2, 3, False, L.ACT_ELU, False), (2, [48], 256, 20, 64, 2, 3, True, L.ACT_NONE, False),
+                                  (1, [32], 64, 11, 15, 2, 3, True, L.ACT_ELU, False)])
 def test_conv_every_kernel_variant(case, dtype):
     """Force each kernel variant (gather, halo-patch 128/64-B chunks, single/double stage, 16x32-block forms) on the
     same launch: all must agree with torch-CPU (the autotuner may pick any of them)."""
@@ -167,13 +171,14 @@ def test_conv_every_kernel_variant(case, dtype):
     old = ops.AUTOTUNE
     ops.AUTOTUNE = False
     try:
-        out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        out = torch.empty(B, OH, OW, pc.cout_pad, dtype=dtype, device=DEV)
         call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(k), pc.taps, pc.cout_pad,
-                             stride, B, H, W, out, H, W, pc.cout_pad, pc.cout_pad, bias=bias_t, addend=add_t, act=act)
+                             stride, B, OH, OW, out, OH, OW, pc.cout_pad, pc.cout_pad, bias=bias_t, addend=add_t, act=act)
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in range(1, 14):  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent
+    for variant in list(range(1, 14)) + [15]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -183,6 +188,9 @@ def test_conv_every_kernel_variant(case, dtype):
         got = to_nchw(out, Cout)
         assert rel(got, ref) < TOL[dtype], variant
         ran.append(variant)
+    if stride == 2:
+        assert 1 in ran and (15 in ran) == (dtype != torch.float32 and k == 3 and (H + 1) // 2 >= 8 and (W + 1) // 2 >= 32)
+        return
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
     assert (13 in ran) == (dtype != torch.float32 and H >= 16)
     assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
