@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: see fal_net_amd/__init__.py (stream -> hardware-queue collisions)
+
 import torch
 import torch.distributed as dist
 
