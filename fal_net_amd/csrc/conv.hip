@@ -1123,9 +1123,12 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
 // Here the (8+2)x(32+2)x3 patch is staged planar in LDS straight from the NCHW f32 input, every lane builds its
 // K = 32 (27 + 5 zeros) im2col fragment from it (k = c*9 + tap: the OIHW flattening, so the f32 master weights are used
 // as they are, no packing), two bf16 MFMAs (sixteen f32 ones) per 32x32 output tile: purely output-write bound.
+#ifndef C3_OCC
+#define C3_OCC 2
+#endif
 #define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, next patch prefetched behind the epilogue
 template <typename T, int NT>
-__global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
+__global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                                   const falnet_conv_t p, int groups_x, int tiles_y) {
     constexpr int PH = PT_TH + 2, PW = PT_PW, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
     __shared__ __attribute__((aligned(16))) float patch[NEL];                       // [3][PH][PW] f32
@@ -1206,41 +1209,38 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv3x3_c3_kernel(const float
         }
         __syncthreads();
         if (tt + 1 < C3_TPW && tix + 1 < tiles_x) patch_load(tx0 + PT_TW);  // in flight behind the MFMAs and the epilogue
-        f32x16 acc[MT][NT];
+        // one output row (32 positions x 32 NT channels) at a time: accumulators + epilogue operands of ONE row in registers
+        // (the whole 2-row tile at once needed 256 VGPRs + spills = 2 waves per SIMD for a kernel that only streams its output)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x16 acc[1][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
-        if constexpr (sizeof(T) == 2) {
+                for (int j = 0; j < 16; ++j) acc[0][nt][j] = 0.f;
+            const float* base = patch + (wave * MT + mt) * PW + r;
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float* base = patch + (wave * MT + mt) * PW + r;
+                for (int ks = 0; ks < 2; ++ks) {
                     s16x8_t afr;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) afr[j] = (short)H16<T>::bits(a_elem(base, ks * 16 + j, ks * 16 + 8 + j));
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<T>::mma(bfr[ks][nt], afr, acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = H16<T>::mma(bfr[ks][nt], afr, acc[0][nt]);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const float a = a_elem(base, ks * 2, ks * 2 + 1);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ks][nt][0], a, acc[0][nt], 0, 0, 0);
                 }
             }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float a = a_elem(patch + (wave * MT + mt) * PW + r, ks * 2, ks * 2 + 1);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ks][nt][0], a, acc[mt][nt], 0, 0, 0);
-                }
-            }
+            epilogue_direct<T, 1, NT>(p, acc, bias, 0, lane, [&](int) -> int64_t {  // operands exchanged above: pixels on lanes
+                const int y = ty0 + wave * MT + mt, xx = tx0 + r;
+                return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
+            });
         }
-        epilogue_direct<T, MT, NT>(p, acc, bias, 0, lane, [&](int mt) -> int64_t {  // operands exchanged above: pixels on lanes
-            const int y = ty0 + wave * MT + mt, xx = tx0 + r;
-            return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
-        });
     }
 }
 
