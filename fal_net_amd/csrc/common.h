@@ -54,8 +54,12 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <typename T> struct H16;
 template <> struct H16<bf16_t> {
+    static __device__ __forceinline__ f32x4_t mma16(s16x8_t a, s16x8_t b, f32x4_t c) {  // v_mfma_f32_16x16x32_bf16
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }          // element 0 of a packed pair
     static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }  // element 1
     static __device__ __forceinline__ unsigned short bits(float v) { return __builtin_bit_cast(unsigned short, (bf16_t)v); }
@@ -64,6 +68,9 @@ template <> struct H16<bf16_t> {
     }
 };
 template <> struct H16<f16_t> {
+    static __device__ __forceinline__ f32x4_t mma16(s16x8_t a, s16x8_t b, f32x4_t c) {  // v_mfma_f32_16x16x32_f16
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)); }
     static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
     static __device__ __forceinline__ unsigned short bits(float v) { return __builtin_bit_cast(unsigned short, (f16_t)v); }

@@ -575,6 +575,42 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
     }
 }
 
+// The same walk on v_mfma_f32_16x16x32 (16-bit operands, exchanged operands only: positions on lanes): one step = one (chunk, tap) with
+// K = 32 (a whole 64-B chunk row), a 32x32 tile = 2 x 2 MFMAs (conv_epilogue.h: Acc16).  px_of(step, mt, pt) / w_of(step, nt, ct) return
+// this lane's 16-B fragment address: position 16 pt + (lane & 15) / weight row m16_row_channel(lane & 15) of half ct, K block lane >> 4.
+template <typename T, int MT, int NT, int NSTEP, typename PxOf, typename WOf>
+__device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[MT][NT]) {
+    constexpr int SLOTS = 3;
+    uint4 fp[SLOTS][MT][2], fw[SLOTS][NT][2];
+    auto load = [&](int step, int slot) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) fp[slot][mt][pt] = *reinterpret_cast<const uint4*>(px_of(step, mt, pt));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) fw[slot][nt][ct] = *reinterpret_cast<const uint4*>(w_of(step, nt, ct));
+    };
+    load(0, 0);
+    if (NSTEP > 1) load(1, 1);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        if (st + SLOTS - 1 < NSTEP) load(st + SLOTS - 1, (st + SLOTS - 1) % SLOTS);
+        const int sl = st % SLOTS;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        acc[mt][nt].t[ct][pt] = H16<T>::mma16(__builtin_bit_cast(s16x8_t, fw[sl][nt][ct]), __builtin_bit_cast(s16x8_t, fp[sl][mt][pt]),
+                                                              acc[mt][nt].t[ct][pt]);
+    }
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -930,7 +966,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_patch_kernel(const falnet
 // prefetched into registers behind the previous block's MFMAs.  K chunks are 64 B (32 bf16 / 16 f32 channels), NCH <= 2.
 //   LDS: W [NCH][9][BN][80 B] + A [NCH][340][80 B]  (BN=64, NCH=2: 92 KB + 54 KB)
 //   4 waves, each 2 rows x BN channels of the block (MT = 2, NT = BN/32); epilogue straight from the accumulators.
-template <typename T, int BN, int NCH>
+template <typename T, int BN, int NCH, bool M16 = false>
 __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
     // eight waves = two per SIMD: while one wave sits in a load / store issue or in its epilogue arithmetic the other one
     // keeps the matrix pipe fed (in-kernel stamps at one wave per SIMD: MFMA 36 % of a block, load issue 25 %, epilogue 32 %).
@@ -1084,6 +1120,26 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
         if (next < ntiles) patch_load(next);  // in flight behind this block's MFMAs and epilogue
         WS_STAMP();  // 4: prefetch issued
         f32x16 acc[MT][NT];
+        if constexpr (M16 && sizeof(T) == 2) {
+            // v_mfma_f32_16x16x32 form (steps = (chunk, tap), K = 32): same LDS image, lane = (position / weight row lane & 15, K block lane >> 4)
+            Acc16 a16[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a16[mt][nt].zero();
+            const int lp = lane & 15, lg = lane >> 4;
+            const char* pxb = Al + ((wm * MT) * PT_PW + lp) * PITCH + lg * 16;
+            const char* wb16 = Wl + (wn * 32 + m16_row_channel(lp)) * PITCH + lg * 16;
+            mma_steps16<T, MT, NT, NCH * 9>(
+                [&](int st, int mt, int pt) { const int c = st / 9, t = st % 9;
+                                              return pxb + ((c * NPIX + mt * PT_PW + 16 * pt + (t / 3) * PT_PW + (t % 3)) * PITCH); },
+                [&](int st, int nt, int ct) { return wb16 + ((st * BN + nt * 32 + 16 * ct) * PITCH); },
+                a16);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) a16[mt][nt].to32(acc[mt][nt]);
+        } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1097,6 +1153,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
             [&](int st, int nt) { const int tc = st / KSEG, ks = st % KSEG;
                                   return bb + ((tc * BN + nt * 32) * PITCH + ks * KSTRIDE); },
             acc);
+        }
         WS_STAMP();  // 5: MFMAs done (issued)
         const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int ty0 = tiy * TH, x = tix * PT_TW + r;
@@ -2332,6 +2389,15 @@ static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t s
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_igemm_kernel<T, 32, SWAP>), grid, dim3(CONV_THREADS), 0, st, p);
 }
 
+// v_mfma_f32_16x16x32 forms (conv_epilogue.h: Acc16) of the weight-stationary and LDS-DMA kernels; FALNET_MFMA16=0 selects the
+// 32x32x16 forms (A/B).  Launched alone with warm caches the two forms are equal (64 -> 64 @256x512: 96.0 vs 93.9 us), inside the training
+// step the 16x16x32 form is faster: same-box A/B, three alternations, weight-stationary kernel only: 1216 -> 1231 pairs/s (+1.2 %),
+// kernel-time sum 7.45 -> 7.35 ms.  (MI355X_MICROARCH.md, MFMA shape: the chip holds a higher clock on this shape under load.)
+static bool falnet_mfma16_enabled() {
+    static const bool on = [] { const char* e = getenv("FALNET_MFMA16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // The dispatcher's decision for one launch; shared by falnet_conv2d and falnet_conv2d_kernel_name.
 struct ConvChoice {
     int patch;               // 1: conv3x3_patch_kernel, 0: conv_igemm_kernel, 2: conv3x3_ws_kernel (kcb = chunks)
@@ -2481,7 +2547,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
     else if (c.patch == 2)
-        snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb);
+        snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32));
     else if (c.patch)
         snprintf(buf, len, "_Z20conv3x3_patch_kernelI%sLi%dELi%dELi%dELb%dELi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, c.tps, c.adb, c.th, c.nwaves);
     else
@@ -2524,7 +2590,9 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         if (gx < 1) gx = 1;
         if (gx > ntiles) gx = ntiles;
         const dim3 grid((unsigned)gx, (unsigned)ny);
-#define LAUNCH_WS(T, BN, NCH) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip)
+        const bool m16 = falnet_mfma16_enabled();  // v_mfma_f32_16x16x32 form (16-bit types)
+#define LAUNCH_WS(T, BN, NCH) do { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
+                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); } while (0)
 #define WS_TABLE(T)                                                                                 \
     if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(T, 64, 2); else LAUNCH_WS(T, 64, 1); }              \
     else { if (c.kcb == 2) LAUNCH_WS(T, 32, 2); else LAUNCH_WS(T, 32, 1); }

@@ -89,6 +89,37 @@ __device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int 
         }
     }
 }
+// ---- 16x16x32 MFMA form of a 32 (channels) x 32 (positions) tile -------------------------------------------------------------
+// v_mfma_f32_16x16x32 holds the chip's clock higher than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, MFMA shape: 1.12-1.15x
+// on random data; measured here by issuing the same operands through two 16x16x32: weight-stationary kernel 850 -> 1040 TFLOP/s).
+// A 32x32 tile becomes 2 (channel halves ct) x 2 (position halves pt) MFMAs, K = 32 each; lane (p = lane & 15, g = lane >> 4) supplies
+// row / column p and K block g of an operand and receives D[4g + f][p] in register f.  To land in epilogue_direct's layout (position
+// 16 pt + p on lane 32 h + 16 pt + p, register 4 m + f = channel 8 m + 4 h + f) WITHOUT a data-dependent shuffle network:
+//   * the weight operand of half ct puts channel 16 ct + 8 e + 4 h' + f on its row i = 8 h' + 4 e + f (m16_row_channel below), so lane row
+//     g of the result holds the registers of lane half h' = g >> 1, group e = g & 1;
+//   * one v_permlane16_swap per register exchanges the odd lane rows of the pt = 0 result with the even lane rows of the pt = 1 result,
+//     after which every lane holds values of ITS OWN position only: four swaps per (ct, 32x32 tile).
+__device__ __forceinline__ int m16_row_channel(int i) { return ((i >> 2) & 1) * 8 + (i >> 3) * 4 + (i & 3); }  // within a 16-channel half
+struct Acc16 {        // one 32x32 tile as four 16x16 results
+    f32x4_t t[2][2];  // [ct][pt]
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) t[ct][pt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void to32(f32x16_t& v) const {  // -> the 32x32x16 accumulator layout epilogue_direct expects
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[ct][0][f]), __float_as_uint(t[ct][1][f]), false, false);
+                v[4 * (2 * ct) + f] = __uint_as_float(r[0]);
+                v[4 * (2 * ct + 1) + f] = __uint_as_float(r[1]);
+            }
+    }
+};
+
 // activation / activation-gradient on one 16-value tile: the (workgroup-uniform) kind is switched ONCE per tile
 __device__ __forceinline__ void act16(float (&v)[16], int act) {
     if (act == FALNET_ACT_ELU) {
