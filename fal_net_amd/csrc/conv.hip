@@ -2394,7 +2394,7 @@ static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t s
 // step the 16x16x32 form is faster: same-box A/B, three alternations, weight-stationary kernel only: 1216 -> 1231 pairs/s (+1.2 %),
 // kernel-time sum 7.45 -> 7.35 ms.  (MI355X_MICROARCH.md, MFMA shape: the chip holds a higher clock on this shape under load.)
 // The same conversion of the LDS-DMA kernel (half steps (tap, channel half), positions of a tap shared by both halves) passed every test and
-// measured neutral in the step (1264 vs 1268 pairs/s): not kept.
+// measured neutral in the step (1264 vs 1268 pairs/s), and so did the nine-tap stages of the halo-patch kernel (1258 vs 1257): not kept.
 static bool falnet_mfma16_enabled() {
     static const bool on = [] { const char* e = getenv("FALNET_MFMA16"); return !(e && e[0] == '0'); }();
     return on;
