@@ -3,6 +3,7 @@
 //                                 compute layout (FAL_netB.py:200 input; loss_functions.py:36 VGG input)
 //   upsample_bwd                : adjoint of F.interpolate(mode='nearest') (FAL_netB.py:58)
 //   maxpool2 fwd/bwd            : torchvision VGG19 features[4,9,18] (loss_functions.py:21-29)
+#include <stdlib.h>
 #include "common.h"
 
 #define EW_THREADS 256
@@ -306,10 +307,36 @@ __global__ __launch_bounds__(EW_THREADS) void gemm_f32_small_kernel(const float*
     }
 }
 
+// Long-K, few-outputs products (dW1x1 = dWc W3x3^T: 49 x 49 outputs, K = 864): one WAVE per output element, lanes stride over K
+// (coalesced when both operands are contiguous along K) and a wave reduction -- the thread-per-output form walked K serially with
+// two uncoalesced loads per step on 10 workgroups: 140 us on the weight-gradient stream of every training step, now ~5 us.
+__global__ __launch_bounds__(EW_THREADS) void gemm_f32_small_wave_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                                                         const float* __restrict__ Bm, int64_t sbk, int64_t sbn,
+                                                                         float* __restrict__ C, int M, int N, int K, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < (int64_t)M * N; i += nwaves) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float* a = A + m * sam;
+        const float* b = Bm + n * sbn;
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(a[k * sak], b[k * sbk], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) C[i] = accumulate ? C[i] + acc : acc;
+    }
+}
+
 extern "C" int falnet_gemm_f32_small(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
                                      int M, int N, int K, int accumulate, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (int64_t)M * N * K <= (1ll << 32), "gemm_f32_small: bad argument (small products only)");
+    static const bool wave_form = [] { const char* e = getenv("FALNET_GEMM_WAVE"); return !(e && e[0] == '0'); }();
+    if (wave_form && K >= 256 && (int64_t)M * N <= 65536) {
+        const int64_t waves = (int64_t)M * N;
+        hipLaunchKernelGGL(gemm_f32_small_wave_kernel, dim3((unsigned)((waves + 3) / 4 > 4096 ? 4096 : (waves + 3) / 4)), dim3(EW_THREADS), 0,
+                           (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C, M, N, K, accumulate);
+        FALNET_RETURN_LAUNCH();
+    }
     hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(ew_grid((int64_t)M * N)), dim3(EW_THREADS), 0, (hipStream_t)stream, A, sam, sak, B, sbk, sbn, C,
                        M, N, K, accumulate);
     FALNET_RETURN_LAUNCH();
