@@ -25,7 +25,8 @@
  *     reference API (images, disparity, synthesised view, MED logits) are planar NCHW f32.
  *   - kernel-selection switches (A/B and tests; read once from the environment): FALNET_DISABLE_PATCH,
  *     FALNET_PATCH_KCB (conv.hip), FALNET_WR_FORM / FALNET_WR_ABL (wgrad_rows.hip), FALNET_HEAD_V1,
- *     FALNET_HEAD_BWD_V1, FALNET_HEAD_PAIR, FALNET_HEAD_FWD2, FALNET_HEAD_BWD2, FALNET_HEAD_WAVE (MED head).
+ *     FALNET_HEAD_BWD_V1, FALNET_HEAD_PAIR, FALNET_HEAD_FWD2, FALNET_HEAD_BWD2, FALNET_HEAD_WAVE (MED head), FALNET_MFMA16 (16x16x32 form of the
+ *     weight-stationary kernel), FALNET_GEMM_WAVE (small f32 GEMM).
  */
 #ifndef FALNET_HIP_H
 #define FALNET_HIP_H
