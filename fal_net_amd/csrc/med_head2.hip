@@ -3,13 +3,13 @@
 // per (pixel, plane) with the VALU busy 97 % / 75 % of the launch, LDS 12 / 16 dwords per (pixel, plane) -- instruction bound at
 // 2.4 TB/s, not HBM bound.  Two rewrites live here:
 //
-//  (1) strided form, W <= 1024, W % 4 == 0 (`*_lds2_kernel`, the Stage-1/2 shapes): the same thread -> pixel map (t, t+256, ..) on a
+//  (1) strided form, W <= 2048 (512 threads above 1024), W % 4 == 0 (`*_lds2_kernel`: the Stage-1/2 shapes; at 384x1280 the forward): the same thread -> pixel map (t, t+256, ..) on a
 //      diet: plane table in VGPRs read by v_readlane (no LDS table, no dependent round trip per plane), logits pre-scaled by log2(e)
 //      while staged (bare v_exp_f32), mixes as t0 + a (t1 - t0), tap index once per (pixel, plane), no per-plane branches, compile-time
 //      pitch for W = 512; backward: the five per-source values interleaved ([s+1][5]: both sources of a pixel behind ONE address,
 //      conflict free), selects instead of divergent branches, 16-bit output in 32-B sectors.  46 / 61 VALU per (pixel, plane):
 //      forward 101 -> 86 us, backward 200 -> 160 us.
-//  (2) wave-neighbour form, 1024 < W <= 1984 (`*_wave_kernel`, the 384x1280 high-resolution shape, which only had the first kernels):
+//  (2) wave-neighbour form, 1024 < W <= 1984 (`*_wave_kernel`; used for the 16-bit backward of the 384x1280 high-resolution shape):
 //      the plane shift k_n is the same for every pixel, so the second tap of pixel x is the FIRST tap of pixel x+1 -- one lane over.
 //      A wave owns 64 consecutive columns, every lane reads ONE tap from LDS and takes its neighbour's with a DPP wavefront shift; the
 //      last lane has no neighbour, so waves overlap by one column (63 outputs per wave forward).  Backward: the adjoint of the two-tap
@@ -27,6 +27,7 @@
 
 #include "common.h"
 
+bool falnet_head_wave_applicable(int W);
 #define HW_MAXT 1024  // one wave per unit of 62 / 63 output columns: 64 * ceil(units / R) threads, R rounds only for rows wider than 16 units
 #define HW_CH 8  // plane rows staged per chunk = planes per online-softmax rescale = channels per gradient store
 
@@ -385,8 +386,8 @@ __global__ __launch_bounds__(HW_MAXT) void med_head_bwd_wave_kernel(
 //     back when they are stored);  * the bilinear mixes as t0 + a (t1 - t0);  * tap index computed once per (pixel, plane);
 //   * compile-time row pitch (WPC) for the common widths: every LDS offset is an immediate;  * no per-plane branches (planes >= N of
 //     the last chunk are masked once), so a chunk's LDS reads issue back to back.
-template <int PPT, int WPC>
-__global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
+template <int PPT, int WPC, int NT>
+__global__ __launch_bounds__(NT) void med_head_fwd_lds2_kernel(
     const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
     const float* __restrict__ max_disp, float* __restrict__ disp, float* __restrict__ p_im0,
     float* __restrict__ stats, int N, int H, int W) {
@@ -401,12 +402,12 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
     const bool want_pan = p_im0 != nullptr;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-    for (int i = threadIdx.x; i < 3 * w4; i += 256) {
+    for (int i = threadIdx.x; i < 3 * w4; i += NT) {
         const int c = i / w4, q = i - c * w4;
         *reinterpret_cast<float4*>(lrow + c * WP + 4 * q) =
             want_pan ? reinterpret_cast<const float4*>(left + ((int64_t)b * 3 + c) * HW + (int64_t)y * W)[q] : zero4;
     }
-    for (int i = threadIdx.x; i < (3 + HW_CH) * ((WP - W) >> 2); i += 256) {  // zero tail of every LDS row
+    for (int i = threadIdx.x; i < (3 + HW_CH) * ((WP - W) >> 2); i += NT) {  // zero tail of every LDS row
         const int per = (WP - W) >> 2;
         *reinterpret_cast<float4*>(lrow + (i / per) * WP + W + 4 * (i % per)) = zero4;
     }
@@ -418,12 +419,12 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
         m0[q] = mw[q] = -INFINITY;
         z0[q] = dacc[q] = zw[q] = p0[q] = p1[q] = p2[q] = 0.f;
     }
-    constexpr int PF = (HW_CH * PPT + 3) / 4;  // float4 per thread: HW_CH rows of W <= 256 PPT floats over 256 threads
+    constexpr int PF = (HW_CH * PPT + 3) / 4;  // float4 per thread: HW_CH rows of W <= NT PPT floats over NT threads
     float4 pf[PF];
     auto fetch = [&](int n0) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int i = threadIdx.x + u * 256;
+            const int i = threadIdx.x + u * NT;
             float4 v = zero4;
             if (i < HW_CH * w4) {
                 const int j = i / w4, q = i - j * w4;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
         __syncthreads();  // previous chunk fully consumed (and the left row / tails written)
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int i = threadIdx.x + u * 256;
+            const int i = threadIdx.x + u * NT;
             if (i < HW_CH * w4) {
                 const int j = i / w4, q = i - j * w4;
                 *reinterpret_cast<float4*>(prow + j * WP + 4 * q) =
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
         const bool partial = n0 + HW_CH > N;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int x = threadIdx.x + q * 256;
+            const int x = threadIdx.x + q * NT;
             if (x >= W) continue;
             float l0[HW_CH], lw[HW_CH];
             int i0[HW_CH];
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
     }
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int x = threadIdx.x + q * 256;
+        const int x = threadIdx.x + q * NT;
         if (x >= W) continue;
         const int64_t pix = (int64_t)y * W + x;
         if (disp) disp[(int64_t)b * HW + pix] = dacc[q] / z0[q];
@@ -532,16 +533,21 @@ __global__ __launch_bounds__(256) void med_head_fwd_lds2_kernel(
 bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
                                  float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream) {
     static const bool off = [] { const char* e = getenv("FALNET_HEAD_FWD2"); return e && e[0] == '0'; }();
-    if (off || (W & 3) || W < 4 || W > 1024 || N > 64 + HW_CH) return false;
-    const int ppt = (W + 255) / 256;
+    if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;  // (plane table: 128 entries, read up to N - 1 + HW_CH - 1)
     const int wp = (W + 7) & ~3;
     const size_t lds = (size_t)(3 + HW_CH) * wp * sizeof(float);
-#define HW_L(P, C) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_fwd_lds2_kernel<P, C>), dim3(B * H), dim3(256), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, N, H, W)
-    if (W == 512) HW_L(2, 516);
-    else if (ppt == 1) HW_L(1, 0);
-    else if (ppt == 2) HW_L(2, 0);
-    else if (ppt == 3) HW_L(3, 0);
-    else HW_L(4, 0);
+#define HW_L(P, C, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_fwd_lds2_kernel<P, C, NT>), dim3(B * H), dim3(NT), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, N, H, W)
+    if (W > 1024) {  // 512 threads: the 384 x 1280 shape (3 pixels per thread)
+        const int ppt = (W + 511) / 512;
+        if (ppt <= 3) HW_L(3, 0, 512); else HW_L(4, 0, 512);
+        return true;
+    }
+    const int ppt = (W + 255) / 256;
+    if (W == 512) HW_L(2, 516, 256);
+    else if (ppt == 1) HW_L(1, 0, 256);
+    else if (ppt == 2) HW_L(2, 0, 256);
+    else if (ppt == 3) HW_L(3, 0, 256);
+    else HW_L(4, 0, 256);
 #undef HW_L
     return true;
 }
@@ -554,8 +560,8 @@ bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const fl
 // output pixel are TEN consecutive dwords behind one address (lane stride 5 dwords: conflict free).
 // (Measured and dropped: one pixel per thread with the pixel's whole 128-B output line held in registers and written at the end --
 // no faster than the paired 32-B stores, 167 vs 169 us.)
-template <typename OUT, int PPT>
-__global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
+template <typename OUT, int PPT, int NT>
+__global__ __launch_bounds__(NT) void med_head_bwd_lds2_kernel(
     const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
     const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
     const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
     const float* st = stats + (int64_t)b * 4 * HW + rowoff;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr float LOG2E = 1.4426950408889634f;
-    for (int i = threadIdx.x; i < W + 1; i += 256) {
+    for (int i = threadIdx.x; i < W + 1; i += NT) {
         const int sx = i - 1;
         float u0 = 0.f, u1 = 0.f, u2 = 0.f, v = 0.f, m = 0.f;
         if (has_pan && sx >= 0) {
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
         float* e = src5 + i * 5;
         e[0] = u0, e[1] = u1, e[2] = u2, e[3] = v, e[4] = m;
     }
-    for (int i = threadIdx.x; i < 2 * HW_CH; i += 256)  // zero head / tail of every plane row
+    for (int i = threadIdx.x; i < 2 * HW_CH; i += NT)  // zero head / tail of every plane row
         *reinterpret_cast<float4*>(prow + (i >> 1) * PP + ((i & 1) ? W + 4 : 0)) = zero4;
     const float* Lrow = dlog0 + (int64_t)b * N * HW + rowoff;
     OUT* Grow = gdlog0 + ((int64_t)b * HW + rowoff) * cpad;
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
     float lm[PPT][3], lc[PPT][3], dm[PPT][3], dc[PPT][3], m0[PPT], gr[PPT], dsp[PPT];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
-        const int x = threadIdx.x + q * 256;
+        const int x = threadIdx.x + q * NT;
         m0[q] = gr[q] = dsp[q] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) lm[q][c] = lc[q][c] = dm[q][c] = dc[q][c] = 0.f;
@@ -627,7 +633,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
     auto fetch = [&](int n0) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const int i = threadIdx.x + u * 256;
+            const int i = threadIdx.x + u * NT;
             float4 v = zero4;
             if (i < HW_CH * w4) {
                 const int j = i / w4, q4 = i - j * w4;
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
         if (n0 < N) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int i = threadIdx.x + u * 256;
+                const int i = threadIdx.x + u * NT;
                 if (i < HW_CH * w4) {
                     const int j = i / w4, q4 = i - j * w4;
                     *reinterpret_cast<float4*>(prow + j * PP + 4 + 4 * q4) =
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(256) void med_head_bwd_lds2_kernel(
         const bool second = ((n0 / HW_CH) & 1) != 0;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int x = threadIdx.x + q * 256;
+            const int x = threadIdx.x + q * NT;
             if (x >= W) continue;
             float gv[HW_CH];
             if (n0 < N) {  // block-uniform
@@ -714,12 +720,17 @@ static void bwd_lds2_launch_t(const float* dlog0, const float* left, const float
                               const float* p_im0, const float* stats, const float* gdisp, const float* gpan, T* gdlog0, int cpad, int B, int N,
                               int H, int W, hipStream_t stream) {
     const size_t lds = (size_t)HW_CH * ((W + 11) & ~3) * sizeof(float) + (size_t)(W + 1) * 5 * sizeof(float);
+#define HW_L(P, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_lds2_kernel<T, P, NT>), dim3(B * H), dim3(NT), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, gdisp, gpan, gdlog0, N, H, W, cpad)
+    if (W > 1024) {
+        const int ppt = (W + 511) / 512;
+        if (ppt <= 3) HW_L(3, 512); else HW_L(4, 512);
+        return;
+    }
     const int ppt = (W + 255) / 256;
-#define HW_L(P) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_bwd_lds2_kernel<T, P>), dim3(B * H), dim3(256), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, gdisp, gpan, gdlog0, N, H, W, cpad)
-    if (ppt == 1) HW_L(1);
-    else if (ppt == 2) HW_L(2);
-    else if (ppt == 3) HW_L(3);
-    else HW_L(4);
+    if (ppt == 1) HW_L(1, 256);
+    else if (ppt == 2) HW_L(2, 256);
+    else if (ppt == 3) HW_L(3, 256);
+    else HW_L(4, 256);
 #undef HW_L
 }
 
@@ -727,7 +738,9 @@ bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const fl
                                  const float* p_im0, const float* stats, const float* gdisp, const float* gpan, void* gdlog0, int cpad,
                                  int dtype, int B, int N, int H, int W, hipStream_t stream) {
     static const bool off = [] { const char* e = getenv("FALNET_HEAD_BWD2"); return e && e[0] == '0'; }();
-    if (off || (W & 3) || W < 4 || W > 1024 || N > 64 + HW_CH) return false;
+    if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;
+    // 8 x 384 x 1280, N = 96: 16-bit gradient 991 us here vs 955 us on the wave-neighbour kernel (f32: 1277 vs 1357; forward 652 vs 1097)
+    if (W > 1024 && dtype != FALNET_F32 && falnet_head_wave_applicable(W)) return false;
 #define HW_D(T) bwd_lds2_launch_t<T>(dlog0, left, min_disp, max_disp, disp, p_im0, stats, gdisp, gpan, (T*)gdlog0, cpad, B, N, H, W, stream)
     FALNET_DISPATCH_DTYPE(dtype, HW_D);
 #undef HW_D
