@@ -28,6 +28,17 @@ __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __rest
                                                              int64_t total, float scale, float* out) {
     __shared__ float red[16];
     float acc = 0.f;
+    if (!mask && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {  // 16-byte loads
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        const float4* b4 = reinterpret_cast<const float4*>(b);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 x = a4[i], y = b4[i];
+            acc += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+        }
+        const float s4 = block_sum(acc, red);
+        if (threadIdx.x == 0) atomicAdd(out, s4 * scale);
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float d = fabsf(a[i] - b[i]);
         if (mask) {
@@ -162,43 +173,85 @@ __device__ __forceinline__ float wy_at(const SmoothArgs& s, int b, int y, int x)
 }
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+// Tiled form: a workgroup stages the grayscale and disparity of a 4 x 64 tile (+ halo 2 / 1) in LDS ONCE and every pixel reads its
+// neighbours from there -- the first kernels recomputed the gray value of every neighbour from three planar loads with bounds checks
+// (23 loads per pixel forward, 59 backward: 25 us each for 13 MB of input).
+#define SM_TY 4
+#define SM_TX 64
+#define SM_GW (SM_TX + 4)
+#define SM_GH (SM_TY + 4)
+#define SM_DW (SM_TX + 2)
+#define SM_DH (SM_TY + 2)
+__device__ __forceinline__ void smooth_stage_tile(const SmoothArgs& s, int b, int ty0, int tx0, float* gt, float* dt) {
+    for (int i = threadIdx.x; i < SM_GH * SM_GW; i += blockDim.x) gt[i] = gray_at(s, b, ty0 - 2 + i / SM_GW, tx0 - 2 + i % SM_GW);
+    for (int i = threadIdx.x; i < SM_DH * SM_DW; i += blockDim.x) dt[i] = disp_at(s, b, ty0 - 1 + i / SM_DW, tx0 - 1 + i % SM_DW);
+}
+// weights at tile-local (ly, lx) (may be -1 .. SM_T? : one pixel outside the tile)
+__device__ __forceinline__ float tile_wx(const float* gt, float gamma, int ly, int lx) {
+    const float* g = gt + (ly + 2) * SM_GW + lx + 2;
+    return __expf(-gamma * fabsf(-g[-1] + 2.f * g[0] - g[1]));
+}
+__device__ __forceinline__ float tile_wy(const float* gt, float gamma, int ly, int lx) {
+    const float* g = gt + (ly + 2) * SM_GW + lx + 2;
+    return __expf(-gamma * fabsf(-g[-SM_GW] + 2.f * g[0] - g[SM_GW]));
+}
+
 __global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, float scale, float* out) {
     __shared__ float red[16];
+    __shared__ float gt[SM_GH * SM_GW], dt[SM_DH * SM_DW];
     const int Wc = s.x1 - s.x0;
-    const int64_t total = (int64_t)s.B * s.H * Wc;
+    const int tiles_x = (Wc + SM_TX - 1) / SM_TX, tiles_y = (s.H + SM_TY - 1) / SM_TY;
+    const int ntiles = s.B * tiles_y * tiles_x;
+    const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = s.x0 + (int)(i % Wc), y = (int)((i / Wc) % s.H), b = (int)(i / ((int64_t)Wc * s.H));
-        const float d = disp_at(s, b, y, x);
-        const float ax = fabsf(d - disp_at(s, b, y, x + 1)) + fabsf(d - disp_at(s, b, y, x - 1));
-        const float ay = fabsf(d - disp_at(s, b, y - 1, x)) + fabsf(d - disp_at(s, b, y + 1, x));
-        acc += ax * wx_at(s, b, y, x) + ay * wy_at(s, b, y, x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx0 = s.x0 + (tile % tiles_x) * SM_TX, ty0 = ((tile / tiles_x) % tiles_y) * SM_TY, b = tile / (tiles_x * tiles_y);
+        __syncthreads();  // previous tile consumed
+        smooth_stage_tile(s, b, ty0, tx0, gt, dt);
+        __syncthreads();
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x < s.x1 && y < s.H) {
+            const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
+            const float d = dp[0];
+            const float ax = fabsf(d - dp[1]) + fabsf(d - dp[-1]);
+            const float ay = fabsf(d - dp[-SM_DW]) + fabsf(d - dp[SM_DW]);
+            acc += ax * tile_wx(gt, s.gamma, ly, lx) + ay * tile_wy(gt, s.gamma, ly, lx);
+        }
     }
     const float r = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(out, r * scale);
 }
 
 // gather form of the adjoint: every pixel sums its own four terms and the one term each of its
-// four in-window neighbours holds on it.
+// four in-window neighbours holds on it.  Tiles cover all W columns (zero outside the window).
 __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, float scale,
                                                                  const float* __restrict__ gscale,
                                                                  float* __restrict__ gdisp, int accumulate) {
+    __shared__ float gt[SM_GH * SM_GW], dt[SM_DH * SM_DW];
     const float gs = scale * (gscale ? gscale[0] : 1.f);
-    const int64_t total = (int64_t)s.B * s.H * s.W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % s.W), y = (int)((i / s.W) % s.H), b = (int)(i / ((int64_t)s.W * s.H));
+    const int tiles_x = (s.W + SM_TX - 1) / SM_TX, tiles_y = (s.H + SM_TY - 1) / SM_TY;
+    const int ntiles = s.B * tiles_y * tiles_x;
+    const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx0 = (tile % tiles_x) * SM_TX, ty0 = ((tile / tiles_x) % tiles_y) * SM_TY, b = tile / (tiles_x * tiles_y);
+        __syncthreads();
+        const bool any = tx0 < s.x1 && tx0 + SM_TX > s.x0;  // block-uniform: tile touches the window
+        if (any) smooth_stage_tile(s, b, ty0, tx0, gt, dt);
+        __syncthreads();
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= s.W || y >= s.H) continue;
         float g = 0.f;
         if (x >= s.x0 && x < s.x1) {
-            const float d = disp_at(s, b, y, x);
-            const float dl = disp_at(s, b, y, x - 1), dr = disp_at(s, b, y, x + 1);
-            const float du = disp_at(s, b, y - 1, x), dd = disp_at(s, b, y + 1, x);
-            g += (sgn(d - dr) + sgn(d - dl)) * wx_at(s, b, y, x) + (sgn(d - du) + sgn(d - dd)) * wy_at(s, b, y, x);
-            if (x - 1 >= s.x0) g -= sgn(dl - d) * wx_at(s, b, y, x - 1);  // left pixel's dx_d  = d[x-1]-d[x]
-            if (x + 1 < s.x1) g -= sgn(dr - d) * wx_at(s, b, y, x + 1);   // right pixel's dx1_d = d[x+1]-d[x]
-            if (y - 1 >= 0) g -= sgn(du - d) * wy_at(s, b, y - 1, x);     // upper pixel's dy1_d = d[y-1]-d[y]
-            if (y + 1 < s.H) g -= sgn(dd - d) * wy_at(s, b, y + 1, x);    // lower pixel's dy_d  = d[y+1]-d[y]
+            const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
+            const float d = dp[0], dl = dp[-1], dr = dp[1], du = dp[-SM_DW], dd = dp[SM_DW];
+            g += (sgn(d - dr) + sgn(d - dl)) * tile_wx(gt, s.gamma, ly, lx) + (sgn(d - du) + sgn(d - dd)) * tile_wy(gt, s.gamma, ly, lx);
+            if (x - 1 >= s.x0) g -= sgn(dl - d) * tile_wx(gt, s.gamma, ly, lx - 1);  // left pixel's dx_d  = d[x-1]-d[x]
+            if (x + 1 < s.x1) g -= sgn(dr - d) * tile_wx(gt, s.gamma, ly, lx + 1);   // right pixel's dx1_d = d[x+1]-d[x]
+            if (y - 1 >= 0) g -= sgn(du - d) * tile_wy(gt, s.gamma, ly - 1, lx);     // upper pixel's dy1_d = d[y-1]-d[y]
+            if (y + 1 < s.H) g -= sgn(dd - d) * tile_wy(gt, s.gamma, ly + 1, lx);    // lower pixel's dy_d  = d[y+1]-d[y]
             g *= gs;
         }
+        const int64_t i = ((int64_t)b * s.H + y) * s.W + x;
         gdisp[i] = accumulate ? gdisp[i] + g : g;
     }
 }
@@ -401,7 +454,8 @@ extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int
     FALNET_CHECK_ARG(img && disp && out && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
-    hipLaunchKernelGGL(smooth_fwd_kernel, dim3(red_grid((int64_t)B * H * (x1 - x0))), dim3(RED_THREADS), 0,
+    const int64_t ftiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((x1 - x0 + SM_TX - 1) / SM_TX);
+    hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(ftiles < RED_BLOCKS ? ftiles : RED_BLOCKS)), dim3(RED_THREADS), 0,
                        (hipStream_t)stream, s, scale, out);
     FALNET_RETURN_LAUNCH();
 }
@@ -411,7 +465,8 @@ extern "C" int falnet_smooth_bwd(const float* img, const float* disp, int B, int
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(img && disp && gdisp && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_bwd: bad argument");
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
-    hipLaunchKernelGGL(smooth_bwd_kernel, dim3(red_grid((int64_t)B * H * W) * 4), dim3(RED_THREADS), 0,
+    const int64_t btiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((W + SM_TX - 1) / SM_TX);
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)(btiles < 4 * RED_BLOCKS ? btiles : 4 * RED_BLOCKS)), dim3(RED_THREADS), 0,
                        (hipStream_t)stream, s, scale, gscale, gdisp, accumulate);
     FALNET_RETURN_LAUNCH();
 }
