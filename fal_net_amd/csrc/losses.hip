@@ -14,6 +14,9 @@ static inline int red_grid(int64_t work_items) {
     return (int)(g < 1 ? 1 : (g > RED_BLOCKS ? RED_BLOCKS : g));
 }
 
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
 static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
@@ -25,21 +28,26 @@ static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
 // ------------------------------------------------------------------ L1 (loss_functions.py:53)
 __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ mask, int C, int64_t HW,
-                                                             int64_t total, float scale, float* out) {
+                                                             int64_t total, float scale, float* out,
+                                                             const float* __restrict__ gscale = nullptr, float* __restrict__ ga = nullptr) {
     __shared__ float red[16];
     float acc = 0.f;
-    if (!mask && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {  // 16-byte loads
+    const float gs = ga ? scale * (gscale ? gscale[0] : 1.f) : 0.f;  // ga: the gradient gscale * scale * sign(a - b) in the same pass (unmasked)
+    if (!mask && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(ga)) & 15) == 0) {  // 16-byte loads
         const float4* a4 = reinterpret_cast<const float4*>(a);
         const float4* b4 = reinterpret_cast<const float4*>(b);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += (int64_t)gridDim.x * blockDim.x) {
             const float4 x = a4[i], y = b4[i];
-            acc += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+            if (ga) reinterpret_cast<float4*>(ga)[i] = make_float4(sgn(d0) * gs, sgn(d1) * gs, sgn(d2) * gs, sgn(d3) * gs);
         }
         const float s4 = block_sum(acc, red);
         if (threadIdx.x == 0) atomicAdd(out, s4 * scale);
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (ga) ga[i] = sgn(a[i] - b[i]) * gs;
         float d = fabsf(a[i] - b[i]);
         if (mask) {
             const int64_t bi = i / (C * HW), p = i % HW;
@@ -102,11 +110,15 @@ __device__ __forceinline__ void put8(float* p, const float (&v)[8]) {
 }
 
 // 8 elements (16 B bf16 / 32 B f32) per thread and iteration when `total` and the pointers allow (VEC), else one
+// ga != nullptr: the gradient gscale[0] * 2 * gsc * (a - b) is written in the same pass (the fused training step knows its upstream
+// scalars before the forward runs: one read of the feature maps instead of two)
 template <typename T, bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
-                                                              int64_t total, float scale, float* out) {
+                                                              int64_t total, float scale, float* out,
+                                                              const float* __restrict__ gscale = nullptr, float gsc = 0.f, T* __restrict__ ga = nullptr) {
     __shared__ float red[16];
     float acc = 0.f;
+    const float gs = ga ? 2.f * gsc * (gscale ? gscale[0] : 1.f) : 0.f;
     if constexpr (VEC) {
         const int64_t n8 = total >> 3;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -114,11 +126,17 @@ __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restric
             diff8(a + 8 * i, b + 8 * i, d);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc += d[j] * d[j];
+            if (ga) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] *= gs;
+                put8(ga + 8 * i, d);
+            }
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
             const float d = to_f32(a[i]) - to_f32(b[i]);
             acc += d * d;
+            if (ga) ga[i] = from_f32<T>(gs * d);
         }
     }
     const float s = block_sum(acc, red);
@@ -171,7 +189,6 @@ __device__ __forceinline__ float wy_at(const SmoothArgs& s, int b, int y, int x)
     const float g = -gray_at(s, b, y - 1, x) + 2.f * gray_at(s, b, y, x) - gray_at(s, b, y + 1, x);
     return __expf(-s.gamma * fabsf(g));
 }
-__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 // Tiled form: a workgroup stages the grayscale and disparity of a 4 x 64 tile (+ halo 2 / 1) in LDS ONCE and every pixel reads its
 // neighbours from there -- the first kernels recomputed the gray value of every neighbour from three planar loads with bounds checks
@@ -224,10 +241,13 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, f
 
 // gather form of the adjoint: every pixel sums its own four terms and the one term each of its
 // four in-window neighbours holds on it.  Tiles cover all W columns (zero outside the window).
+// fwd_out != nullptr: the loss itself (smooth_fwd_kernel's sum, times scale) is accumulated from the same tiles
 __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, float scale,
                                                                  const float* __restrict__ gscale,
-                                                                 float* __restrict__ gdisp, int accumulate) {
+                                                                 float* __restrict__ gdisp, int accumulate, float* fwd_out = nullptr) {
     __shared__ float gt[SM_GH * SM_GW], dt[SM_DH * SM_DW];
+    __shared__ float red[16];
+    float facc = 0.f;
     const float gs = scale * (gscale ? gscale[0] : 1.f);
     const int tiles_x = (s.W + SM_TX - 1) / SM_TX, tiles_y = (s.H + SM_TY - 1) / SM_TY;
     const int ntiles = s.B * tiles_y * tiles_x;
@@ -244,7 +264,9 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, f
         if (x >= s.x0 && x < s.x1) {
             const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
             const float d = dp[0], dl = dp[-1], dr = dp[1], du = dp[-SM_DW], dd = dp[SM_DW];
-            g += (sgn(d - dr) + sgn(d - dl)) * tile_wx(gt, s.gamma, ly, lx) + (sgn(d - du) + sgn(d - dd)) * tile_wy(gt, s.gamma, ly, lx);
+            const float wx = tile_wx(gt, s.gamma, ly, lx), wy = tile_wy(gt, s.gamma, ly, lx);
+            g += (sgn(d - dr) + sgn(d - dl)) * wx + (sgn(d - du) + sgn(d - dd)) * wy;
+            if (fwd_out) facc += (fabsf(d - dr) + fabsf(d - dl)) * wx + (fabsf(d - du) + fabsf(d - dd)) * wy;
             if (x - 1 >= s.x0) g -= sgn(dl - d) * tile_wx(gt, s.gamma, ly, lx - 1);  // left pixel's dx_d  = d[x-1]-d[x]
             if (x + 1 < s.x1) g -= sgn(dr - d) * tile_wx(gt, s.gamma, ly, lx + 1);   // right pixel's dx1_d = d[x+1]-d[x]
             if (y - 1 >= 0) g -= sgn(du - d) * tile_wy(gt, s.gamma, ly - 1, lx);     // upper pixel's dy1_d = d[y-1]-d[y]
@@ -253,6 +275,11 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, f
         }
         const int64_t i = ((int64_t)b * s.H + y) * s.W + x;
         gdisp[i] = accumulate ? gdisp[i] + g : g;
+    }
+    if (fwd_out) {  // block-uniform
+        __syncthreads();
+        const float r = block_sum(facc, red);
+        if (threadIdx.x == 0) atomicAdd(fwd_out, r * scale);
     }
 }
 
@@ -532,5 +559,42 @@ extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, voi
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(src && out && B > 0 && n > 0, "rowmax: bad argument");
     hipLaunchKernelGGL(rowmax_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, src, out, n);
+    FALNET_RETURN_LAUNCH();
+}
+
+// ---- loss and gradient in ONE pass (the fused training step: upstream scalars are known before the forward runs) ----------------
+extern "C" int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale,
+                                 float* ga, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(a && b && out && ga && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd: bad argument");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
+                       out, gscale, ga);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale_out, float* out, float scale_grad,
+                                  const float* gscale, void* ga, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(a && b && out && ga && npix > 0 && Cpad > 0, "mse_fwd_bwd: bad argument");
+    const int64_t total = npix * Cpad;
+    const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
+    const int grid = red_grid(vec ? total / 8 : total);
+#define MSE_FB(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale_out, out, gscale, scale_grad, (T*)ga)
+#define MSE_FB_T(T) if (vec) MSE_FB(T, true); else MSE_FB(T, false)
+    FALNET_DISPATCH_DTYPE(dtype, MSE_FB_T);
+#undef MSE_FB_T
+#undef MSE_FB
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale,
+                                     float* out, const float* gscale, float* gdisp, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(img && disp && out && gdisp && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd_bwd: bad argument");
+    SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
+    const int64_t btiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((W + SM_TX - 1) / SM_TX);
+    hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)(btiles < RED_BLOCKS ? btiles : RED_BLOCKS)), dim3(RED_THREADS), 0, (hipStream_t)stream, s,
+                       scale, gscale, gdisp, 0, out);
     FALNET_RETURN_LAUNCH();
 }

@@ -208,7 +208,10 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
         S = plan.buf["step_scalars"] = torch.zeros(2, device=dev)
     S.zero_()  # [rec = L1 + a_p * perceptual, sm]
     n_img = B * C * H * W
-    L.check(lib.falnet_l1_fwd(L.ptr(rpan), L.ptr(rt), None, B, C, H * W, 1.0 / n_img, L.ptr(S), 1, st), "l1_fwd")  # loss_functions.py:53
+    # every loss term AND its adjoint in one pass over its operands (the upstream scalars -- loss scale, a_p, a_sm -- are known now)
+    g_pan, g_disp = b["g_pan"], b["g_disp"]
+    L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(_seed(dev, s)), L.ptr(g_pan), st),
+            "l1_fwd_bwd")  # loss_functions.py:53
     vplan = None
     if a_p > 0:
         vm = LF.vgg._get()
@@ -225,26 +228,21 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
             ln = LF._nhwc(lab.to(o.dtype))
             Bo, Ho, Wo, Co = o.shape
             sc = 1.0 / o.numel()
-            L.check(lib.falnet_mse_fwd(L.ptr(o), L.ptr(ln), Bo * Ho * Wo, Co, a_p * sc, L.ptr(S), 1, code, st), "mse_fwd")
             feats.append((o, ln, Bo * Ho * Wo, Co, sc))
+        for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
+            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(_seed(dev, s * a_p)), L.ptr(go), code, st),
+                    "mse_fwd_bwd")
     x0 = int(0.20 * W)
     sc_sm = 1.0 / (B * H * (W - x0))
     if a_sm > 0:  # Train_Stage1_K.py:255
-        L.check(lib.falnet_smooth_fwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), 1, st), "smooth_fwd")
-    # ---- adjoints (every node is linear in its upstream scalar: s = loss scale) ----
-    g_pan, g_disp = b["g_pan"], b["g_disp"]
+        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), L.ptr(_seed(dev, s * a_sm)),
+                                          L.ptr(g_disp), st), "smooth_fwd_bwd")
+    # ---- the VGG adjoint (every node is linear in its upstream scalar: s = loss scale) joins the L1 gradient ----
     if vplan is not None:
-        for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
-            L.check(lib.falnet_mse_bwd(L.ptr(o), L.ptr(ln), npix, Co, sc, L.ptr(_seed(dev, s * a_p)), L.ptr(go), code, st), "mse_bwd")
         for c in vplan.bwd:
             c()
-        g_pan.copy_(vplan.g_in)
+        g_pan.add_(vplan.g_in)
         vplan.busy = False
-    L.check(lib.falnet_l1_bwd(L.ptr(rpan), L.ptr(rt), None, B, C, H * W, 1.0 / n_img, L.ptr(_seed(dev, s)), L.ptr(g_pan),
-                              1 if vplan is not None else 0, st), "l1_bwd")
-    if a_sm > 0:
-        L.check(lib.falnet_smooth_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(_seed(dev, s * a_sm)), L.ptr(g_disp), 0,
-                                      st), "smooth_bwd")
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
     unscale = 1.0 / s
     Sc = S.clone()  # the accumulators are reused by the next step

@@ -289,6 +289,15 @@ int falnet_smooth_fwd(const float* img, const float* disp, int B, int H, int W, 
                       float gamma, float scale, float* out, int accumulate, void* stream);
 int falnet_smooth_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1,
                       float gamma, float scale, const float* gscale, float* gdisp, int accumulate, void* stream);
+/* Loss AND gradient in one pass over the operands (a training step that knows its upstream scalars before the forward runs:
+ * fal_net_amd/train.py:_stage1_fused): out[0] += the loss term exactly as the *_fwd entry point with accumulate = 1 adds it; the
+ * gradient exactly as the *_bwd entry point writes it (assigned, not accumulated). */
+int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale, float* ga,
+                      void* stream);
+int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale_out, float* out, float scale_grad,
+                       const float* gscale, void* ga, int dtype, void* stream);
+int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale, float* out,
+                          const float* gscale, float* gdisp, void* stream);
 /* mixing for masked perceptual input: out = m*a + (1-m)*b (loss_functions.py:55); and grad wrt a: ga = m*g */
 int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, int B, int C, int64_t HW, void* stream);
 
