@@ -602,6 +602,27 @@ def test_losses():
         gd = torch.empty(B, 1, H, W, device=DEV)
         L.check(lib.falnet_smooth_bwd(L.ptr(img_d), L.ptr(dsp_d), B, H, W, x0, x1, gamma, sc, L.ptr(None), L.ptr(gd), 0, L.stream_ptr()))
         assert rel(gd, dsp.grad) < 1e-5
+        # loss + gradient in one pass (the fused training step's entry point): same numbers, seeded upstream scalar
+        seed, acc2, gd2 = torch.tensor([3.0], device=DEV), torch.zeros(1, device=DEV), torch.full((B, 1, H, W), float("nan"), device=DEV)
+        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(img_d), L.ptr(dsp_d), B, H, W, x0, x1, gamma, sc, L.ptr(acc2), L.ptr(seed), L.ptr(gd2), L.stream_ptr()))
+        assert abs(float(acc2) - float(ref)) < 1e-5 * abs(float(ref)) and rel(gd2, 3.0 * dsp.grad) < 1e-5
+    # L1 and MSE: loss + gradient in one pass
+    a2, b2 = torch.randn(B, 3, H, W, generator=g), torch.randn(B, 3, H, W, generator=g)
+    a2d, b2d = a2.to(DEV), b2.to(DEV)
+    seed, acc2, ga2 = torch.tensor([0.5], device=DEV), torch.zeros(1, device=DEV), torch.full((B, 3, H, W), float("nan"), device=DEV)
+    sc = 1.0 / a2.numel()
+    L.check(lib.falnet_l1_fwd_bwd(L.ptr(a2d), L.ptr(b2d), B, 3, H * W, sc, L.ptr(acc2), L.ptr(seed), L.ptr(ga2), L.stream_ptr()))
+    assert abs(float(acc2) - float((a2 - b2).abs().mean())) < 1e-5 * float((a2 - b2).abs().mean())
+    assert rel(ga2, 0.5 * sc * torch.sign(a2 - b2)) < 1e-6
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        x, y = torch.randn(2, 64, 6, 8, generator=g), torch.randn(2, 64, 6, 8, generator=g)
+        xt, yt = to_nhwc(x, dtype), to_nhwc(y, dtype)
+        acc2.zero_()
+        gx = torch.full_like(xt, float("nan"))
+        scm = 1.0 / x.numel()
+        L.check(lib.falnet_mse_fwd_bwd(L.ptr(xt), L.ptr(yt), 2 * 6 * 8, 64, 0.25 * scm, L.ptr(acc2), scm, L.ptr(seed), L.ptr(gx), L.dtype_code(dtype), L.stream_ptr()))
+        assert abs(float(acc2) - 0.25 * float(((x - y) ** 2).mean())) < tol * float(((x - y) ** 2).mean())
+        assert rel(to_nchw(gx, 64), 0.5 * 2 * scm * (x - y)) < tol
     # mse on NHWC, flip, rowmax, mask mix
     for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
         x, y = torch.randn(2, 40, 5, 9, generator=g), torch.randn(2, 40, 5, 9, generator=g)
