@@ -97,7 +97,8 @@ class BackBone(nn.Module):
                     m.bias.data.zero_()
 
 
-_TAIL_MAIN = "conv1,conv1_1.conv1"  # default of FALNET_TAIL_MAIN (same-box A/B: +0.7 % over level 0 alone)
+_TAIL_MAIN = ""  # default of FALNET_TAIL_MAIN: extra weight gradients for the main stream's tail beside level 0's (re-tuned after the later kernel
+# changes made the MAIN stream the longer chain again: "conv1,conv1_1.conv1" was +0.7 % once, now -0.6 %)
 _TAIL_LEVELS = int(os.environ.get("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
