@@ -125,6 +125,20 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             tile_offsets(q.tile, 1);
         }
     };
+    // one piece of the issue cursor's chunk (i = 0 .. KP + KW - 1: patch pieces, then weight pieces); the pieces of chunk it + 1 are
+    // issued one per MFMA step inside chunk it's loop -- in-kernel stamps of the all-at-once form: 2 000-2 500 of a chunk's 9 000 cycles
+    // were spent in the issue of ~10 gathering DMA instructions with the matrix pipe idle (both waves of a SIMD issued at the same time)
+    auto issue_piece = [&](const Cur& q, int buf, int i) {
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
     auto issue = [&](const Cur& q, int buf) {
         const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
         const T* wbase = wptr + q.kofs;
@@ -171,13 +185,30 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         advance(qi);
     }
     int ctile = blockIdx.x, cc = 0;  // compute cursor
+#ifdef FALNET_CD_STAMPS
+    // profiling build (tools/cd_stamps.py): s_memtime at the phase boundaries of the first 48 chunks, every wave of workgroup (0, 0) -> p.splitk_ws
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
+    int stamp_i = 0;
+#define CD_STAMP()                                                                                   \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        unsigned long long t_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (stamp_out && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 256) stamp_out[wave * 256 + stamp_i] = t_; \
+        ++stamp_i;                                                                                   \
+    } while (0)
+#else
+#define CD_STAMP() do {} while (0)
+#endif
     for (int it = 0; it < total; ++it) {
+        CD_STAMP();  // 0: loop top
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own pieces of chunk `it` landed; own reads of chunk it-1 done
+        CD_STAMP();  // 1: own DMA landed
         __builtin_amdgcn_s_barrier();                                // chunk `it` complete for every wave; buffer (it+1)&1 is free
-        if (it + 1 < total) {
-            issue(qi, (it + 1) & 1);
-            advance(qi);
-        }
+        CD_STAMP();  // 2: barrier passed
+        const bool more = it + 1 < total;
+        CD_STAMP();  // 3: (nothing issued up front any more)
         // fragment bases of this chunk's buffer: ONE add per lane address (hipcc otherwise keeps every (address + tap offset)
         // of both buffers in registers -- ~70 VGPRs of loop-invariant sums -- and spills)
         int bo = (it & 1) * BUF;
@@ -204,6 +235,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #pragma unroll
         for (int st = 0; st < 18; ++st) {
             if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
+            if (st < KP + KW && more) issue_piece(qi, (it + 1) & 1, st);  // (wave-uniform)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -211,6 +243,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads of the next step
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
         }
+        if (more) advance(qi);
+        CD_STAMP();  // 4: MFMAs issued
         if (++cc == nchunks) {  // tile finished: epilogue straight from the accumulators, then the next tile starts from zero
             cc = 0;
             int b, ty0, tx0;
@@ -238,7 +272,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #pragma unroll
                     for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
         }
+        CD_STAMP();  // 5: (epilogue) done
     }
+#undef CD_STAMP
 }
 
 // dense 3x3 stride-1 launch in bf16 / f16 with 32-channel-granular sources at the launch size or exactly half of it (the
