@@ -388,6 +388,16 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
             if (q.tile < ntiles) tile_offsets(q.tile);
         }
     };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {  // one piece per MFMA step (see conv3x3_dma_kernel)
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            if (id < A_PIECES) cd_glds16(sptr + sbat + q.c * KCV + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.c * KCV + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
     auto issue = [&](const Cur& q, int buf) {
         const T* sbase = sptr + sbat + q.c * KCV;
         const T* wbase = wptr + q.c * KCV;
@@ -433,10 +443,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
     for (int it = 0; it < total; ++it) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 < total) {
-            issue(qi, (it + 1) & 1);
-            advance(qi);
-        }
+        const bool more = it + 1 < total;
         int bo = (it & 1) * BUF;
         asm volatile("" : "+s"(bo));
         const char* const Bf = lds;
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
 #pragma unroll
         for (int st = 0; st < 18; ++st) {
             if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
+            if (st < KP + KW && more) issue_piece(qi, (it + 1) & 1, st);
             const int t = st >> 1;
             const int cls = (((t / 3) + 1) & 1) * 2 + (((t % 3) + 1) & 1);  // (py, px) of this tap
 #pragma unroll
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
             __builtin_amdgcn_sched_group_barrier(0x100, MT + 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
         }
+        if (more) advance(qi);
         if (++cc == nchunks) {
             cc = 0;
             int b, ty0, tx0;
@@ -636,6 +645,17 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
             tile_offsets(q.tile, 1);
         }
     };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {  // one piece per MFMA step (see conv3x3_dma_kernel)
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
     auto issue = [&](const Cur& q, int buf) {
         const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
         const T* wbase = wptr + q.kofs;
@@ -682,10 +702,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
     for (int it = 0; it < total; ++it) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (it + 1 < total) {
-            issue(qi, (it + 1) & 1);
-            advance(qi);
-        }
+        const bool more = it + 1 < total;
         int bo = (it & 1) * BUF;
         asm volatile("" : "+s"(bo));
         const char* const Bf = lds;
@@ -706,11 +723,17 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             if (t + 1 < 9) load_step(t + 1, (t + 1) & 1);
+            if (t < KP + KW && more) issue_piece(qi, (it + 1) & 1, t);
+            if (t == 8 && KP + KW > 9 && more) {  // (BN = 128: more pieces than taps)
+#pragma unroll
+                for (int i = 9; i < KP + KW; ++i) issue_piece(qi, (it + 1) & 1, i);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt][0][0] = H16<T>::mma(fb[t & 1][nt], fa[t & 1], acc[nt][0][0]);
             __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
         }
+        if (more) advance(qi);
         if (++cc == nchunks) {
             cc = 0;
             int b, ty0, tx0;
