@@ -578,8 +578,8 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
 // The same walk on v_mfma_f32_16x16x32 (16-bit operands, exchanged operands only: positions on lanes): one step = one (chunk, tap) with
 // K = 32 (a whole 64-B chunk row), a 32x32 tile = 2 x 2 MFMAs (conv_epilogue.h: Acc16).  px_of(step, mt, pt) / w_of(step, nt, ct) return
 // this lane's 16-B fragment address: position 16 pt + (lane & 15) / weight row m16_row_channel(lane & 15) of half ct, K block lane >> 4.
-template <typename T, int MT, int NT, int NSTEP, typename PxOf, typename WOf>
-__device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[MT][NT]) {
+template <typename T, int MT, int NT, int NSTEP, typename PxOf, typename WOf, typename Hook = NoHook>
+__device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[MT][NT], Hook hook = Hook()) {
     constexpr int SLOTS = 3;
     uint4 fp[SLOTS][MT][2], fw[SLOTS][NT][2];
     auto load = [&](int step, int slot) {
@@ -608,6 +608,11 @@ __device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[M
                     for (int pt = 0; pt < 2; ++pt)
                         acc[mt][nt].t[ct][pt] = H16<T>::mma16(__builtin_bit_cast(s16x8_t, fw[sl][nt][ct]), __builtin_bit_cast(s16x8_t, fp[sl][mt][pt]),
                                                               acc[mt][nt].t[ct][pt]);
+        if constexpr (!std::is_same<Hook, NoHook>::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            hook(st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -1172,6 +1177,266 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
         WS_STAMP();  // 6: epilogue done
     }
 #undef WS_STAMP
+}
+
+// ------------------------------------------------------------------------------------------ weight-stationary 3x3, two-phase
+// conv3x3_ws_kernel's eight waves walk barrier -> refill -> MFMA -> epilogue in lock step (one patch buffer): while they all sit in the
+// epilogue arithmetic (ELU: ~11 % of the launch) and in the load / store issue, the matrix pipe idles (in-kernel stamps).
+// Here the eight waves are TWO groups of four (one wave per SIMD each) with a patch buffer per group and HALF-height tiles, and the groups
+// run half a period apart: between two workgroup barriers group A issues the MFMAs of its tile while group B -- the OTHER wave of every
+// SIMD -- does the epilogue of its previous tile, loads its next patch and stores it to LDS; at the next barrier the roles swap.
+//   LDS: W [NCH][9][BN][80 B] + 2 x A [NCH][(TH+2) x 34][80 B]   (BN = 64, NCH = 2: TH = 4, 92 KB + 2 x 32 KB)
+// Tiles j = 0, 1, ... of a persistent workgroup go to group j & 1.
+template <typename T, int BN, int NCH, bool M16 = false, bool FULL = false>
+__global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip) {
+    constexpr int NTHR = 512, GTHR = 256, WAVES_N = BN / 32, WAVES_M = 4 / WAVES_N;
+    constexpr int MT = 2, NT = 1, TH = MT * WAVES_M;
+    constexpr int KCB = 64, PITCH = KCB + 16, SEGS = KCB / 16;
+    constexpr int NPIX = (TH + 2) * PT_PW;
+    constexpr int KCV = KCB / (int)sizeof(T), EPS = 16 / (int)sizeof(T);
+    constexpr int W_BYTES = NCH * 9 * BN * PITCH, A_BYTES = NCH * NPIX * PITCH;
+    constexpr int W_LOADS = NCH * 9 * BN * SEGS, W_SLOTS = (W_LOADS + NTHR - 1) / NTHR;
+    static_assert(W_BYTES + 2 * A_BYTES <= 160 * 1024, "weights + two patches must fit in LDS");
+    __shared__ __attribute__((aligned(16))) char lds[W_BYTES + 2 * A_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, gtid = tid & (GTHR - 1), gw = wave & 3;  // waves w and w + 4 share a SIMD and belong to different groups
+    char* Wl = lds;
+    char* Al = lds + W_BYTES + grp * A_BYTES;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = gw / WAVES_N, wn = gw % WAVES_N;
+    const int n0 = blockIdx.y * BN;
+
+    {  // weights: once per workgroup, all 512 threads (as conv3x3_ws_kernel)
+        uint4 wreg[W_SLOTS];
+#pragma unroll
+        for (int u = 0; u < W_SLOTS; ++u) {
+            const int idx = tid + u * NTHR;
+            wreg[u] = make_uint4(0, 0, 0, 0);
+            if (idx < W_LOADS) {
+                const int seg = idx % SEGS, row = (idx / SEGS) % BN, t = (idx / (SEGS * BN)) % 9, c = idx / (SEGS * BN * 9);
+                if (n0 + row < p.w_rows && c * KCV < p.cin_total)
+                    wreg[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.weight) +
+                                                              ((int64_t)(n0 + row) * p.w_taps + (flip ? 8 - t : t)) * p.cin_total + c * KCV + seg * EPS);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < W_SLOTS; ++u) {
+            const int idx = tid + u * NTHR;
+            if (idx < W_LOADS) {
+                const int seg = idx % SEGS, row = (idx / SEGS) % BN, tc = idx / (SEGS * BN);
+                *reinterpret_cast<uint4*>(Wl + (tc * BN + row) * PITCH + seg * 16) = wreg[u];
+            }
+        }
+    }
+    // FULL (both chunks from ONE source of exactly 2 x 64 B per pixel): one load stream whose consecutive eight lanes cover a pixel's whole
+    // 128-B line, instead of one stream per chunk reading half lines
+    constexpr int LS = FULL ? 1 : NCH, LSEGS = FULL ? SEGS * NCH : SEGS;
+    static_assert(!FULL || NCH == 2, "FULL: two chunks");
+    constexpr int C_LOADS = NPIX * LSEGS, C_SLOTS = (C_LOADS + GTHR - 1) / GTHR;
+    const T* c_ptr[NCH];
+    int64_t c_sb[NCH], c_sy[NCH];
+    int c_sx[NCH], c_hs[NCH], c_ws[NCH];
+    bool c_ok[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {  // workgroup-uniform source of chunk c (hoisted scalars, see conv3x3_ws_kernel)
+        int sidx = 0, c0 = c * KCV;
+        if (c0 >= p.src[0].C) {
+            c0 -= p.src[0].C;
+            sidx = 1;
+        }
+        c_ok[c] = sidx < p.nsrc && c0 < (sidx ? p.src[1].C : p.src[0].C);
+        c_ptr[c] = reinterpret_cast<const T*>(sidx ? p.src[1].ptr : p.src[0].ptr) + c0;
+        c_sb[c] = sidx ? p.src[1].sb : p.src[0].sb;
+        c_sy[c] = sidx ? p.src[1].sy : p.src[0].sy;
+        c_sx[c] = (int)(sidx ? p.src[1].sx : p.src[0].sx);
+        c_hs[c] = (sidx ? p.src[1].H : p.src[0].H) != p.IH ? 1 : 0;
+        c_ws[c] = (sidx ? p.src[1].W : p.src[0].W) != p.IW ? 1 : 0;
+    }
+    int a_lds[C_SLOTS], a_pp[C_SLOTS];
+#pragma unroll
+    for (int u = 0; u < C_SLOTS; ++u) {
+        const int idx = gtid + u * GTHR;
+        a_lds[u] = -1;
+        a_pp[u] = 0;
+        if (idx < C_LOADS) {
+            const int seg = idx % LSEGS, px = idx / LSEGS;
+            a_lds[u] = (seg / SEGS) * NPIX * PITCH + px * PITCH + (seg % SEGS) * 16;
+            a_pp[u] = ((seg * EPS) << 16) | ((px / PT_PW) << 8) | (px % PT_PW);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LS; ++c)
+        if (!FULL && !c_ok[c]) {
+#pragma unroll
+            for (int u = 0; u < C_SLOTS; ++u)
+                if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(Al + c * NPIX * PITCH + a_lds[u]) = make_uint4(0, 0, 0, 0);
+        }
+
+    const int ntiles = p.B * tiles_y * tiles_x;
+    uint4 areg[LS][C_SLOTS];
+    int pl_b = 0, pl_ty0 = 0, pl_tx0 = 0;
+    auto patch_target = [&](int tile) {
+        const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y;
+        pl_b = tile / (tiles_x * tiles_y);
+        pl_ty0 = tiy * TH;
+        pl_tx0 = tix * PT_TW;
+    };
+    auto patch_load_slot = [&](int c, int u) {  // one 16-B load of the tile set by patch_target
+        const int pp = a_pp[u];
+        const int vy = pl_ty0 - 1 + ((pp >> 8) & 0xff), vx = pl_tx0 - 1 + (pp & 0xff);
+        const bool ok = a_lds[u] >= 0 && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok && c_ok[c])
+            v = *reinterpret_cast<const uint4*>(c_ptr[c] + (int64_t)pl_b * c_sb[c] + (int64_t)(vy >> c_hs[c]) * c_sy[c] + (vx >> c_ws[c]) * c_sx[c] + (pp >> 16));
+        areg[c][u] = v;
+    };
+    // the slots of a patch in two halves: the first is loaded by the wave in its MATRIX role (in front of the MFMAs), the second in its
+    // store role (in front of the epilogue) -- a wave is held ~290 cycles in the issue of every 1-KB load by the CU's memory path, so the
+    // loads are split to balance the two roles (stamps: matrix 3.9 k, epilogue 3.4 k, load issue 2.3 k, LDS stores 0.8 k cycles per tile)
+    constexpr int C_HALF = (C_SLOTS + 1) / 2;
+    auto patch_load_half = [&](auto half) {
+        constexpr int H = decltype(half)::value;
+#pragma unroll
+        for (int u = H ? C_HALF : 0; u < (H ? C_SLOTS : C_HALF); ++u)
+#pragma unroll
+            for (int c = 0; c < LS; ++c) patch_load_slot(c, u);
+    };
+    auto patch_store_half = [&](auto half) {
+        constexpr int H = decltype(half)::value;
+#pragma unroll
+        for (int c = 0; c < LS; ++c)
+            if (c_ok[c]) {
+#pragma unroll
+                for (int u = H ? C_HALF : 0; u < (H ? C_SLOTS : C_HALF); ++u)
+                    if (a_lds[u] >= 0) *reinterpret_cast<uint4*>(Al + c * NPIX * PITCH + a_lds[u]) = areg[c][u];
+            }
+    };
+    using Half0 = std::integral_constant<int, 0>;
+    using Half1 = std::integral_constant<int, 1>;
+
+    constexpr int KSEG = KCB / 32;
+    const int lane_k = sizeof(T) == 2 ? h * 16 : h * (KCB / 2);
+    constexpr int KSTRIDE = sizeof(T) == 2 ? 32 : 16;
+    const char* ab = Al + ((wm * MT) * PT_PW + r) * PITCH + lane_k;
+    const char* bb = Wl + (wn * 32 + r) * PITCH + lane_k;
+    float bias[NT][16];
+    load_bias16<NT>(p, n0 + wn * 32, h, bias);
+
+    // tiles of this workgroup: blockIdx.x + j * gridDim.x; group grp takes j = grp, grp + 2, ...
+    const int nj = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int n_a = (nj + 1) >> 1, n_b = nj >> 1;
+    const int nph = max(2 * n_a + 1, 2 * n_b + 2);  // group 0: refill at even phases, group 1 at odd ones
+    const int tstride = 2 * (int)gridDim.x;
+    int pend = (int)blockIdx.x + grp * (int)gridDim.x;  // tile whose patch is in flight to / waiting in registers (-1: none)
+    int ready = -1, done = -1;                           // tile staged in LDS / tile whose accumulators await the epilogue
+    if (pend < ntiles) {
+        patch_target(pend);
+        patch_load_half(Half0{});
+    } else {
+        pend = -1;
+    }
+    f32x16 acc[MT][NT];
+#ifdef FALNET_WS_STAMPS
+    // profiling build (tools/ws2_stamps.py): four s_memtime stamps per phase of workgroup 0, every wave -> p.splitk_ws
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
+    int stamp_i = 0;
+#define WS2_STAMP()                                                                                      \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        unsigned long long t_;                                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (stamp_out && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 256) stamp_out[wave * 256 + stamp_i] = t_; \
+        ++stamp_i;                                                                                       \
+    } while (0)
+#else
+#define WS2_STAMP() do {} while (0)
+#endif
+    for (int ph = 0; ph < nph; ++ph) {
+        WS2_STAMP();  // 0: phase top
+        __syncthreads();
+        WS2_STAMP();  // 1: after the barrier
+        if (((ph + grp) & 1) == 0) {
+            // ---- store role (this group's MFMAs are done, its patch buffer is free): first half of the next patch registers -> LDS, second
+            // half global -> registers (in flight behind the epilogue), epilogue of the previous tile, second half -> LDS
+            if (pend >= 0) {
+                patch_store_half(Half0{});
+                patch_target(pend);
+                patch_load_half(Half1{});
+            }
+            WS2_STAMP();  // 2: patch stored
+            if (done >= 0) {
+                const int tix = done % tiles_x, tiy = (done / tiles_x) % tiles_y, b = done / (tiles_x * tiles_y);
+                const int ty0 = tiy * TH, x = tix * PT_TW + r;
+                const int cstride = p.out_cstride;
+                const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
+                auto pixoff = [&](int mt) -> int64_t {
+                    const int y = ty0 + wm * MT + mt;
+                    if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                    return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                };
+                auto pooloff = [&](int mt) -> int64_t {
+                    const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                    return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+                };
+                epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * 32, lane, pixoff, pooloff);
+                done = -1;
+            }
+            WS2_STAMP();  // 3: epilogue done
+            if (pend >= 0) {
+                patch_store_half(Half1{});
+                ready = pend;
+                pend = -1;
+            }
+        } else if (ready >= 0) {
+            // ---- matrix role: the tile staged in the previous phase; the group's next patch goes to registers behind the MFMAs
+            if (ready + tstride < ntiles) {
+                pend = ready + tstride;
+                patch_target(pend);
+                patch_load_half(Half0{});
+            }
+            WS2_STAMP();  // 2
+            WS2_STAMP();
+            if constexpr (M16 && sizeof(T) == 2) {
+                Acc16 a16[MT][NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) a16[mt][nt].zero();
+                const int lp = lane & 15, lg = lane >> 4;
+                const char* pxb = Al + ((wm * MT) * PT_PW + lp) * PITCH + lg * 16;
+                const char* wb16 = Wl + (wn * 32 + m16_row_channel(lp)) * PITCH + lg * 16;
+                mma_steps16<T, MT, NT, NCH * 9>(
+                    [&](int st, int mt, int pt) { const int c = st / 9, t = st % 9;
+                                                  return pxb + ((c * NPIX + mt * PT_PW + 16 * pt + (t / 3) * PT_PW + (t % 3)) * PITCH); },
+                    [&](int st, int nt, int ct) { return wb16 + ((st * BN + nt * 32 + 16 * ct) * PITCH); },
+                    a16);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) a16[mt][nt].to32(acc[mt][nt]);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+                mma_steps<T, MT, NT, NCH * 9 * KSEG, true, 3, FALNET_PIN_WS>(
+                    [&](int st, int mt) { const int c = st / (9 * KSEG), t = (st / KSEG) % 9, ks = st % KSEG;
+                                          return ab + ((c * NPIX + mt * PT_PW + (t / 3) * PT_PW + (t % 3)) * PITCH + ks * KSTRIDE); },
+                    [&](int st, int nt) { const int tc = st / KSEG, ks = st % KSEG;
+                                          return bb + ((tc * BN + nt * 32) * PITCH + ks * KSTRIDE); },
+                    acc);
+            }
+            done = ready;
+            ready = -1;
+        } else {
+            WS2_STAMP();
+            WS2_STAMP();
+        }
+    }
+#undef WS2_STAMP
 }
 
 // ------------------------------------------------------------------------------------------ first layer (Cin = 3)
@@ -2455,7 +2720,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16, "conv2d: unknown variant %d", variant);
     if (variant == 15) {  // LDS-DMA forward 3x3 stride-2 (conv_dma.hip)
         if (!falnet_conv_s2f_dma_applicable(p)) {
             falnet_set_error("conv2d: variant 15 needs a canonical 16-bit 3x3 stride-2 pad-1 NHWC launch (>= 8 x 32 outputs) with sources at the input size");
@@ -2478,8 +2743,8 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
-    if (variant == 10) {
-        // weight-stationary persistent kernel: every K chunk of a BN-channel weight slice stays in LDS
+    if (variant == 10 || variant == 16) {
+        // weight-stationary persistent kernel: every K chunk of a BN-channel weight slice stays in LDS (16: two-phase form, c.adb = 1)
         bool ok = dense3x3 && ctot * esz <= 128 && ctot * esz % 64 == 0 && p.src[0].C * esz % 64 == 0;
         for (int s = 0; s < p.nsrc && ok; ++s)  // sources at the launch size or exactly 2x upsampled
             ok = (p.src[s].H == p.IH || 2 * p.src[s].H == p.IH) && (p.src[s].W == p.IW || 2 * p.src[s].W == p.IW) && p.src[s].C < 4096;
@@ -2492,7 +2757,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.patch = 2;
         c.bn = (p.w_rows % 64 == 0 && p.Cout > 32) ? 64 : 32;
         c.kcb = ctot * esz / 64;  // chunks
-        c.tps = 9; c.adb = 0; c.th = c.bn == 64 ? 8 : 16; c.nwaves = 8;
+        c.tps = 9; c.adb = variant == 16; c.th = (c.bn == 64 ? 8 : 16) >> c.adb; c.nwaves = 8;
         return 0;
     }
     if (variant >= 2 && (!dense3x3 || (variant == 2 && !c128) || ((variant == 3 || variant == 5 || variant == 6 || variant == 8) && ctot / (64 / esz) < 2) ||
@@ -2549,7 +2814,8 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
     else if (c.patch == 2)
-        snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32));
+        snprintf(buf, len, c.adb ? "_Z18conv3x3_ws2_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii" : "_Z17conv3x3_ws_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb,
+                 (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32));
     else if (c.patch)
         snprintf(buf, len, "_Z20conv3x3_patch_kernelI%sLi%dELi%dELi%dELb%dELi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, c.tps, c.adb, c.th, c.nwaves);
     else
@@ -2585,7 +2851,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
     if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st);
     if (c.patch == 2) {
-        const int ws_th = c.bn == 64 ? 8 : 16;
+        const int ws_th = c.th;
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;
         const int ny = (p.Cout + c.bn - 1) / c.bn, ntiles = p.B * tiles_x * tiles_y;
         int gx = 256 / ny;  // one persistent workgroup per CU (146 KB of LDS each)
@@ -2593,14 +2859,22 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         if (gx > ntiles) gx = ntiles;
         const dim3 grid((unsigned)gx, (unsigned)ny);
         const bool m16 = falnet_mfma16_enabled();  // v_mfma_f32_16x16x32 form (16-bit types)
-#define LAUNCH_WS(T, BN, NCH) do { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
-                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws_kernel<T, BN, NCH, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); } while (0)
+        static const bool ws2_full_on = !(getenv("FALNET_WS2_FULL") && atoi(getenv("FALNET_WS2_FULL")) == 0);
+        const bool ws2_full = ws2_full_on && p.nsrc == 1 && (int64_t)p.src[0].C * (p.dtype == FALNET_F32 ? 4 : 2) == 128;  // whole-line load stream
+#define LAUNCH_WS1(K, T, BN, NCH) do { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(K<T, BN, NCH, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
+                                       else hipLaunchKernelGGL(HIP_KERNEL_NAME(K<T, BN, NCH, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); } while (0)
+#define LAUNCH_WS2(T, BN, NCH) do { if (NCH == 2 && ws2_full) { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws2_kernel<T, BN, 2, true, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
+                                         else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws2_kernel<T, BN, 2, false, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); } \
+                                     else LAUNCH_WS1(conv3x3_ws2_kernel, T, BN, NCH); } while (0)
+#define LAUNCH_WS(T, BN, NCH) do { if (c.adb) LAUNCH_WS2(T, BN, NCH); else LAUNCH_WS1(conv3x3_ws_kernel, T, BN, NCH); } while (0)
 #define WS_TABLE(T)                                                                                 \
     if (c.bn == 64) { if (c.kcb == 2) LAUNCH_WS(T, 64, 2); else LAUNCH_WS(T, 64, 1); }              \
     else { if (c.kcb == 2) LAUNCH_WS(T, 32, 2); else LAUNCH_WS(T, 32, 1); }
         FALNET_DISPATCH_DTYPE(p.dtype, WS_TABLE);
 #undef WS_TABLE
 #undef LAUNCH_WS
+#undef LAUNCH_WS1
+#undef LAUNCH_WS2
         FALNET_RETURN_LAUNCH();
     }
     if (c.patch) {

@@ -6,13 +6,29 @@
 
 typedef f32x16_t f32x16;
 
+// ELU / ReLU in the fewest VALU issue slots (the epilogue arithmetic of the 64-channel full-resolution layers is ~11 % of their launch):
+//   elu(v) = v > 0 ? v : exp(v) - 1 = max(v, min(exp(v), 1) - 1)   [v > 0: the clamped exponential is 1, max(v, 0) = v; v <= 0: exp(v) <= 1 and
+//   exp(v) - 1 >= v] -- the same values as the select form, with the min as the CLAMP output modifier of v_exp_f32 (fmed3(x, 0, 1) folds into it)
+//   and one v_max instead of v_cmp + v_cndmask; the v_max is written in asm so hipcc does not put a canonicalising v_max v, v in front of it.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float elu_f(float v) {
+    const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(v * 1.44269504088896340736f), 0.f, 1.f);
+    return max_raw(v, e - 1.f);
+}
+__device__ __forceinline__ float relu_f(float v) { return max_raw(v, 0.f); }
+// d elu / dx from the OUTPUT y (>= -1): y > 0 ? 1 : y + 1 = clamp(y + 1, 0, 1) (the clamp modifier of the v_add)
+__device__ __forceinline__ float elu_grad_from_out(float y) { return __builtin_amdgcn_fmed3f(y + 1.f, 0.f, 1.f); }
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == FALNET_ACT_ELU) return v > 0.f ? v : (__expf(v) - 1.f);
-    if (act == FALNET_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == FALNET_ACT_ELU) return elu_f(v);
+    if (act == FALNET_ACT_RELU) return relu_f(v);
     return v;
 }
 __device__ __forceinline__ float act_grad_from_out(float y, int kind) {
-    if (kind == FALNET_ACT_ELU) return y > 0.f ? 1.f : y + 1.f;
+    if (kind == FALNET_ACT_ELU) return elu_grad_from_out(y);
     if (kind == FALNET_ACT_RELU) return y > 0.f ? 1.f : 0.f;
     return 1.f;
 }
@@ -124,16 +140,33 @@ struct Acc16 {        // one 32x32 tile as four 16x16 results
 __device__ __forceinline__ void act16(float (&v)[16], int act) {
     if (act == FALNET_ACT_ELU) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = v[j] > 0.f ? v[j] : (__expf(v[j]) - 1.f);
+        for (int j0 = 0; j0 < 16; j0 += 8) {  // stage by stage over eight values: packed multiplies / adds, no wait state behind the exponentials
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = f32x2{v[j0 + 2 * j], v[j0 + 2 * j + 1]} * 1.44269504088896340736f;  // v_pk_mul_f32
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                e[j].x = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[j].x), 0.f, 1.f);
+                e[j].y = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(e[j].y), 0.f, 1.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = e[j] - 1.f;  // v_pk_add_f32
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j0 + 2 * j] = max_raw(v[j0 + 2 * j], e[j].x);
+                v[j0 + 2 * j + 1] = max_raw(v[j0 + 2 * j + 1], e[j].y);
+            }
+        }
     } else if (act == FALNET_ACT_RELU) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 16; ++j) v[j] = relu_f(v[j]);
     }
 }
 __device__ __forceinline__ void actgrad16(float (&v)[16], const float (&y)[16], int kind) {
     if (kind == FALNET_ACT_ELU) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] *= y[j] > 0.f ? 1.f : y[j] + 1.f;
+        for (int j = 0; j < 16; ++j) v[j] *= elu_grad_from_out(y[j]);
     } else if (kind == FALNET_ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;

@@ -420,6 +420,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
                 if M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
                     cands += [(v, k) for k in (2, 4) if w2 * k <= 2048]
     cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1), (10, 1)]
+    if os.environ.get("FALNET_WS2", "1") == "1":
+        cands += [(16, 1)]  # two-phase weight-stationary
     if os.environ.get("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
         if d.isy == 2 and os.environ.get("FALNET_S2F_DMA", "1") == "1":

@@ -107,6 +107,8 @@ typedef struct {
                                   13 LDS-DMA double-buffered persistent kernel (16-bit operands, 16x32 positions x 64 channels per
                                   workgroup, sources at the launch size or exactly half of it);
                                   15 forward 3x3 stride-2 by LDS-DMA (parity-de-interleaved patch, 16-channel chunks);
+                                  16 = 10 with two groups of four waves half a period apart (one in its MFMAs while the other stores,
+                                  loads and runs the epilogue), half-height tiles;
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

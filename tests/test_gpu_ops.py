@@ -178,7 +178,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 14)) + [15]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2
+    for variant in list(range(1, 14)) + [15, 16]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -193,7 +193,7 @@ def test_conv_every_kernel_variant(case, dtype):
         return
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
     assert (13 in ran) == (dtype != torch.float32 and H >= 16)
-    assert (10 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
+    assert (10 in ran) == (16 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -217,7 +217,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13]:
+    for variant in list(range(1, 11)) + [13, 16]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         if out is not None:
@@ -259,7 +259,7 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13]:
+    for variant in list(range(1, 11)) + [13, 16]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())

@@ -24,7 +24,7 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("iconv4 128+256->256 @32x64", [128, 256], 256, 32, 64, None),
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
 ]
-VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("dma", 13)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13)]
 lib = L.lib()
 for name, groups, cout, H, W, up in LAYERS:
     cin = sum(groups)
@@ -35,11 +35,12 @@ for name, groups, cout, H, W, up in LAYERS:
     srcs_t = []
     for g in groups:
         h, ww = up if up else (H, W)
-        srcs_t.append(torch.randn(B, h, ww, ops.pad_c(g), device=DEV).to(dtype))
+        srcs_t.append((torch.randn(B, h, ww, ops.pad_c(g), device=DEV) * float(os.environ.get('BENCH_SCALE', '1'))).to(dtype))  # BENCH_SCALE=0: all-zero activations (clock / power probe)
     out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
     ops.AUTOTUNE = False
+    pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV) if os.environ.get('BENCH_POOL') else None  # BENCH_POOL=1: only the 2x2-pooled map is stored
     call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
-                         H, W, out, H, W, pc.cout_pad, pc.cout_pad, act=L.ACT_ELU)
+                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled, act={'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')])
     flops = 2.0 * B * H * W * cout * cin * 9
     times = {v: [] for v, _ in VARIANTS}
     ref = None
@@ -57,7 +58,9 @@ for name, groups, cout, H, W, up in LAYERS:
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1) / 5)
             if rnd == 0:
-                if ref is None:
+                if pooled is not None:
+                    pass
+                elif ref is None:
                     ref = out.float().clone()
                 else:
                     assert float((out.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()), (name, v)
