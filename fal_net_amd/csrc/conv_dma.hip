@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             };
             float bias[NT][16];  // (loaded per tile: 32 registers that would otherwise stay live across the MFMA loop)
             load_bias16<NT>(p, n0, h, bias);
-            epilogue_direct<T, MT, NT>(p, acc, bias, n0, lane, pixoff, pooloff);
+            epilogue_direct<T, MT, NT, decltype(pixoff), decltype(pooloff), -1>(p, acc, bias, n0, lane, pixoff, pooloff);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
                     if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
                     return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
                 };
-                epilogue_direct<T, MT, 1>(p, acc[c], bias, n0, lane, pixoff);
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1>(p, acc[c], bias, n0, lane, pixoff);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
             for (int nt = 0; nt < NT; ++nt) {
                 float bias[1][16];
                 load_bias16<1>(p, n0 + 32 * nt, h, bias);
-                epilogue_direct<T, 1, 1>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
+                epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, -1>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;
             }

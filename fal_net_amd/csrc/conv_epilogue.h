@@ -81,6 +81,55 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ base, int64_t o,
         }
     }
 }
+// The same load in two steps: tile_fetch issues this lane's loads WITHOUT a branch (an invalid lane reads element 0 of the tensor and is
+// zeroed in tile_unpack), so that all loads of a tile -- and of the next one -- are in flight before the first s_waitcnt; the conditional form
+// above compiles to one exec-masked block per 16-B load, each followed by s_waitcnt vmcnt(0).
+template <typename T>
+struct TileRaw {
+    static constexpr int N = sizeof(T) == 2 ? 2 : 4;
+    uint4 c[N];
+    unsigned okmask;
+};
+template <typename T>
+__device__ __forceinline__ void tile_fetch(const T* __restrict__ base, int64_t o, int cbase, int h, int Cout, TileRaw<T>& r) {
+    r.okmask = 0;
+#pragma unroll
+    for (int q = 0; q < TileRaw<T>::N; ++q) {
+        const int cb = sizeof(T) == 2 ? cbase + 16 * q + 8 * h : cbase + 8 * q + 4 * h;
+        const bool ok = o >= 0 && cb < Cout;
+        r.okmask |= ok ? 1u << q : 0u;
+        r.c[q] = *reinterpret_cast<const uint4*>(base + (ok ? o + cb : (int64_t)0));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_unpack(TileRaw<T>& r, float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < TileRaw<T>::N; ++q)
+        if (!((r.okmask >> q) & 1)) r.c[q] = make_uint4(0, 0, 0, 0);
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half_swap(r.c[q].x, r.c[q].z);
+            half_swap(r.c[q].y, r.c[q].w);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned w0 = (k & 1) ? r.c[k >> 1].z : r.c[k >> 1].x, w1 = (k & 1) ? r.c[k >> 1].w : r.c[k >> 1].y;
+            v[4 * k + 0] = H16<T>::lo(w0);
+            v[4 * k + 1] = H16<T>::hi(w0);
+            v[4 * k + 2] = H16<T>::lo(w1);
+            v[4 * k + 3] = H16<T>::hi(w1);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[4 * k + 0] = __uint_as_float(r.c[k].x);
+            v[4 * k + 1] = __uint_as_float(r.c[k].y);
+            v[4 * k + 2] = __uint_as_float(r.c[k].z);
+            v[4 * k + 3] = __uint_as_float(r.c[k].w);
+        }
+    }
+}
 template <typename T>
 __device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int cbase, int h, int Cout, const float (&v)[16]) {
     if constexpr (sizeof(T) == 2) {
@@ -188,7 +237,9 @@ __device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP
 }
 // PixOff(mt) -> element offset of channel 0 of this lane's pixel in slab mt (or -1); PoolOff(mt) (odd mt, even column)
 // -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
-template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool>
+// AHEAD = operand slabs in flight beyond the current one (1: conv.hip's kernels; -1: the LDS-DMA kernels, which have no registers to spare:
+// conditional loads at the point of use)
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1>
 __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
                                                 PixOff pixoff, PoolOff pooloff = PoolOff()) {
     constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
@@ -203,22 +254,37 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
     for (int nt = 0; nt < NT; ++nt) {
         const int cbase = nbase + nt * 32;
         float hp[16];
+        // residual / activation-output operands: fetched one row slab AHEAD (branch-free loads, conv_epilogue.h: tile_fetch), so their latency
+        // sits behind the previous slab's arithmetic and stores instead of in front of every 16-B load
+        constexpr int NR = AHEAD < 0 ? 1 : 1 + AHEAD;
+        TileRaw<T> ra[NR], rb[NR];
+        if (AHEAD > 0) {
+            if (addend) tile_fetch<T>(addend, pixoff(0), cbase, h, p.Cout, ra[0]);  // workgroup-uniform branches: the half swaps inside need every lane
+            if (actout) tile_fetch<T>(actout, pixoff(0), cbase, h, p.Cout, rb[0]);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int64_t o = pixoff(mt);
+            if (AHEAD >= 0 && (AHEAD ? mt + 1 < MT : true)) {
+                const int mf = mt + AHEAD;
+                if (addend) tile_fetch<T>(addend, pixoff(mf), cbase, h, p.Cout, ra[mf & AHEAD]);
+                if (actout) tile_fetch<T>(actout, pixoff(mf), cbase, h, p.Cout, rb[mf & AHEAD]);
+            }
             float v[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = acc[mt][nt][j] + bias[nt][j];
-            if (addend) {  // workgroup-uniform branches: the half swaps inside need every lane
+            if (addend) {
                 float a[16];
-                tile_load<T>(addend, o, cbase, h, p.Cout, a);
+                if constexpr (AHEAD < 0) tile_load<T>(addend, o, cbase, h, p.Cout, a);
+                else tile_unpack<T>(ra[mt & (AHEAD < 0 ? 0 : AHEAD)], a);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] += a[j];
             }
             act16(v, p.act);
             if (actout) {
                 float a[16];
-                tile_load<T>(actout, o, cbase, h, p.Cout, a);
+                if constexpr (AHEAD < 0) tile_load<T>(actout, o, cbase, h, p.Cout, a);
+                else tile_unpack<T>(rb[mt & (AHEAD < 0 ? 0 : AHEAD)], a);
                 actgrad16(v, a, p.actout_kind);
             }
             if (p.out_layout == FALNET_OUT_PLANAR_F32) {
