@@ -22,6 +22,10 @@
 #include <stdlib.h>
 #include "conv_epilogue.h"
 
+#ifndef FALNET_DMA_EPI_AHEAD
+#define FALNET_DMA_EPI_AHEAD -1  // conv_epilogue.h: epilogue_direct's operand prefetch depth (-1: conditional loads at the point of use)
+#endif
+
 // 32 KiB of zeros: the 'pixel' / 'weight row' every out-of-image or out-of-range 16-B piece is fetched from.  Invalid lanes carry
 // the OFFSET of this page relative to their tensor, so a piece's address is always base + offset (+ channel offset < 16 K
 // elements): no compare / select per piece and chunk.
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             };
             float bias[NT][16];  // (loaded per tile: 32 registers that would otherwise stay live across the MFMA loop)
             load_bias16<NT>(p, n0, h, bias);
-            epilogue_direct<T, MT, NT, decltype(pixoff), decltype(pooloff), -1>(p, acc, bias, n0, lane, pixoff, pooloff);
+            epilogue_direct<T, MT, NT, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc, bias, n0, lane, pixoff, pooloff);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
                     if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
                     return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
                 };
-                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1>(p, acc[c], bias, n0, lane, pixoff);
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[c], bias, n0, lane, pixoff);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
             for (int nt = 0; nt < NT; ++nt) {
                 float bias[1][16];
                 load_bias16<1>(p, n0 + 32 * nt, h, bias);
-                epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, -1>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
+                epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;
             }
