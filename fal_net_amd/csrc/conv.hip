@@ -2802,6 +2802,12 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
     return 0;
 }
 
+// conv3x3_ws2_kernel's FULL form: both 64-B chunks from ONE source of exactly 128 B per pixel -> one load stream of whole 128-B lines
+static bool ws2_whole_lines(const falnet_conv_t& p) {
+    static const bool on = !(getenv("FALNET_WS2_FULL") && atoi(getenv("FALNET_WS2_FULL")) == 0);
+    return on && p.nsrc == 1 && (int64_t)p.src[0].C * (p.dtype == FALNET_F32 ? 4 : 2) == 128;
+}
+
 // Symbol of the kernel falnet_conv2d will launch for this descriptor (the name rocprofv3 reports): lets a harness
 // group launches by the real instantiation.
 extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int len) {
@@ -2814,8 +2820,11 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
     else if (c.patch == 2)
-        snprintf(buf, len, c.adb ? "_Z18conv3x3_ws2_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii" : "_Z17conv3x3_ws_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb,
-                 (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32));
+    {
+        const int m16 = (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32);
+        if (c.adb) snprintf(buf, len, "_Z18conv3x3_ws2_kernelI%sLi%dELi%dELb%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, m16, (int)(c.kcb == 2 && ws2_whole_lines(*pp)));
+        else snprintf(buf, len, "_Z17conv3x3_ws_kernelI%sLi%dELi%dELb%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, m16);
+    }
     else if (c.patch)
         snprintf(buf, len, "_Z20conv3x3_patch_kernelI%sLi%dELi%dELi%dELb%dELi%dELi%dEEv13falnet_conv_tiii", t, c.bn, c.kcb, c.tps, c.adb, c.th, c.nwaves);
     else
@@ -2859,8 +2868,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
         if (gx > ntiles) gx = ntiles;
         const dim3 grid((unsigned)gx, (unsigned)ny);
         const bool m16 = falnet_mfma16_enabled();  // v_mfma_f32_16x16x32 form (16-bit types)
-        static const bool ws2_full_on = !(getenv("FALNET_WS2_FULL") && atoi(getenv("FALNET_WS2_FULL")) == 0);
-        const bool ws2_full = ws2_full_on && p.nsrc == 1 && (int64_t)p.src[0].C * (p.dtype == FALNET_F32 ? 4 : 2) == 128;  // whole-line load stream
+        const bool ws2_full = ws2_whole_lines(p);
 #define LAUNCH_WS1(K, T, BN, NCH) do { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(K<T, BN, NCH, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
                                        else hipLaunchKernelGGL(HIP_KERNEL_NAME(K<T, BN, NCH, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); } while (0)
 #define LAUNCH_WS2(T, BN, NCH) do { if (NCH == 2 && ws2_full) { if (m16 && sizeof(T) == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_ws2_kernel<T, BN, 2, true, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, c.flip); \
