@@ -1322,19 +1322,21 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
     float bias[NT][16];
     load_bias16<NT>(p, n0 + wn * 32, h, bias);
 
+    auto tile_xy = [&](int tile, int& b, int& ty0, int& x) {
+        const int tix = tile % tiles_x, tiy = (tile / tiles_x) % tiles_y;
+        b = tile / (tiles_x * tiles_y);
+        ty0 = tiy * TH;
+        x = tix * PT_TW + r;
+    };
     // tiles of this workgroup: blockIdx.x + j * gridDim.x; group grp takes j = grp, grp + 2, ...
     const int nj = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int n_a = (nj + 1) >> 1, n_b = nj >> 1;
     const int nph = max(2 * n_a + 1, 2 * n_b + 2);  // group 0: refill at even phases, group 1 at odd ones
     const int tstride = 2 * (int)gridDim.x;
-    int pend = (int)blockIdx.x + grp * (int)gridDim.x;  // tile whose patch is in flight to / waiting in registers (-1: none)
-    int ready = -1, done = -1;                           // tile staged in LDS / tile whose accumulators await the epilogue
-    if (pend < ntiles) {
-        patch_target(pend);
-        patch_load_half(Half0{});
-    } else {
-        pend = -1;
-    }
+    int next = (int)blockIdx.x + grp * (int)gridDim.x;  // next tile to stage
+    int ready = -1, done = -1;                           // tile staged in LDS / finished tile whose outputs await their stores
+    const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
+    PackedOut<T, MT, NT> fin;                            // the finished tile between the two phases (NHWC outputs)
     f32x16 acc[MT][NT];
 #ifdef FALNET_WS_STAMPS
     // profiling build (tools/ws2_stamps.py): four s_memtime stamps per phase of workgroup 0, every wave -> p.splitk_ws
@@ -1357,19 +1359,19 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
         __syncthreads();
         WS2_STAMP();  // 1: after the barrier
         if (((ph + grp) & 1) == 0) {
-            // ---- store role (this group's MFMAs are done, its patch buffer is free): first half of the next patch registers -> LDS, second
-            // half global -> registers (in flight behind the epilogue), epilogue of the previous tile, second half -> LDS
-            if (pend >= 0) {
-                patch_store_half(Half0{});
-                patch_target(pend);
+            // ---- refill role (this group's MFMAs are done, its patch buffer is free): next patch global -> registers, the STORES of the tile
+            // finished in the previous phase (its arithmetic ran in the matrix role, behind the MFMAs), patch registers -> LDS
+            const bool more = next < ntiles;
+            if (more) {
+                patch_target(next);
+                patch_load_half(Half0{});
                 patch_load_half(Half1{});
             }
-            WS2_STAMP();  // 2: patch stored
+            WS2_STAMP();  // 2: loads issued
             if (done >= 0) {
-                const int tix = done % tiles_x, tiy = (done / tiles_x) % tiles_y, b = done / (tiles_x * tiles_y);
-                const int ty0 = tiy * TH, x = tix * PT_TW + r;
+                int b, ty0, x;
+                tile_xy(done, b, ty0, x);
                 const int cstride = p.out_cstride;
-                const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
                 auto pixoff = [&](int mt) -> int64_t {
                     const int y = ty0 + wm * MT + mt;
                     if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
@@ -1379,22 +1381,20 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
                     const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
                     return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
                 };
-                epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * 32, lane, pixoff, pooloff);
+                if (planar_out) epilogue_direct<T, MT, NT>(p, acc, bias, n0 + wn * 32, lane, pixoff, pooloff);  // (planar f32 logits: whole epilogue here)
+                else epilogue_store_packed<T, MT, NT>(p, fin, n0 + wn * 32, lane, pixoff, pooloff);
                 done = -1;
             }
-            WS2_STAMP();  // 3: epilogue done
-            if (pend >= 0) {
+            WS2_STAMP();  // 3: outputs stored
+            if (more) {
+                patch_store_half(Half0{});
                 patch_store_half(Half1{});
-                ready = pend;
-                pend = -1;
+                ready = next;
+                next += tstride;
             }
         } else if (ready >= 0) {
-            // ---- matrix role: the tile staged in the previous phase; the group's next patch goes to registers behind the MFMAs
-            if (ready + tstride < ntiles) {
-                pend = ready + tstride;
-                patch_target(pend);
-                patch_load_half(Half0{});
-            }
+            // ---- matrix role: MFMAs of the tile staged in the previous phase, then its epilogue ARITHMETIC (bias, residual, activation,
+            // activation gradient, pooling, 16-bit packing) into `fin` -- VALU work this wave issues while the other wave of the SIMD sits in load / store issue
             WS2_STAMP();  // 2
             WS2_STAMP();
             if constexpr (M16 && sizeof(T) == 2) {
@@ -1428,6 +1428,21 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
                     [&](int st, int nt) { const int tc = st / KSEG, ks = st % KSEG;
                                           return bb + ((tc * BN + nt * 32) * PITCH + ks * KSTRIDE); },
                     acc);
+            }
+            if (!planar_out) {
+                int b, ty0, x;
+                tile_xy(ready, b, ty0, x);
+                const int cstride = p.out_cstride;
+                auto pixoff = [&](int mt) -> int64_t {
+                    const int y = ty0 + wm * MT + mt;
+                    if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                    return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                };
+                auto pooloff = [&](int mt) -> int64_t {
+                    const int py = (ty0 + wm * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                    return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+                };
+                epilogue_direct<T, MT, NT, decltype(pixoff), decltype(pooloff), 1, true>(p, acc, bias, n0 + wn * 32, lane, pixoff, pooloff, &fin);
             }
             done = ready;
             ready = -1;

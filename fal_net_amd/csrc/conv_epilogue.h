@@ -154,6 +154,50 @@ __device__ __forceinline__ void tile_store(T* __restrict__ base, int64_t o, int 
         }
     }
 }
+// A finished 32 x 32 tile as it goes to memory, still in accumulator order (no lane-half exchange yet): what a wave keeps when the
+// arithmetic and the stores of its epilogue run in different phases (conv3x3_ws2_kernel).
+template <typename T>
+struct PackedTile {
+    static constexpr int N = sizeof(T) == 2 ? 8 : 16;
+    unsigned w[N];
+};
+template <typename T>
+__device__ __forceinline__ void tile_pack(const float (&v)[16], PackedTile<T>& t) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t.w[2 * k + 0] = pack16x2<T>(v[4 * k + 0], v[4 * k + 1]);
+            t.w[2 * k + 1] = pack16x2<T>(v[4 * k + 2], v[4 * k + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t.w[j] = __float_as_uint(v[j]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void tile_store_packed(T* __restrict__ base, int64_t o, int cbase, int h, int Cout, PackedTile<T>& t) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            half_swap(t.w[4 * q + 0], t.w[4 * q + 2]);
+            half_swap(t.w[4 * q + 1], t.w[4 * q + 3]);
+            const int cb = cbase + 16 * q + 8 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<uint4*>(base + o + cb) = make_uint4(t.w[4 * q + 0], t.w[4 * q + 1], t.w[4 * q + 2], t.w[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cb = cbase + 8 * k + 4 * h;
+            if (o >= 0 && cb < Cout) *reinterpret_cast<uint4*>(base + o + cb) = make_uint4(t.w[4 * k], t.w[4 * k + 1], t.w[4 * k + 2], t.w[4 * k + 3]);
+        }
+    }
+}
+template <typename T, int MT, int NT>
+struct PackedOut {  // epilogue_direct<..., DEFER = true> fills it, epilogue_store_packed writes it out
+    PackedTile<T> out[MT][NT];
+    PackedTile<T> pool[(MT + 1) / 2][NT];
+};
+
 // ---- 16x16x32 MFMA form of a 32 (channels) x 32 (positions) tile -------------------------------------------------------------
 // v_mfma_f32_16x16x32 holds the chip's clock higher than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, MFMA shape: 1.12-1.15x
 // on random data; measured here by issuing the same operands through two 16x16x32: weight-stationary kernel 850 -> 1040 TFLOP/s).
@@ -239,9 +283,10 @@ __device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP
 // -> offset of the 2x2-reduced pixel in p.pool_out (or -1).  Slabs are consecutive image rows, lanes consecutive columns.
 // AHEAD = operand slabs in flight beyond the current one (1: conv.hip's kernels; -1: the LDS-DMA kernels, which have no registers to spare:
 // conditional loads at the point of use)
-template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1>
+// DEFER: nothing is stored; the finished tiles go to *defer (NHWC outputs only), epilogue_store_packed writes them later.
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1, bool DEFER = false>
 __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
-                                                PixOff pixoff, PoolOff pooloff = PoolOff()) {
+                                                PixOff pixoff, PoolOff pooloff = PoolOff(), PackedOut<T, MT, NT>* defer = nullptr) {
     constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
     const int h = lane >> 5;
     const T* addend = reinterpret_cast<const T*>(p.addend);
@@ -287,7 +332,9 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
                 else tile_unpack<T>(rb[mt & (AHEAD < 0 ? 0 : AHEAD)], a);
                 actgrad16(v, a, p.actout_kind);
             }
-            if (p.out_layout == FALNET_OUT_PLANAR_F32) {
+            if constexpr (DEFER) {
+                tile_pack<T>(v, defer->out[mt][nt]);
+            } else if (p.out_layout == FALNET_OUT_PLANAR_F32) {
                 // planar f32 [B][Cout][OH][OW] (the MED logits): o = offset of channel 0 of this lane's pixel, channel stride
                 // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
                 float* po = reinterpret_cast<float*>(p.out);
@@ -327,7 +374,8 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
                             tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
                             actgrad16(m, a, p.pool_actout_kind);
                         }
-                        tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
+                        if constexpr (DEFER) tile_pack<T>(m, defer->pool[mt >> 1][nt]);
+                        else tile_store<T>(pool_out, po, cbase, h, p.Cout, m);
                     }
                 }
             }
@@ -335,3 +383,22 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
     }
 }
 
+// Second half of a deferred epilogue: lane-half exchange + 16-B stores of the tiles epilogue_direct<..., DEFER> left in `d`.
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff>
+__device__ __forceinline__ void epilogue_store_packed(const falnet_conv_t& p, PackedOut<T, MT, NT>& d, int nbase, int lane, PixOff pixoff, PoolOff pooloff) {
+    const int h = lane >> 5;
+    T* out = reinterpret_cast<T*>(p.out);
+    T* pool_out = reinterpret_cast<T*>(p.pool_out);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cbase = nbase + nt * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (out) tile_store_packed<T>(out, pixoff(mt), cbase, h, p.Cout, d.out[mt][nt]);
+            if ((mt & 1) && pool_out) {
+                const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
+                tile_store_packed<T>(pool_out, po, cbase, h, p.Cout, d.pool[mt >> 1][nt]);
+            }
+        }
+    }
+}
