@@ -26,7 +26,8 @@
  *   - kernel-selection switches (A/B and tests; read once from the environment): FALNET_DISABLE_PATCH,
  *     FALNET_PATCH_KCB (conv.hip), FALNET_WR_FORM / FALNET_WR_ABL (wgrad_rows.hip), FALNET_HEAD_V1,
  *     FALNET_HEAD_BWD_V1, FALNET_HEAD_PAIR, FALNET_HEAD_FWD2, FALNET_HEAD_BWD2, FALNET_HEAD_WAVE (MED head), FALNET_MFMA16 (16x16x32 form of the
- *     weight-stationary kernel), FALNET_GEMM_WAVE (small f32 GEMM).
+ *     weight-stationary kernel), FALNET_WS2_FULL (whole-line loads of the two-phase weight-stationary kernel, variant 16), FALNET_GEMM_WAVE
+ *     (small f32 GEMM).  Host side (fal_net_amd/ops.py): FALNET_WS2 / FALNET_NO_DMA / FALNET_S2F_DMA gate autotune candidates.
  */
 #ifndef FALNET_HIP_H
 #define FALNET_HIP_H
