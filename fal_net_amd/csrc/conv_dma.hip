@@ -175,13 +175,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_lane[ks] = A_BYTES + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[NT][MT][1];  // [nt][mt]: the epilogue runs per 32-channel slice (one slice's bias / operands in registers at a time)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+            for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
     Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
     if (total > 0) {
         tile_offsets(qi.tile, 0);
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = H16<T>::mma(fb[st & 1][nt], fa[st & 1][mt], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[nt][mt][0] = H16<T>::mma(fb[st & 1][nt], fa[st & 1][mt], acc[nt][mt][0]);
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads of the next step
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
         }
@@ -266,15 +266,16 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
                 const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
                 return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
             };
-            float bias[NT][16];  // (loaded per tile: 32 registers that would otherwise stay live across the MFMA loop)
-            load_bias16<NT>(p, n0, h, bias);
-            epilogue_direct<T, MT, NT, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc, bias, n0, lane, pixoff, pooloff);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < NT; ++nt) {
+                float bias[1][16];  // (loaded per tile and slice: registers that would otherwise stay live across the MFMA loop)
+                load_bias16<1>(p, n0 + 32 * nt, h, bias);
+                epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff, pooloff);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[mt][nt][j] = 0.f;
+                    for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
+            }
         }
         CD_STAMP();  // 5: (epilogue) done
     }
