@@ -19,6 +19,8 @@ import json
 import os
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # application-level choice, before HIP initialises (fal_net_amd/__init__.py)
+
 parser = argparse.ArgumentParser(description='FAL_net Stage 1 on MI355X', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
 parser.add_argument('-d', '--data', metavar='DIR', default=None, help='path to dataset (unused with --synthetic)')
 parser.add_argument('-n0', '--dataName0', default='Kitti')
@@ -91,7 +93,12 @@ def main(step='stage1_step'):
             f.write(''.join('%15s: %s\n' % (k, v) for k, v in vars(args).items()))
 
     network_data = torch.load(args.pretrained, map_location='cpu') if args.pretrained else None
-    if stage2 and network_data is None:  # Stage 2 fine-tunes a Stage-1 model (Train_Stage2_K.py:66-71); without one: seeded weights
+    if stage2 and not args.synthetic and not (args.pretrained and args.fix_model) and not getattr(args, 'allow_seeded_teacher', False):
+        # the reference torch.loads both (Train_Stage2_K.py:66-71,190-198): a real-data Stage-2 run must not silently distil from a
+        # random, untrained teacher or fine-tune random weights
+        raise SystemExit('Stage 2 on real data needs --pretrained <stage-1 checkpoint> and --fix_model <stage-1 checkpoint> '
+                         '(seeded stand-ins are used with --synthetic only; --allow-seeded-teacher overrides, for tests)')
+    if stage2 and network_data is None:  # --synthetic: seeded stand-in for the Stage-1 model
         network_data = {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
     m_model = models.__dict__[args.m_model](network_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev)
     fix_model = None
@@ -122,11 +129,12 @@ def main(step='stage1_step'):
                                       shuffle=True, rank=rank, world=world)
         vroot = os.path.join(args.data, args.vdataName)
         vtriples = DS.kitti2015_pairs(vroot) if os.path.isdir(vroot) else []
-        if vtriples:
+        if vtriples and rank == 0:  # only rank 0 validates: the other ranks start no validation workers
             val_loader = DS.make_loader(DS.StereoValDataset(vroot, vtriples), args.tbatch_size, args.workers, shuffle=False, drop_last=False)
         real_augment = DT.StereoAugment(args.crop_height, args.crop_width)
         if rank == 0:
             print('=> {} training pairs, {} validation pairs'.format(len(pairs), len(vtriples)))
+    vtriples_any = train_loader is not None and bool(vtriples)  # the same on every rank (same files): gates the post-validation barrier
     steps_per_epoch = args.epoch_size or (len(train_loader) if train_loader is not None else 100)
     best = -1
     # synthetic mode: a small pool of seeded batches resident in HBM, cycled (generating 25 MB of noise on the CPU every
@@ -184,9 +192,14 @@ def main(step='stage1_step'):
             if i % args.print_freq == 0:
                 losses.update(float(out['loss']), args.batch_size)
                 rec_losses.update(float(out['rec']), args.batch_size)
+                if not (losses.val == losses.val and abs(losses.val) != float('inf')):  # fail loudly: a NaN loss never recovers
+                    raise FloatingPointError('non-finite loss {} at epoch {} iteration {}'.format(losses.val, epoch, i))
+                f16_scale = out['scaler'].check() if out.get('scaler') is not None else None  # raises when f16 gradients overflow at scale 1
                 if rank == 0:
                     rec = {'epoch': epoch, 'iter': i, 'of': steps_per_epoch, 'loss': losses.val, 'rec_loss': rec_losses.val,
                            'pairs_per_s': world * args.batch_size * (i + 1) / (time.time() - end)}
+                    if f16_scale is not None:
+                        rec['f16_loss_scale'], rec['f16_skipped_steps'] = f16_scale
                     if stage2:
                         rec['mirror'] = float(out['mirror'])
                     print(json.dumps(rec), flush=True)
@@ -199,6 +212,10 @@ def main(step='stage1_step'):
                 best = res['rmse']
             is_best = res['rmse'] <= best
             best = min(res['rmse'], best)
+        if world > 1 and vtriples_any:
+            # rank 0 validated (200 full-size frames, the first of each size builds a plan): hold the other ranks HERE rather than
+            # inside the next epoch's first gradient all-reduce, whose RCCL timeout that time would count against
+            dist.barrier()
         if rank == 0:
             utils.save_checkpoint({'epoch': epoch + 1, 'm_model': args.m_model, 'state_dict': m_model.state_dict(), 'best_rmse': best},
                                   is_best, save_path)

@@ -11,7 +11,9 @@ import Train_Stage1_K as base
 if __name__ == '__main__':
     base.parser.description = 'FAL_net Stage 2 on MI355X'
     base.parser.add_argument('-mirror_loss', '--a_mr', type=float, default=1)
-    base.parser.add_argument('--fix_model', default=None, help='Stage-1 checkpoint of the frozen teacher (reference format)')
+    base.parser.add_argument('--fix_model', default=None, help='Stage-1 checkpoint of the frozen teacher (reference format); required with -d')
+    base.parser.add_argument('--allow-seeded-teacher', action='store_true',
+                             help='real-data run WITHOUT Stage-1 checkpoints: seeded (untrained) student and teacher -- tests only')
     base.parser.set_defaults(batch_size=4, lr=0.00005, milestones=[5, 10], epochs=20, a_sm=0.4 * 2 / 512)
     base.args = base.parser.parse_args()
     base.main(step='stage2_step')

@@ -18,7 +18,10 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: see fal_net_amd/__init__.py (stream -> hardware-queue collisions)
+# The step runs three concurrent HIP streams; on HIP's default four hardware queues two of them sometimes share a queue and
+# serialize (1.5-13 % slower, one run in four to eight).  An application-level, process-global choice that must be made before HIP
+# initialises -- so it is made HERE (and in the Train_* / Test_KITTI scripts), not by importing the library (fal_net_amd/__init__.py).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 import torch.distributed as dist
@@ -70,17 +73,30 @@ def hbm_traffic_from_profiles(kernel_symbol):
     return None
 
 
-def cpu_baseline(workload, height, width, levels, sample_batch=2, timed=3):
-    """Reported CPU baseline: the oracle's step of the same workload (fp32, torch CPU) on a bounded sample: one warm-up
-    step, then `timed` steps, plus the single-pair forward of BASELINE configs[0].
-    Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get *slower* beyond that
-    (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, height, width, levels, sample_batch=8, timed=2):
+    """Reported CPU baseline: the oracle's step of the same workload (fp32, torch CPU) at the benchmark's own batch (B = 8,
+    BASELINE.md section 4) on a bounded sample: one warm-up step, then `timed` steps (about 30 s on the GPU box's host), plus the
+    single-pair forward of BASELINE configs[0].  Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get
+    *slower* beyond that (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
     from fal_net_amd import synthetic
     from oracle import falnet_oracle as O
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     if height * width > 256 * 512:
         sample_batch, timed = 1, 2  # 384x1280, N=96: one pair per step keeps the leg under a minute
+    elif workload == "stage2":
+        sample_batch = 4  # the Stage-2 step runs three 2B forwards: B=4 keeps the leg at about 30 s
     left, right, mn, mx = synthetic.synthetic_pair(sample_batch, height, width, seed=1234)
     sd = synthetic.seeded_falnetb_state_dict(levels)
     params = O.leaf_params(sd)
@@ -110,7 +126,8 @@ def cpu_baseline(workload, height, width, levels, sample_batch=2, timed=3):
         fwd = (time.time() - t1) / 3
     name = {"stage1": "Stage-1 step (fwd+VGG+losses+bwd+Adam)", "stage2": "Stage-2 step (teacher fwd, 2B student fwd, masks, losses, bwd, Adam)",
             "highres": "Stage-1 step (fwd+VGG+losses+bwd+Adam)"}[workload]
-    return {"value": sample_batch / dt, "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
+    return {"value": sample_batch / dt, "unit": "stereo-pairs/s", "cores": cores, "kind": "port", "host_cpu": host_cpu_model(),
+            "host_logical_cpus": os.cpu_count(),
             "sample": f"1 warm-up + {timed} timed x {name}, B={sample_batch}, {height}x{width}, N={levels}, "
                       f"fp32 torch-CPU oracle, {torch.get_num_threads()} threads, {dt:.2f} s per step",
             "configs0_forward_pairs_per_s": 1.0 / fwd,
@@ -142,6 +159,76 @@ def parity_vs_oracle(height, width, levels, dev):
     out["gate_f32"] = 1e-4
     out["sample"] = f"1 pair, {height}x{width}, N={levels}, seeded weights, forward (disp) vs CPU oracle"
     return out
+
+
+def allreduce_report(model, step, args, world, rank, dev, ms_per_step):
+    """The step's single collective, measured after the timed region (every rank takes part; rank 0 reports):
+      * `param_checksum_equal`: the flat parameter buffers of all ranks are still bit-identical after the timed steps (a racing
+        bucket of the overlapped all-reduce would make them drift) -- asserted on every rank;
+      * `isolated_ms`: each gradient bucket's all-reduce and the whole 67.7 MB buffer alone (barrier, HIP events around the
+        collective on the current stream, median of 5), with the achieved bus bandwidth 2 (N-1)/N x bytes / time against the xGMI
+        bounds of BASELINE.md section 3 (ring, per-link 153 GB/s: 0.78 ms at N = 8; all seven links direct: 0.11 ms);
+      * `exposed_ms` = step time - step time of the same steps with the collective SKIPPED (same box, same kernels): what the
+        pipelined buckets do not hide behind backward."""
+    import torch.distributed as dist
+    from fal_net_amd import train
+    flat, grad = model.flat_parameters(), model.flat_gradients()
+    d = flat.double()
+    mine = torch.stack([d.sum(), (d * d).sum(), d.abs().max()])
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(torch.equal(lo, hi))
+    assert same, f"rank {rank}: parameters differ across ranks after the timed steps (checksum {mine.tolist()} not in [{lo.tolist()}, {hi.tolist()}])"
+    seen = torch.zeros(world, device=dev)
+    seen[rank] = 1
+    dist.all_reduce(seen)
+
+    def timed_allreduce(t):
+        ts = []
+        for _ in range(6):
+            dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts[1:])[len(ts[1:]) // 2]
+    scratch = torch.zeros_like(grad)
+    buckets = model.gradient_buckets()
+    iso = {"whole_buffer": timed_allreduce(scratch)}
+    for i, (a, b) in enumerate(buckets):
+        iso[f"bucket{i}"] = timed_allreduce(scratch[a:b])
+    nbytes = grad.numel() * 4
+    busbw = lambda ms_, nb: 2 * (world - 1) / max(world, 1) * nb / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+    # the same steps without the collective (weights diverge across ranks from here on: nothing after this compares them)
+    train._SKIP_ALLREDUCE = True
+    try:
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    finally:
+        train._SKIP_ALLREDUCE = False
+    ms_nocomm = float(t) * 1e3 / args.steps
+    ring_ms = 2 * (world - 1) / max(world, 1) * nbytes / 153e9 * 1e3
+    direct_ms = ring_ms / 7.0
+    return {"bytes": nbytes, "buckets_bytes": [(b - a) * 4 for a, b in buckets], "overlapped": getattr(model, "bucket_hook", None) is not None,
+            "ranks_seen": int(seen.sum().item()), "param_checksum_equal": same,
+            "isolated_ms": iso, "isolated_busbw_GBps": {k: busbw(v, nbytes if k == "whole_buffer" else (buckets[int(k[6:])][1] - buckets[int(k[6:])][0]) * 4)
+                                                        for k, v in iso.items()},
+            "ms_per_step_without_collective": ms_nocomm, "exposed_ms": ms_per_step - ms_nocomm,
+            "xgmi_bound_ms": {"ring_per_link_153GBps": ring_ms, "all_7_links_direct": direct_ms},
+            "isolated_vs_ring_bound": (ring_ms / iso["whole_buffer"]) if iso["whole_buffer"] > 0 else None}
 
 
 def main():
@@ -251,6 +338,9 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss,
                    "launch": "hipGraph replay" if graphed else "eager"},
     }
+
+    if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
+        result["allreduce"] = allreduce_report(model, eager_step, args, world, rank, dev, ms)
 
     if rank == 0 and not args.no_roofline:
         # instrumented pass (NOT part of the timed region): HIP events around every launch

@@ -109,6 +109,10 @@ SIGNATURES = {
     "falnet_mask_mix": [_P, _P, _P, _P, _I, _I, _L, _P],
     "falnet_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "falnet_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
+    "falnet_adam_step_guarded": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _P],
+    "falnet_grad_guard": [_P, _L, _P, _P],
+    "falnet_loss_scale_update": [_P, _F, _F, _I, _F, _F, _P],
+    "falnet_loss_seeds": [_P, _P, _P, _I, _P],
     "falnet_hflip": [_P, _P, _L, _I, _P],
     "falnet_resample_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "falnet_augment_normalize": [_P, _I, _I, _I, _I, _I, _I, _I, _D, _D, _D, _D, _D, _F, _F, _F, _P, _P],

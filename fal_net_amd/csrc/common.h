@@ -7,6 +7,16 @@
 
 void falnet_set_error(const char* fmt, ...);
 
+// Kernel-selection switches are for A/B experiments and ablations only: the product library (default build) reads NO environment
+// variable -- every switch sits at its default and the alternative kernels are not reachable.  `python -m fal_net_amd._build --ab`
+// (-DFALNET_AB) builds the experiment library in which the FALNET_* variables named in include/falnet_hip.h are honoured.
+#ifdef FALNET_AB
+#include <stdlib.h>
+static inline const char* falnet_ab_env(const char* name) { return getenv(name); }
+#else
+static inline const char* falnet_ab_env(const char*) { return nullptr; }
+#endif
+
 #define FALNET_CHECK_ARG(cond, ...)                 \
     do {                                            \
         if (!(cond)) {                              \

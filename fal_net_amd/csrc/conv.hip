@@ -2676,7 +2676,7 @@ static void launch_conv(const falnet_conv_t& p, int bn, dim3 grid, hipStream_t s
 // The same conversion of the LDS-DMA kernel (half steps (tap, channel half), positions of a tap shared by both halves) passed every test and
 // measured neutral in the step (1264 vs 1268 pairs/s), and so did the nine-tap stages of the halo-patch kernel (1258 vs 1257): not kept.
 static bool falnet_mfma16_enabled() {
-    static const bool on = [] { const char* e = getenv("FALNET_MFMA16"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = falnet_ab_env("FALNET_MFMA16"); return !(e && e[0] == '0'); }();
     return on;
 }
 
@@ -2687,9 +2687,9 @@ struct ConvChoice {
 };
 
 // A/B switch for tests and profiling: FALNET_DISABLE_PATCH=1 routes every launch to the gather kernel
-static bool g_disable_patch = [] { const char* e = getenv("FALNET_DISABLE_PATCH"); return e && e[0] == '1'; }();
+static bool g_disable_patch = [] { const char* e = falnet_ab_env("FALNET_DISABLE_PATCH"); return e && e[0] == '1'; }();
 // K bytes per chunk of the pipelined patch kernel: 128 (1 workgroup/CU), 64 (2 workgroups/CU), 0 = mode S only
-static int g_patch_kcb = [] { const char* e = getenv("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
+static int g_patch_kcb = [] { const char* e = falnet_ab_env("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
 
 
 bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // conv_dma.hip
@@ -2819,7 +2819,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
 
 // conv3x3_ws2_kernel's FULL form: both 64-B chunks from ONE source of exactly 128 B per pixel -> one load stream of whole 128-B lines
 static bool ws2_whole_lines(const falnet_conv_t& p) {
-    static const bool on = !(getenv("FALNET_WS2_FULL") && atoi(getenv("FALNET_WS2_FULL")) == 0);
+    static const bool on = !(falnet_ab_env("FALNET_WS2_FULL") && atoi(falnet_ab_env("FALNET_WS2_FULL")) == 0);
     return on && p.nsrc == 1 && (int64_t)p.src[0].C * (p.dtype == FALNET_F32 ? 4 : 2) == 128;
 }
 

@@ -782,7 +782,7 @@ bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p) {
 int falnet_conv_s2f_dma_launch(const falnet_conv_t& p, hipStream_t st) {
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 7) / 8;
     const int ntiles = p.B * tiles_x * tiles_y;
-    static const bool allow128 = [] { const char* e = getenv("FALNET_S2F_BN128"); return e && e[0] == '1'; }();  // (128-channel form: 36-41 spilled VGPRs)
+    static const bool allow128 = [] { const char* e = falnet_ab_env("FALNET_S2F_BN128"); return e && e[0] == '1'; }();  // (128-channel form: 36-41 spilled VGPRs)
     const bool wide = allow128 && p.w_rows % 128 == 0 && p.Cout > 64;
     const int bn = wide ? 128 : 64;
     const int ny = (p.Cout + bn - 1) / bn;

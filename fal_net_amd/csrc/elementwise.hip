@@ -330,7 +330,7 @@ extern "C" int falnet_gemm_f32_small(const float* A, int64_t sam, int64_t sak, c
                                      int M, int N, int K, int accumulate, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && (int64_t)M * N * K <= (1ll << 32), "gemm_f32_small: bad argument (small products only)");
-    static const bool wave_form = [] { const char* e = getenv("FALNET_GEMM_WAVE"); return !(e && e[0] == '0'); }();
+    static const bool wave_form = [] { const char* e = falnet_ab_env("FALNET_GEMM_WAVE"); return !(e && e[0] == '0'); }();
     if (wave_form && K >= 256 && (int64_t)M * N <= 65536) {
         const int64_t waves = (int64_t)M * N;
         hipLaunchKernelGGL(gemm_f32_small_wave_kernel, dim3((unsigned)((waves + 3) / 4 > 4096 ? 4096 : (waves + 3) / 4)), dim3(EW_THREADS), 0,

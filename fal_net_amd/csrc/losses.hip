@@ -354,7 +354,11 @@ __global__ __launch_bounds__(RED_THREADS) void adam_kernel(float* __restrict__ p
 __global__ __launch_bounds__(RED_THREADS) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                                const float* __restrict__ state, float b1, float b2, float eps,
-                                                               float grad_scale) {
+                                                               float grad_scale, const float* __restrict__ scaler) {
+    if (scaler != nullptr) {
+        if (scaler[2] != 0.f) return;  // non-finite gradient somewhere: skip the whole update (uniform over the grid)
+        grad_scale /= scaler[0];
+    }
     const float lr = state[0];
     const float t = state[1] + 1.0f;
     const float step_size = lr / (1.0f - powf(b1, t));
@@ -379,7 +383,41 @@ __global__ __launch_bounds__(RED_THREADS) void adam_dev_kernel(float* __restrict
         reinterpret_cast<float4*>(v)[i] = vv;
     }
 }
-__global__ void adam_tick_kernel(float* state) { state[1] += 1.0f; }
+__global__ void adam_tick_kernel(float* state, const float* __restrict__ scaler) {
+    if (scaler == nullptr || scaler[2] == 0.f) state[1] += 1.0f;  // a skipped (overflowed) step does not count
+}
+
+// ------------------------------------------------------------------ dynamic loss scale of the f16 path (GradScaler semantics, device-resident)
+// scaler = {scale, good_steps, overflow_flag, skipped_steps}.  The guard raises the flag when any element of the (all-reduced)
+// flat gradient is inf / NaN; the guarded Adam then leaves p, m, v and the step count untouched; the update kernel halves the scale
+// (or doubles it after `interval` clean steps) and clears the flag.  No host synchronisation anywhere.
+__global__ __launch_bounds__(RED_THREADS) void grad_guard_kernel(const float* __restrict__ g, int64_t n4, float* __restrict__ scaler) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        // (x - x) is 0 for every finite x and NaN for inf / NaN
+        const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad |= !(t == 0.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) scaler[2] = 1.f;  // benign race: every writer stores the same value
+}
+__global__ void loss_seeds_kernel(const float* __restrict__ scaler, const float* __restrict__ coef, float* __restrict__ seeds, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) seeds[i] = scaler[0] * coef[i];
+}
+__global__ void loss_scale_update_kernel(float* scaler, float growth, float backoff, float interval, float min_scale, float max_scale) {
+    if (scaler[2] != 0.f) {
+        scaler[0] = fmaxf(scaler[0] * backoff, min_scale);
+        scaler[1] = 0.f;
+        scaler[3] += 1.f;
+    } else {
+        scaler[1] += 1.f;
+        if (scaler[1] >= interval) {
+            scaler[0] = fminf(scaler[0] * growth, max_scale);
+            scaler[1] = 0.f;
+        }
+    }
+    scaler[2] = 0.f;
+}
 
 // ------------------------------------------------------------------ flip / per-sample max (Train_Stage2_K.py:248-253,319)
 __global__ __launch_bounds__(RED_THREADS) void hflip_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -537,13 +575,41 @@ extern "C" int falnet_adam_step(float* p, const float* g, float* m, float* v, in
     FALNET_RETURN_LAUNCH();
 }
 
-extern "C" int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
-                                    float eps, float grad_scale, void* stream) {
+static int adam_dev_launch(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2, float eps, float grad_scale,
+                           const float* scaler, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(p && g && m && v && state && n > 0 && (n & 3) == 0, "adam_step_dev: bad argument (n must be a multiple of 4)");
     FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_dev: buffers must be 16-B aligned");
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps, grad_scale);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps, grad_scale, scaler);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, scaler);
+    FALNET_RETURN_LAUNCH();
+}
+extern "C" int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
+                                    float eps, float grad_scale, void* stream) {
+    return adam_dev_launch(p, g, m, v, n, state, b1, b2, eps, grad_scale, nullptr, stream);
+}
+extern "C" int falnet_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
+                                        float eps, float grad_scale, const float* scaler, void* stream) {
+    FALNET_CHECK_ARG(scaler, "adam_step_guarded: scaler is NULL");
+    return adam_dev_launch(p, g, m, v, n, state, b1, b2, eps, grad_scale, scaler, stream);
+}
+extern "C" int falnet_grad_guard(const float* g, int64_t n, float* scaler, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(g && scaler && n > 0 && (n & 3) == 0 && ((uintptr_t)g & 15) == 0, "grad_guard: bad argument (n % 4 == 0, 16-B aligned)");
+    hipLaunchKernelGGL(grad_guard_kernel, dim3(1024), dim3(RED_THREADS), 0, (hipStream_t)stream, g, n >> 2, scaler);
+    FALNET_RETURN_LAUNCH();
+}
+extern "C" int falnet_loss_seeds(const float* scaler, const float* coef, float* seeds, int n, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(scaler && coef && seeds && n > 0, "loss_seeds: bad argument");
+    hipLaunchKernelGGL(loss_seeds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, coef, seeds, n);
+    FALNET_RETURN_LAUNCH();
+}
+extern "C" int falnet_loss_scale_update(float* scaler, float growth, float backoff, int interval, float min_scale, float max_scale, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(scaler && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval >= 1 && min_scale > 0.f && max_scale >= min_scale,
+                     "loss_scale_update: bad argument");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scaler, growth, backoff, (float)interval, min_scale, max_scale);
     FALNET_RETURN_LAUNCH();
 }
 

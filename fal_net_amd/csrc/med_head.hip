@@ -686,7 +686,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void med_maskr_acfalse_kernel(
 // ---------------------------------------------------------------------------------------- C-ABI
 #include <stdlib.h>
 // FALNET_HEAD_V1=1: first forward kernel (per-lane global taps) instead of the LDS-staged one (A/B, tests)
-static const bool g_head_v1 = [] { const char* e = getenv("FALNET_HEAD_V1"); return e && e[0] == '1'; }();
+static const bool g_head_v1 = [] { const char* e = falnet_ab_env("FALNET_HEAD_V1"); return e && e[0] == '1'; }();
 
 // wave-neighbour kernels (med_head2.hip)
 bool falnet_head_wave_applicable(int W);
@@ -776,8 +776,8 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     FALNET_CHECK_ARG(cpad >= N && cpad % 8 == 0, "med_head_bwd_nhwc: cpad=%d must be a multiple of 8 >= N", cpad);
     FALNET_CHECK_ARG(dtype == FALNET_F32 || dtype == FALNET_BF16 || dtype == FALNET_F16, "med_head_bwd_nhwc: bad dtype %d", dtype);
     const size_t lds = sizeof(PlaneTab) + (size_t)5 * (W + 3) * sizeof(float);
-    static const bool v1 = [] { const char* e = getenv("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
-    static const int pair = [] { const char* e = getenv("FALNET_HEAD_PAIR"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const bool v1 = [] { const char* e = falnet_ab_env("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
+    static const int pair = [] { const char* e = falnet_ab_env("FALNET_HEAD_PAIR"); return (e && e[0] == '0') ? 0 : 1; }();
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!v1 && al16(dlog0) && al16(grad_dlog0_nhwc) &&
         falnet_head_bwd_lds2_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, grad_disp, grad_p_im0, grad_dlog0_nhwc, cpad, dtype, B, N, H,

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NT) void med_head_fwd_lds2_kernel(
 
 bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
                                  float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream) {
-    static const bool off = [] { const char* e = getenv("FALNET_HEAD_FWD2"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_FWD2"); return e && e[0] == '0'; }();
     if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;  // (plane table: 128 entries, read up to N - 1 + HW_CH - 1)
     const int wp = (W + 7) & ~3;
     const size_t lds = (size_t)(3 + HW_CH) * wp * sizeof(float);
@@ -737,7 +737,7 @@ static void bwd_lds2_launch_t(const float* dlog0, const float* left, const float
 bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, const float* disp,
                                  const float* p_im0, const float* stats, const float* gdisp, const float* gpan, void* gdlog0, int cpad,
                                  int dtype, int B, int N, int H, int W, hipStream_t stream) {
-    static const bool off = [] { const char* e = getenv("FALNET_HEAD_BWD2"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_BWD2"); return e && e[0] == '0'; }();
     if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;
     // 8 x 384 x 1280, N = 96: 16-bit gradient 991 us here vs 955 us on the wave-neighbour kernel (f32: 1277 vs 1357; forward 652 vs 1097)
     if (W > 1024 && dtype != FALNET_F32 && falnet_head_wave_applicable(W)) return false;
@@ -749,7 +749,7 @@ bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const fl
 
 // ---------------------------------------------------------------------------------------- launch helpers (called from med_head.hip's C-ABI)
 bool falnet_head_wave_applicable(int W) {
-    static const bool off = [] { const char* e = getenv("FALNET_HEAD_WAVE"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_WAVE"); return e && e[0] == '0'; }();
     return !off && (W & 3) == 0 && W >= 64 && W <= 62 * 16 * 2;
 }
 

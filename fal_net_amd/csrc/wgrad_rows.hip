@@ -707,8 +707,8 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
     const int ntiles = ntci * ntco;
     const int nstrips = (p.TW + WR_TW - 1) / WR_TW;
     const dim3 grid((unsigned)(ntiles * p.nsplit));
-    static const int abl = [] { const char* e = getenv("FALNET_WR_ABL"); return e ? atoi(e) : 0; }();
-    static const int form = [] { const char* e = getenv("FALNET_WR_FORM"); return e ? atoi(e) : 8; }();  // 8: eight-wave form (default), 4: four waves
+    static const int abl = [] { const char* e = falnet_ab_env("FALNET_WR_ABL"); return e ? atoi(e) : 0; }();
+    static const int form = [] { const char* e = falnet_ab_env("FALNET_WR_FORM"); return e ? atoi(e) : 8; }();  // 8: eight-wave form (default), 4: four waves
 #define WR_LAUNCH8(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<TT, DD, AA>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
 #define WR_LAUNCH4(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<TT, DD, AA>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
     if (form == 4) {

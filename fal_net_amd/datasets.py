@@ -68,6 +68,25 @@ def kitti2015_pairs(root, with_disp=True):
     return out
 
 
+def eigen_test_triples(list_file, root):
+    """The Eigen test split with improved ground truth (Datasets/Kitti_eigen_test_improved.py:33-45): every line of `list_file` is
+    'left right' (or 'left right gt'); the ground truth of a two-column line is the projected depth map beside the drive,
+    <drive>/proj_depth/groundtruth/image_02/<frame>.png, derived from the left path exactly as the reference slices it (the last 29
+    characters are 'image_02/data/<10 digits>.png').  Lines whose image or ground truth is missing under `root` are skipped."""
+    if not os.path.isfile(list_file):
+        raise FileNotFoundError(f"test list {list_file!r} not found (one 'left right [gt]' line per frame, paths relative to <data>/<tdataName>)")
+    out = []
+    with open(list_file) as f:
+        for ln in f.read().splitlines():
+            c = ln.split()
+            if len(c) < 2:
+                continue
+            gt = c[2] if len(c) >= 3 else os.path.join(c[0][0:-29], "proj_depth", "groundtruth", "image_02", c[0][-14:])
+            if os.path.isfile(os.path.join(root, c[0])) and os.path.isfile(os.path.join(root, gt)):
+                out.append((c[0], c[1], gt))
+    return out
+
+
 class StereoValDataset(data.Dataset):
     """Full-size validation pairs with ground-truth disparity (listdataset_test.py:52-113; KITTI disparity PNGs are uint16 / 256,
     :43-46).  __getitem__ -> (left_u8, right_u8, disp_f32 (H, W) or None)."""

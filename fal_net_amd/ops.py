@@ -29,11 +29,37 @@ AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 # Every plan-build-time choice (conv variant / split-K factor, fused vs separate stride-2 data gradients) is remembered in a JSON
 # file next to the library, keyed by the launch's shape signature: a later process replays the same variants WITHOUT timing
 # launches -- bench, profile and test runs then execute the same kernels (reproducible traces, no autotune launches inside a
-# rocprofv3 collection, two ranks of one job on the same choices).  FALNET_AUTOTUNE_CACHE=<path> moves the file, =0 disables
-# it; a miss is autotuned as before and appended (best effort: a read-only tree just keeps autotuning).
-_CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_cache.json"))
+# rocprofv3 collection, two ranks of one job on the same choices).
+#   * The file carries a header (`_meta`): the hash of the conv kernel sources it was tuned with, falnet_version() and the GPU
+#     architecture.  A file whose header does not match the running library is IGNORED (every entry re-tuned): a stale entry can
+#     no longer pin a variant after a kernel rewrite.
+#   * The packaged file is READ-ONLY for ordinary processes (tests, training, bench): new choices live in memory only.  It is
+#     written when FALNET_AUTOTUNE_CACHE=<path> names a file explicitly (tools/regen_cache.sh) or FALNET_AUTOTUNE_CACHE_WRITE=1.
+#   * FALNET_AUTOTUNE_CACHE=0 disables it; so does any non-default candidate-gating switch (FALNET_NO_DMA, FALNET_WS2,
+#     FALNET_S2F_DMA, FALNET_S2D_DMA, FALNET_S2_SPLITK, FALNET_GATHER_NARROW): an A/B run must tune, not replay.
+_PKG_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_cache.json")
+_CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", _PKG_CACHE)
+_CACHE_WRITABLE = ("FALNET_AUTOTUNE_CACHE" in os.environ and _CACHE_PATH != "0") or os.environ.get("FALNET_AUTOTUNE_CACHE_WRITE") == "1"
+_GATES = {"FALNET_NO_DMA": "0", "FALNET_WS2": "1", "FALNET_S2F_DMA": "1", "FALNET_S2D_DMA": "1", "FALNET_S2_SPLITK": "1",
+          "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_DMA128": "1"}
+if any(os.environ.get(k, v) != v for k, v in _GATES.items()):
+    _CACHE_PATH = "0"
 _CACHE = None
 _CACHE_DIRTY = False
+_TUNE_SOURCES = ("conv.hip", "conv_dma.hip", "conv_epilogue.h", "common.h", "deep.hip")  # what a cached conv choice depends on
+
+
+def cache_meta():
+    """Header a cache file must carry to be replayed by this library build."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in _TUNE_SOURCES:
+        path = os.path.join(csrc, name)
+        if os.path.isfile(path):
+            with open(path, "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return {"src_hash": h.hexdigest()[:16], "version": int(L.lib().falnet_version()), "arch": "gfx950"}
 
 
 def _cache():
@@ -44,7 +70,11 @@ def _cache():
             try:
                 import json
                 with open(_CACHE_PATH) as f:
-                    _CACHE = json.load(f)
+                    data = json.load(f)
+                if data.pop("_meta", None) == cache_meta():
+                    _CACHE = data
+                elif os.environ.get("FALNET_AUTOTUNE_LOG") == "1":
+                    print(f"[autotune] {_CACHE_PATH}: tuned with another build of the kernels -- ignored", file=sys.stderr)
             except (OSError, ValueError):
                 _CACHE = {}
     return _CACHE
@@ -62,15 +92,15 @@ def cache_put(key, value):
 
 
 def cache_flush():
-    """Write new choices back (atomic rename; silently skipped when the tree is read-only)."""
+    """Write new choices back (atomic rename) -- only to a file the user named or with FALNET_AUTOTUNE_CACHE_WRITE=1."""
     global _CACHE_DIRTY
-    if not _CACHE_DIRTY or _CACHE_PATH == "0":
+    if not _CACHE_DIRTY or _CACHE_PATH == "0" or not _CACHE_WRITABLE:
         return
     try:
         import json
         tmp = _CACHE_PATH + f".{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump(dict(sorted(_cache().items())), f, indent=0)
+            json.dump({"_meta": cache_meta(), **dict(sorted(_cache().items()))}, f, indent=0)
         os.replace(tmp, _CACHE_PATH)
         _CACHE_DIRTY = False
     except OSError:

@@ -33,7 +33,9 @@ class FlatAdam:
         for p in self.model.parameters():
             p.grad = None
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, scaler=None):
+        """`scaler`: the model's LossScaler (f16 path) -- the update then divides the gradients by the device-resident scale, is
+        skipped as a whole when the all-reduced gradient holds an inf / NaN, and the scale backs off / grows (GradScaler semantics)."""
         flat, grad = self.model.flat_parameters(), self.model.flat_gradients()
         if flat is None:
             raise RuntimeError("FlatAdam.step before any forward/backward of the model")
@@ -47,8 +49,15 @@ class FlatAdam:
             self.state[0] = self._lr_dev
         self.t += 1
         b1, b2 = self.betas
-        L.check(L.lib().falnet_adam_step_dev(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
-                                             b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
+        if scaler is None:
+            L.check(L.lib().falnet_adam_step_dev(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
+                                                 b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
+        else:
+            st = L.stream_ptr()
+            L.check(L.lib().falnet_grad_guard(L.ptr(grad), grad.numel(), L.ptr(scaler.state), st), "grad_guard")
+            L.check(L.lib().falnet_adam_step_guarded(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
+                                                     b1, b2, self.eps, float(grad_scale), L.ptr(scaler.state), st), "adam_step_guarded")
+            scaler.update()
         if _os.environ.get("FALNET_PACK_AFTER_ADAM", "1") == "1":
             self.model.repack_after_optimizer()  # the raw-pointer update is invisible to autograd's version counters
         else:
@@ -56,24 +65,72 @@ class FlatAdam:
 
 
 # f16 compute path: activation gradients are stored in IEEE half (normal range >= 6.1e-5) while a mean loss over B*3*H*W
-# elements seeds them at ~1e-7 -- they would flush to subnormals / zero.  Static loss scaling: backward runs on S * loss
-# (every autograd node of the step is linear in its upstream gradient), the f32 weight gradients come out S times too
-# large and 1/S is folded into the fused Adam launch beside 1/world.  bf16 / f32 have the f32 exponent range: S = 1.
+# elements seeds them at ~1e-7 -- they would flush to subnormals / zero.  Loss scaling: backward runs on S * loss (every node of
+# the step is linear in its upstream gradient), the f32 weight gradients come out S times too large and 1/S is folded into
+# the fused Adam launch beside 1/world.  bf16 / f32 have the f32 exponent range: S = 1, no scaler.
+# S is DYNAMIC and lives on the device (GradScaler semantics without a host sync): a gradient that overflows f16 (|x| > 65504)
+# somewhere in backward puts inf / NaN into the flat f32 gradient; falnet_grad_guard (after the all-reduce, so every rank
+# decides alike) raises a flag, the guarded Adam skips the whole update, and the scale halves; it doubles again after
+# FALNET_F16_GROWTH_INTERVAL clean steps.  A run whose scale has collapsed to 1 and still overflows is broken: LossScaler.check()
+# (called at --print-freq by the training scripts) raises.
 _F16_LOSS_SCALE = float(_os.environ.get("FALNET_F16_LOSS_SCALE", "8192"))
+_F16_GROWTH_INTERVAL = int(_os.environ.get("FALNET_F16_GROWTH_INTERVAL", "2000"))
 
 
-def loss_scale(model):
-    return _F16_LOSS_SCALE if getattr(model, "compute_dtype", None) == torch.float16 else 1.0
+class LossScaler:
+    """Device-resident dynamic loss scale: state = [scale, clean steps, overflow flag, skipped steps] (f32[4])."""
+
+    def __init__(self, device, init=None, growth=2.0, backoff=0.5, interval=None, min_scale=1.0, max_scale=65536.0):
+        self.state = torch.tensor([float(init or _F16_LOSS_SCALE), 0.0, 0.0, 0.0], device=device)
+        self.growth, self.backoff, self.interval = growth, backoff, int(interval or _F16_GROWTH_INTERVAL)
+        self.min_scale, self.max_scale = min_scale, max_scale
+        self._seeds = {}
+
+    def seeds(self, *coef):
+        """Device tensor seeds[i] = scale * coef[i] for THIS step (one tiny launch): the `gscale` operands of the loss kernels."""
+        key = tuple(float(c) for c in coef)
+        if key not in self._seeds:
+            self._seeds[key] = (torch.tensor(key, device=self.state.device), torch.empty(len(key), device=self.state.device))
+        c, out = self._seeds[key]
+        L.check(L.lib().falnet_loss_seeds(L.ptr(self.state), L.ptr(c), L.ptr(out), len(key), L.stream_ptr()), "loss_seeds")
+        return out
+
+    def scale_tensor(self):
+        return self.state[0]
+
+    def update(self):
+        L.check(L.lib().falnet_loss_scale_update(L.ptr(self.state), self.growth, self.backoff, self.interval, self.min_scale, self.max_scale,
+                                                 L.stream_ptr()), "loss_scale_update")
+
+    def check(self):
+        """Host-side health check (synchronises: call it at logging frequency, not per step).  Returns (scale, skipped steps);
+        raises when the scale has backed off to its floor and the last step still overflowed -- the run is diverging."""
+        scale, clean, flag, skipped = (float(x) for x in self.state.tolist())
+        if scale <= self.min_scale and clean == 0 and skipped > 0:
+            raise FloatingPointError(f"f16 step: gradients are non-finite even at loss scale {scale} ({int(skipped)} steps skipped): "
+                                     "the run diverged (use --dtype bf16 / f32 or a lower learning rate)")
+        return scale, int(skipped)
+
+
+def loss_scaler(model):
+    """The model's LossScaler (created on first use) on the f16 compute path, None otherwise."""
+    if getattr(model, "compute_dtype", None) != torch.float16:
+        return None
+    sc = getattr(model, "_loss_scaler", None)
+    dev = next(model.parameters()).device
+    if sc is None or sc.state.device != dev:
+        sc = model._loss_scaler = LossScaler(dev)
+    return sc
 
 
 def scaled_backward(loss, model):
-    """loss.backward() with the model's loss scale; returns the factor the optimiser must apply to the gradients."""
-    s = loss_scale(model)
-    if s == 1.0:
+    """loss.backward() under the model's loss scale; returns the LossScaler the optimiser must be given (None: no scaling)."""
+    sc = loss_scaler(model)
+    if sc is None:
         loss.backward()
-        return 1.0
-    (loss * s).backward()
-    return 1.0 / s
+        return None
+    (loss * sc.scale_tensor()).backward()
+    return sc
 
 
 def sync_parameters(model, check=True):
@@ -111,8 +168,13 @@ def enable_overlapped_allreduce(model):
     model._pending_reduces = []
 
     def hook(bucket, flat_slice):
+        if _SKIP_ALLREDUCE:
+            return
         model._pending_reduces.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True))
     model.bucket_hook = hook
+
+
+_SKIP_ALLREDUCE = False  # bench.py only: time the same steps without the collective (exposed communication = the difference)
 
 
 def allreduce_gradients(model):
@@ -121,6 +183,10 @@ def allreduce_gradients(model):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DIST):
         return 1.0
     pending = getattr(model, "_pending_reduces", None)
+    if _SKIP_ALLREDUCE:
+        if pending:
+            pending.clear()
+        return 1.0 / dist.get_world_size()
     if pending:
         for w in pending:
             w.wait()  # current stream waits for the collective
@@ -187,7 +253,12 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     plan = model._plan(B, H, W, dev)
     plan._ensure_backward()
     b = plan.buf
-    s = loss_scale(model)
+    sc = loss_scaler(model)
+    if sc is None:
+        seed_l1, seed_p, seed_sm = _seed(dev, 1.0), _seed(dev, a_p), _seed(dev, a_sm)
+    else:  # f16: the upstream scalars carry the device-resident loss scale
+        sd3 = sc.seeds(1.0, a_p, a_sm)
+        seed_l1, seed_p, seed_sm = sd3[0:], sd3[1:], sd3[2:]
     joins = []
     if a_p > 0:
         if _os.environ.get("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
@@ -210,7 +281,7 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     n_img = B * C * H * W
     # every loss term AND its adjoint in one pass over its operands (the upstream scalars -- loss scale, a_p, a_sm -- are known now)
     g_pan, g_disp = b["g_pan"], b["g_disp"]
-    L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(_seed(dev, s)), L.ptr(g_pan), st),
+    L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(g_pan), st),
             "l1_fwd_bwd")  # loss_functions.py:53
     vplan = None
     if a_p > 0:
@@ -230,12 +301,12 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
             sc = 1.0 / o.numel()
             feats.append((o, ln, Bo * Ho * Wo, Co, sc))
         for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
-            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(_seed(dev, s * a_p)), L.ptr(go), code, st),
+            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(seed_p), L.ptr(go), code, st),
                     "mse_fwd_bwd")
     x0 = int(0.20 * W)
     sc_sm = 1.0 / (B * H * (W - x0))
     if a_sm > 0:  # Train_Stage1_K.py:255
-        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), L.ptr(_seed(dev, s * a_sm)),
+        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), L.ptr(seed_sm),
                                           L.ptr(g_disp), st), "smooth_fwd_bwd")
     # ---- the VGG adjoint (every node is linear in its upstream scalar: s = loss scale) joins the L1 gradient ----
     if vplan is not None:
@@ -244,12 +315,11 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
         g_pan.add_(vplan.g_in)
         vplan.busy = False
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
-    unscale = 1.0 / s
     Sc = S.clone()  # the accumulators are reused by the next step
     out = {"loss": torch.add(Sc[0], Sc[1], alpha=a_sm), "rec": Sc[0], "sm": Sc[1] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp,
-           "grad_scale": unscale}
+           "scaler": sc}
     if optimize:
-        opt.step(allreduce_gradients(model) * unscale)
+        opt.step(allreduce_gradients(model), scaler=sc)
     return out
 
 
@@ -283,11 +353,11 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
         c = int(0.20 * W)
         sm_loss = smoothness(left[:, :, :, c:], ldisp[:, :, :, c:], gamma=2)  # :255
     loss = rec_loss + a_sm * sm_loss  # :258
-    unscale = scaled_backward(loss, model)
+    sc = scaled_backward(loss, model)
     out = {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
-           "rpan": rpan, "ldisp": ldisp, "grad_scale": unscale}
+           "rpan": rpan, "ldisp": ldisp, "scaler": sc}
     if optimize:
-        opt.step(allreduce_gradients(model) * unscale)
+        opt.step(allreduce_gradients(model), scaler=sc)
     return out
 
 
@@ -312,10 +382,10 @@ def stage1_slow_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 /
         sm_loss = (smoothness(left[:, :, :, c2:], ldisp[:, :, :, c2:], gamma=2) +
                    smoothness(right[:, :, :, 0:c8], rdisp[:, :, :, 0:c8], gamma=2)) / 2
     loss = rec_loss + a_sm * sm_loss  # :281
-    unscale = scaled_backward(loss, model)
-    opt.step(allreduce_gradients(model) * unscale)
+    sc = scaled_backward(loss, model)
+    opt.step(allreduce_gradients(model), scaler=sc)
     return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss.detach() if torch.is_tensor(sm_loss) else sm_loss,
-            "rpan": rpan, "lpan": lpan, "ldisp": ldisp, "rdisp": rdisp}
+            "rpan": rpan, "lpan": lpan, "ldisp": ldisp, "rdisp": rdisp, "scaler": sc}
 
 
 class GraphedStage1Step:
@@ -344,7 +414,7 @@ class GraphedStage1Step:
     def __call__(self):
         self.graph.replay()
         if self.multi:
-            self.opt.step(allreduce_gradients(self.model) * self.out["grad_scale"])
+            self.opt.step(allreduce_gradients(self.model), scaler=self.out["scaler"])
         else:
             self.opt.t += 1  # host mirror of the device step count
         return self.out
@@ -439,8 +509,7 @@ def stage2_step(model, fix_model, opt, left, right, max_disp, a_p=0.01, a_sm=0.4
     if a_mr > 0:  # :316-324: per-sample 1 / max(teacher disparity), (1 - O) weight, windowed masked L1 -- three launches per view
         mirror_loss = (mirror_loss_fnc(ldisp, mldisp, O_L, c2, W) + mirror_loss_fnc(rdisp, mrdisp, O_R, 0, c8)) / 2
     loss = rec_loss + a_sm * sm_loss + a_mr * mirror_loss
-    unscale = scaled_backward(loss, model)
-    scale = allreduce_gradients(model)
-    opt.step(scale * unscale)
+    sc = scaled_backward(loss, model)
+    opt.step(allreduce_gradients(model), scaler=sc)
     return {"loss": loss.detach(), "rec": rec_loss.detach(), "sm": sm_loss, "mirror": mirror_loss, "ldisp": ldisp, "rdisp": rdisp,
-            "O_L": O_L, "O_R": O_R}
+            "O_L": O_L, "O_R": O_R, "scaler": sc}

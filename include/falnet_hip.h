@@ -314,6 +314,21 @@ int falnet_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int falnet_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
                          float eps, float grad_scale, void* stream);
 
+/* Dynamic loss scale of the f16 compute path (torch.cuda.amp.GradScaler semantics; the reference is f32-only, Train_Stage1_K.py:258-262
+ * `loss.backward(); optimizer.step()`), device-resident so that no step synchronises with the host:
+ *   scaler = {scale, clean steps since the last change, overflow flag, skipped steps} (f32[4], caller-initialised {S0, 0, 0, 0}).
+ * falnet_grad_guard: scaler[2] = 1 when any of g[0, n) is inf / NaN (run AFTER the gradient all-reduce: every rank sees the same sum).
+ * falnet_adam_step_guarded: falnet_adam_step_dev with gradients multiplied by grad_scale / scaler[0]; when scaler[2] != 0 the whole
+ *   update (p, m, v, step count) is skipped.
+ * falnet_loss_scale_update (after Adam): overflow -> scale = max(scale * backoff, min_scale), skipped++; else clean++ and scale =
+ *   min(scale * growth, max_scale) every `interval` clean steps; clears the flag.
+ * falnet_loss_seeds: seeds[i] = scaler[0] * coef[i] -- the upstream-gradient scalars (`gscale`) of the loss kernels above. */
+int falnet_grad_guard(const float* g, int64_t n, float* scaler, void* stream);
+int falnet_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float* state, float b1, float b2,
+                             float eps, float grad_scale, const float* scaler, void* stream);
+int falnet_loss_scale_update(float* scaler, float growth, float backoff, int interval, float min_scale, float max_scale, void* stream);
+int falnet_loss_seeds(const float* scaler, const float* coef, float* seeds, int n, void* stream);
+
 /* Stage-2 occlusion mask (Train_Stage2_K.py:296-302): out = a * b, forced to 1 in the column window [x0, x1); planar f32
  * [B][1][H][W], no gradient */
 int falnet_occlusion_mask(const float* a, const float* b, float* out, int B, int H, int W, int x0, int x1, void* stream);

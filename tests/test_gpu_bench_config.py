@@ -1,0 +1,116 @@
+"""GPU parity at the BENCHMARK's own configuration (BASELINE configs[1] / configs[3]: B = 8, 256 x 512, N = 49).
+
+`bench.py` picks its kernels from the B-keyed entries of the committed autotune cache (`...|B8|...`: the persistent LDS-DMA /
+weight-stationary variants on shapes no small test launches at that batch), so this module runs exactly those launches and holds
+them to the CPU oracle (f32, the 1e-4 gate of north_star) and the 16-bit paths to the f32 HIP step (reported, bounded loosely:
+the reference is f32-only).  Reference: Train_Stage1_K.py:233-262, Train_Stage2_K.py:233-331."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fal_net_amd import loss_functions as LF  # noqa: E402
+from fal_net_amd import synthetic, train  # noqa: E402
+from fal_net_amd.models import FAL_netB  # noqa: E402
+from oracle import falnet_oracle as O  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-4
+B, H, W, N = 8, 256, 512, 49
+_F32 = {}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _build(dtype, train_mode=True):
+    LF.set_compute_dtype(dtype)
+    m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(N)}, no_levels=N, compute_dtype=dtype).to(DEV)
+    return m.train() if train_mode else m.eval()
+
+
+def _stage1(dtype):
+    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)  # bench.py's rank-0 batch
+    m = _build(dtype)
+    out = train.stage1_step(m, train.FlatAdam(m), left.to(DEV), right.to(DEV), mx.to(DEV), optimize=False)
+    res = {"loss": float(out["loss"]), "rec": float(out["rec"]), "sm": float(out["sm"]), "ldisp": out["ldisp"].clone().cpu(),
+           "rpan": out["rpan"].clone().cpu(), "flat_grad": m.flat_gradients().clone(),
+           "gnorm": {k: float(p.grad.norm()) for k, p in m.named_parameters() if p.grad is not None}}
+    del m
+    LF.set_compute_dtype(torch.float32)
+    return res
+
+
+def _f32_stage1():
+    if "s1" not in _F32:
+        _F32["s1"] = _stage1(torch.float32)
+    return _F32["s1"]
+
+
+def test_stage1_b8_f32_vs_oracle():
+    """One Stage-1 step at B=8, 256x512, N=49 in f32 against the CPU oracle: loss scalars and disparity 1e-4, synthesised view
+    2e-4 (the reference's own fp32 grid noise), every parameter's gradient norm 2e-3."""
+    hip = _f32_stage1()
+    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)
+    sd = synthetic.seeded_falnetb_state_dict(N)
+    params = O.leaf_params(sd)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = O.stage1_step(params, O.OracleAdam(params), synthetic.seeded_vgg19_state_dict(), left, right, mn, mx)  # gradients in ref["grads"]
+    for k in ("loss", "rec", "sm"):
+        assert abs(hip[k] - float(ref[k])) / abs(float(ref[k])) < TOL, (k, hip[k], float(ref[k]))
+    assert rel(hip["ldisp"], ref["ldisp"]) < TOL
+    assert rel(hip["rpan"], ref["rpan"]) < 2e-4
+    worst = ("", 0.0)
+    for k, gn in hip["gnorm"].items():
+        g = ref["grads"].get(k)
+        if g is None:
+            continue
+        e = abs(gn - float(g.norm())) / float(g.norm())
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 2e-3, (k, gn, float(g.norm()))
+    print("B=8 f32 vs oracle: worst gradient-norm deviation", worst)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_stage1_b8_16bit_vs_f32_hip(dt):
+    """The benchmark's own dtype (bf16) and f16 at the benchmark's own batch against the f32 HIP step of the same inputs."""
+    ref, got = _f32_stage1(), _stage1(dt)
+    lrel = abs(got["loss"] - ref["loss"]) / ref["loss"]
+    drel = rel(got["ldisp"], ref["ldisp"])
+    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
+    worst = max(((k, abs(v - ref["gnorm"][k]) / ref["gnorm"][k]) for k, v in got["gnorm"].items()), key=lambda t: t[1])
+    print(f"B=8 {dt} vs f32 HIP: loss rel {lrel:.2e}, disp max-rel {drel:.2e}, grad cosine {cos:.5f}, worst grad-norm rel {worst}")
+    assert torch.isfinite(got["flat_grad"]).all()
+    assert lrel < 2e-2 and cos > 0.98
+    assert drel < (1e-1 if dt == torch.bfloat16 else 2e-2)
+    assert worst[1] < 0.25, worst
+
+
+def _stage2(dtype):
+    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)
+    m, fix = _build(dtype), _build(dtype, train_mode=False)
+    for q in fix.parameters():
+        q.requires_grad_(False)
+    out = train.stage2_step(m, fix, train.FlatAdam(m, lr=5e-5), left.to(DEV), right.to(DEV), mx.to(DEV))
+    res = {k: float(out[k]) for k in ("loss", "rec", "sm", "mirror")}
+    res.update(ldisp=out["ldisp"].detach().clone().cpu(), rdisp=out["rdisp"].detach().clone().cpu(), flat_grad=m.flat_gradients().clone())
+    del m, fix
+    LF.set_compute_dtype(torch.float32)
+    return res
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_stage2_b8_16bit_vs_f32_hip(dt):
+    """Stage-2 (BASELINE configs[3]) at B=8/GPU: the 16-bit steps against the f32 HIP step (itself pinned to the oracle at
+    256x512 B=2 by tests/test_gpu_step.py::test_stage2_step_256x512_vs_oracle and to the reference by golden G3)."""
+    if "s2" not in _F32:
+        _F32["s2"] = _stage2(torch.float32)
+    ref, got = _F32["s2"], _stage2(dt)
+    dev = {k: abs(got[k] - ref[k]) / abs(ref[k]) for k in ("loss", "rec", "sm", "mirror")}
+    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
+    print(f"Stage-2 B=8 {dt} vs f32 HIP: {dev}, ldisp {rel(got['ldisp'], ref['ldisp']):.2e}, grad cosine {cos:.5f}")
+    assert torch.isfinite(got["flat_grad"]).all()
+    assert dev["loss"] < 3e-2 and dev["rec"] < 3e-2 and cos > 0.97
+    assert rel(got["ldisp"], ref["ldisp"]) < (1.5e-1 if dt == torch.bfloat16 else 3e-2)

@@ -85,7 +85,7 @@ def test_kitti_native_size_forward_and_ms_pp_vs_oracle():
     assert rel(pp, ref_pp) < 2e-4
 
 
-@pytest.mark.parametrize("script,extra", [("Train_Stage1_K.py", []), ("Train_Stage2_K.py", ["-no_levels", "7"])])
+@pytest.mark.parametrize("script,extra", [("Train_Stage1_K.py", []), ("Train_Stage2_K.py", ["-no_levels", "7", "--allow-seeded-teacher"])])
 def test_entry_scripts_train_and_validate_on_generated_pngs(script, extra, tmp_path):
     """The real-data path end to end without KITTI: generated PNG tree + pair list -> loader workers decode -> uint8 upload ->
     GPU augmentation -> two optimiser steps -> validate() on two 375 x 1242 KITTI-2015-shaped pairs (RMSE, EPE, KITTI errors) ->
@@ -106,3 +106,74 @@ def test_entry_scripts_train_and_validate_on_generated_pngs(script, extra, tmp_p
     assert len(val) == 1 and 0 < val[0]["val_rmse"] < 255 and np.isfinite(val[0]["val_epe"]) and set(val[0]["kitti"]) == set(utils.kitti_error_names)
     assert os.path.isfile(save / "checkpoint.pth.tar") and os.path.isfile(save / "model_best.pth.tar")
     assert "=> 4 training pairs, 2 validation pairs" in r.stdout
+    if script == "Train_Stage2_K.py":  # a real-data Stage-2 run without Stage-1 checkpoints must refuse (the reference torch.loads them)
+        bad = subprocess.run([c for c in cmd if c != "--allow-seeded-teacher"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert bad.returncode != 0 and "--fix_model" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.parametrize("mode", ["Kitti2015", "Kitti_eigen_test_improved"])
+def test_test_kitti_evaluates_a_dataset(mode, tmp_path):
+    """Test_KITTI.py as an evaluator (reference Test_KITTI.py:103-117,255-280): file-list dataset at B = 1 over a generated PNG
+    tree -> forward + ms_pp in f16 -> KITTI errors (+ EPE for KITTI 2015) -> errors.txt; the same frames through
+    inference.evaluate in f32 must give the metrics the CPU oracle's disparities give (the metric chain itself is pinned by G6)."""
+    import json
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_logic import _write_png_fixture
+    from fal_net_amd import datasets as DS
+    from oracle import falnet_oracle as O
+    root, _ = _write_png_fixture(tmp_path, n_train=1, n_val=2)
+    args = ["-tn", mode]
+    if mode == "Kitti2015":
+        troot = os.path.join(root, "Kitti2015")
+        triples = DS.kitti2015_pairs(troot)
+    else:  # Eigen split: <drive>/image_02/data/<frame>.png + <drive>/proj_depth/groundtruth/image_02/<frame>.png (uint16 depth * 256)
+        rng = np.random.default_rng(3)
+        troot = os.path.join(root, mode)
+        lines = []
+        for i in range(2):
+            drive = os.path.join("2011_09_26", "2011_09_26_drive_0002_sync")
+            for cam in ("image_02", "image_03"):
+                os.makedirs(os.path.join(troot, drive, cam, "data"), exist_ok=True)
+                Image.fromarray(rng.integers(0, 256, (375, 1242, 3), dtype=np.uint8)).save(os.path.join(troot, drive, cam, "data", f"{i:010d}.png"))
+            os.makedirs(os.path.join(troot, drive, "proj_depth", "groundtruth", "image_02"), exist_ok=True)
+            depth = (rng.random((375, 1242)) * 80 * 256).astype(np.uint16)
+            depth[rng.random((375, 1242)) < 0.7] = 0
+            Image.fromarray(depth).save(os.path.join(troot, drive, "proj_depth", "groundtruth", "image_02", f"{i:010d}.png"))
+            lines.append(f"{drive}/image_02/data/{i:010d}.png {drive}/image_03/data/{i:010d}.png")
+        lines.append("2011_09_26/2011_09_26_drive_0002_sync/image_02/data/0000009999.png 2011_09_26/2011_09_26_drive_0002_sync/image_03/data/0000009999.png")
+        lst = tmp_path / "eigen_test.txt"
+        lst.write_text("\n".join(lines) + "\n")
+        args += ["--test_list", str(lst)]
+        triples = DS.eigen_test_triples(str(lst), troot)
+    assert len(triples) == 2
+    save = tmp_path / "res"
+    cmd = [sys.executable, os.path.join(ROOT, "Test_KITTI.py"), "-d", str(root), "--allow-seeded-weights", "--dtype", "f16", "-w", "2",
+           "--save-path", str(save)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["frames"] == 2 and set(out["kitti"]) == set(utils.kitti_error_names) and all(np.isfinite(list(out["kitti"].values())))
+    txt = open(save / "errors.txt").read()
+    assert "Number of parameters" in txt and "EPE" in txt and "abs_rel" in txt
+    if mode == "Kitti2015":
+        assert out["epe"] > 0
+    # without --model and without the explicit flag the evaluator refuses (the reference torch.loads the checkpoint)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "Test_KITTI.py"), "-d", str(root)] + args, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r2.returncode != 0 and "--model" in (r2.stderr + r2.stdout)
+    # f32 evaluation loop vs the oracle's disparities through the same metric chain
+    sd = synthetic.seeded_falnetb_state_dict(49)
+    m = FAL_netB({"state_dict": sd}, 49, compute_dtype=torch.float32).to(DEV).eval()
+    loader = DS.make_loader(DS.StereoValDataset(troot, triples[:1]), 1, 0, shuffle=False, drop_last=False)
+    got = inference.evaluate(m, loader, data_name=mode, post="ms_pp", log=None)
+    left_u8, _, gt = DS.StereoValDataset(troot, triples[:1])[0]
+    left = DS.to_model_input(left_u8, "cpu")
+    mx = torch.full((1, 1, 1), 300.0)
+    mn = mx * 2.0 / 300.0
+    with torch.no_grad():
+        ref = O.ms_pp(sd, left, O.falnet_forward(sd, left, mn, mx), mn, mx)
+    t_np, p_np = gt.view(1, *gt.shape).numpy(), ref.squeeze(1).numpy()
+    gd, pd = (utils.disps_to_depths_kitti2015 if mode == "Kitti2015" else utils.disps_to_depths_kitti)(t_np, p_np)
+    want = utils.compute_kitti_errors(gd[0], pd[0])
+    for name, w in zip(utils.kitti_error_names, want):
+        assert abs(got["kitti"][name] - w) <= 1e-3 * abs(w) + 1e-6, (name, got["kitti"][name], w)

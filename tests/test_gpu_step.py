@@ -431,3 +431,66 @@ def test_fused_step_matches_autograd_step(dt):
     else:
         assert float(torch.nn.functional.cosine_similarity(ga, gf, dim=0)) > 0.999
     LF.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_f16_overflow_skips_the_step_and_backs_the_scale_off(fused):
+    """f16 path with a loss scale far too large: activation gradients overflow IEEE half -> inf / NaN in the flat f32 gradient.
+    The device-side guard must skip the whole Adam update (weights, moments and step count untouched), halve the scale, and the
+    run must recover once the scale fits; a clean step must move the weights and leave the scale alone.  No host sync in the step."""
+    left, right, mn, mx = synthetic.synthetic_pair(2, 64, 128, seed=3, distinct=True)
+    left, right, mx = left.to(DEV), right.to(DEV), mx.to(DEV)
+    m = build(49, torch.float16).train()
+    opt = train.FlatAdam(m, lr=1e-4)
+    old = train._FUSED_STEP
+    train._FUSED_STEP = fused
+    try:
+        out = train.stage1_step(m, opt, left, right, mx)  # clean step at the default scale
+        sc = out["scaler"]
+        assert sc is not None and sc.check() == (8192.0, 0)
+        w0, t0 = m.flat_parameters().clone(), float(opt.state[1])
+        m0 = opt.m.clone()
+        sc.state[0] = 2.0 ** 40  # forces an overflow in backward
+        train.stage1_step(m, opt, left, right, mx)
+        assert not torch.isfinite(m.flat_gradients()).all()
+        assert torch.equal(m.flat_parameters(), w0) and torch.equal(opt.m, m0) and float(opt.state[1]) == t0
+        scale, skipped = sc.check()
+        assert scale == 2.0 ** 39 and skipped == 1
+        sc.state[0] = 8192.0
+        train.stage1_step(m, opt, left, right, mx)
+        assert torch.isfinite(m.flat_gradients()).all() and not torch.equal(m.flat_parameters(), w0) and float(opt.state[1]) == t0 + 1
+        assert sc.check() == (8192.0, 1)
+        # growth: after `interval` clean steps the scale doubles
+        sc.interval = 2
+        train.stage1_step(m, opt, left, right, mx)
+        assert sc.check()[0] == 8192.0 * 2 or sc.check()[0] == 8192.0  # (one or two clean steps since the last change)
+        train.stage1_step(m, opt, left, right, mx)
+        assert sc.check()[0] >= 8192.0 * 2
+        # a scale at its floor that still overflows is a diverged run: check() raises
+        sc.state[0], sc.min_scale = 2.0 ** 40, 2.0 ** 40
+        train.stage1_step(m, opt, left, right, mx)
+        with pytest.raises(FloatingPointError):
+            sc.check()
+    finally:
+        train._FUSED_STEP = old
+        LF.set_compute_dtype(torch.float32)
+
+
+def test_overlapped_allreduce_equals_single_allreduce_world1():
+    """The bucketed asynchronous all-reduce (hook fired from the weight-gradient side stream while backward continues) against
+    `_no_overlap` (one all-reduce of the whole flat buffer after backward) on a world-size-1 RCCL group, f32 and loss-scaled f16:
+    one step each from the same weights: same gradients (to the reordering of f32 atomics / a flipped 16-bit rounding when the two
+    module instances autotune differently) and same weights (to Adam's +-lr on sign-unstable near-zero gradients)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dist_world1.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(res)
+    for name, tol in (("f32", 2e-3), ("f16", 5e-2)):
+        x = res[name]
+        assert x["finite"]
+        assert abs(x["loss"][0] - x["loss"][1]) <= (1e-5 if name == "f32" else 5e-3) * abs(x["loss"][1]), (name, x)
+        assert x["grad_rel"] < tol, (name, x)
+        assert x["w_maxabs"] <= 2.1e-4, (name, x)  # one Adam step of lr = 1e-4: at most a flipped +-lr on sign-unstable elements
