@@ -15,6 +15,9 @@ ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 OUT_NHWC, OUT_PLANAR_F32 = 0, 1
 CPAD = 32  # channel padding granule of NHWC tensors / packed weights (falnet_channel_pad)
 
+# FALNET_DETERMINISTIC=1: bit-identical results from run to run (include/falnet_hip.h: falnet_set_deterministic; host side in ops.py)
+DETERMINISTIC = os.environ.get("FALNET_DETERMINISTIC") == "1"
+
 # FALNET_LIB: alternative build of the same C-ABI (kernel A/B experiments); default = the in-tree library
 _LIB_PATH = os.environ.get("FALNET_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfalnet_hip.so")
 
@@ -72,6 +75,8 @@ SIGNATURES = {
     "falnet_last_error": [],
     "falnet_channel_pad": [_I],
     "falnet_set_device": [_I],
+    "falnet_set_deterministic": [_I],
+    "falnet_get_deterministic": [],
     "falnet_conv2d": [C.POINTER(Conv), _P],
     "falnet_conv3x3_c3": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_conv2d_multi": [C.POINTER(Conv), _I, _P],
@@ -85,6 +90,7 @@ SIGNATURES = {
     "falnet_wgrad_reduce_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_blocks": [_I, _I, _I],
     "falnet_bias_grad_batched": [_P, _I, _I, _I, _P],
+    "falnet_bias_grad_batched_det": [_P, _I, _I, _I, _P, _L, _P],
     "falnet_pack_weights": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "falnet_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -106,6 +112,7 @@ SIGNATURES = {
     "falnet_smooth_fwd_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "falnet_smooth_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
     "falnet_smooth_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P],
+    "falnet_step_scalars": [_P, _F, _P, _P],
     "falnet_mask_mix": [_P, _P, _P, _P, _I, _I, _L, _P],
     "falnet_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "falnet_adam_step_dev": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P],
@@ -141,6 +148,8 @@ def lib():
             fn = getattr(l, name)  # AttributeError here = header/library drift: fail loudly
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
+        if DETERMINISTIC:
+            l.falnet_set_deterministic(1)
         _lib = l
     return _lib
 

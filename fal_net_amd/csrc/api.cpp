@@ -18,6 +18,15 @@ void falnet_set_error(const char* fmt, ...) {
 // header check it.  300: round 3 (falnet_conv_t.variant 17/18, falnet_wgrad_t deterministic flag, falnet_adam_step_dev finite guard).
 extern "C" int falnet_version(void) { return 300; }
 extern "C" const char* falnet_last_error(void) { return g_err; }
+
+// Deterministic mode (process-wide): see include/falnet_hip.h.  Read by the launchers of conv.hip / losses.hip.
+static int g_deterministic = 0;
+int falnet_deterministic() { return g_deterministic; }
+extern "C" int falnet_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return 0;
+}
+extern "C" int falnet_get_deterministic(void) { return g_deterministic; }
 extern "C" int falnet_channel_pad(int dtype) { (void)dtype; return 32; }
 
 // Launch functions make the device of the caller's stream current themselves (common.h: falnet_enter_stream); this sets it

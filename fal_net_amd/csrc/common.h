@@ -6,6 +6,7 @@
 #include "../../include/falnet_hip.h"
 
 void falnet_set_error(const char* fmt, ...);
+int falnet_deterministic();  // api.cpp: falnet_set_deterministic() state
 
 // Kernel-selection switches are for A/B experiments and ablations only: the product library (default build) reads NO environment
 // variable -- every switch sits at its default and the alternative kernels are not reachable.  `python -m fal_net_amd._build --ab`

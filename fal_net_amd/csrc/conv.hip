@@ -2514,8 +2514,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const falnet_
     else if (d.ntaps == 1) wgrad_reduce_body<1>(d, rel, tile, accumulate);
 }
 
+// Deterministic form: `ws` != nullptr -> every block writes its per-channel sums to ws[blockIdx.x][512] (plain stores) and
+// bias_grad_finish_kernel adds them in block order (the atomic form's result depends on the order its blocks arrive in).
+__global__ __launch_bounds__(512) void bias_grad_finish_kernel(const falnet_biasgrad_t* __restrict__ descs, const float* __restrict__ ws) {
+    const falnet_biasgrad_t d = descs[blockIdx.x];
+    const int c = threadIdx.x;
+    if (c >= d.cout) return;
+    float s = 0.f;
+    for (int k = 0; k < d.blocks; ++k) s += ws[(int64_t)(d.block_begin + k) * 512 + c];
+    d.db[c] += s;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_biasgrad_t* __restrict__ descs, int n) {
+__global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_biasgrad_t* __restrict__ descs, int n, float* __restrict__ ws = nullptr) {
     __shared__ float red[256 * 8];
     __shared__ int entry_begin[64];
     const int li = find_entry(descs, n, entry_begin);
@@ -2552,7 +2563,10 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
             for (int i = 0; i < 8; ++i) {
                 float t = 0.f;
                 for (int k = 0; k < rows; ++k) t += red[(k * spb + sl) * 8 + i];
-                if (seg * 8 + i < d.cout) atomicAdd(d.db + seg * 8 + i, t);
+                if (seg * 8 + i < d.cout) {
+                    if (ws) ws[(int64_t)blockIdx.x * 512 + seg * 8 + i] = t;
+                    else atomicAdd(d.db + seg * 8 + i, t);
+                }
             }
         }
         __syncthreads();
@@ -2625,9 +2639,22 @@ extern "C" int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int
 extern "C" int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0, "bias_grad_batched: bad argument");
-#define BIAS_B(T) hipLaunchKernelGGL(bias_grad_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
+    FALNET_CHECK_ARG(!falnet_deterministic(), "bias_grad_batched: f32 atomics -- use falnet_bias_grad_batched_det in deterministic mode");
+#define BIAS_B(T) hipLaunchKernelGGL(bias_grad_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n, (float*)nullptr)
     FALNET_DISPATCH_DTYPE(dtype, BIAS_B);
 #undef BIAS_B
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_bias_grad_batched_det(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, float* ws, int64_t ws_floats,
+                                            void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0 && ws, "bias_grad_batched_det: bad argument");
+    FALNET_CHECK_ARG(ws_floats >= (int64_t)total_blocks * 512, "bias_grad_batched_det: workspace of %lld floats needed (512 per block)", (long long)total_blocks * 512);
+#define BIAS_B(T) hipLaunchKernelGGL(bias_grad_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n, ws)
+    FALNET_DISPATCH_DTYPE(dtype, BIAS_B);
+#undef BIAS_B
+    hipLaunchKernelGGL(bias_grad_finish_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, descs_dev, (const float*)ws);
     FALNET_RETURN_LAUNCH();
 }
 
@@ -2869,6 +2896,10 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");
+    if (p.ksplit > 1 && falnet_deterministic()) {
+        falnet_set_error("conv2d: split-K (f32 atomics) is not available in deterministic mode");
+        return -2;
+    }
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
@@ -2984,6 +3015,10 @@ extern "C" int falnet_conv2d_multi(const falnet_conv_t* descs, int n, void* stre
                 if (int r = check_src(descs[i].src[s], 32, "conv2d_multi")) return r;
         FALNET_CHECK_ARG(falnet_conv_s2d_dma_applicable(descs, n), "conv2d_multi: variant 14 needs the four parity classes of one 16-bit 3x3 stride-2 data gradient");
         return falnet_conv_s2d_dma_launch(descs, (hipStream_t)stream);
+    }
+    if (descs[0].ksplit > 1 && falnet_deterministic()) {
+        falnet_set_error("conv2d_multi: split-K (f32 atomics) is not available in deterministic mode");
+        return -2;
     }
     falnet_conv4_t pp;
     int64_t maxM = 0;
@@ -3107,6 +3142,7 @@ static int check_wgrad_desc(const falnet_wgrad_t& p) {
 }
 
 static bool wgrad_kernel_fuses_bias(WgradKernel k) {
+    if (falnet_deterministic()) return false;  // the fused form adds with f32 atomics from every workgroup
     return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS;
 }
 
@@ -3177,6 +3213,7 @@ extern "C" int falnet_wgrad_reduce(const float* partial, int nsplit, int ntaps, 
     int groups = 1;
     if (nsplit >= 16 && blocks < 1024) groups = (1024 + blocks - 1) / blocks;
     if (groups > nsplit / 8) groups = nsplit / 8 > 0 ? nsplit / 8 : 1;
+    if (falnet_deterministic()) groups = 1;  // one writer per gradient element: slabs summed in slab order
     const int use_atomics = (groups > 1 || accumulate) ? 1 : 0;
     if (groups > 1 && !accumulate) {
         hipError_t e = hipMemsetAsync(grad, 0, sizeof(float) * (size_t)cout * cin * ntaps, (hipStream_t)stream);
@@ -3199,6 +3236,7 @@ extern "C" int falnet_bias_grad(const void* g, int64_t npix, int gC, int cout, f
     const int segs = gC / 8, spb = segs < 256 ? segs : 256, rows = 256 / spb;
     int64_t gx = (npix + rows * 16 - 1) / (rows * 16);
     gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    if (falnet_deterministic()) gx = 1;  // one block = one add per channel (slow; the batched _det form is the training path)
     const dim3 grid((unsigned)gx, 1);
 #define BIAS_L(T) hipLaunchKernelGGL(bias_grad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, npix, gC, cout, db)
     FALNET_DISPATCH_DTYPE(dtype, BIAS_L);

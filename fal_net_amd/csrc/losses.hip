@@ -17,6 +17,32 @@ static inline int red_grid(int64_t work_items) {
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
+// Tail of every scalar reduction: thread 0 of each workgroup holds the workgroup's (scaled) sum.
+//   default       : one f32 atomic per workgroup on the scalar -- the order of the <= RED_BLOCKS adds varies from run to run;
+//   deterministic : falnet_set_deterministic(1) -- every workgroup publishes its sum (agent-scope atomic store), takes a ticket,
+//                   and the LAST arriver adds the partials in workgroup order onto the scalar: bit-identical from run to run.
+//                   One static scratch per device: reductions of one device must not run concurrently on two streams (the
+//                   training steps run all of them on the main stream).
+__device__ float g_red_partial[RED_BLOCKS];
+__device__ unsigned g_red_ticket = 0;
+__device__ __forceinline__ void red_finish(float* out, float v, int det) {
+    if (threadIdx.x != 0) return;
+    if (!det) {
+        atomicAdd(out, v);
+        return;
+    }
+    __hip_atomic_store(&g_red_partial[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned t = __hip_atomic_fetch_add(&g_red_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1 == gridDim.x) {
+        __threadfence();
+        float s = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) s += __hip_atomic_load(&g_red_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[0] += s;  // the only writer of this launch; earlier launches are ordered by the stream
+        __hip_atomic_store(&g_red_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
@@ -29,7 +55,7 @@ static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
 __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ mask, int C, int64_t HW,
                                                              int64_t total, float scale, float* out,
-                                                             const float* __restrict__ gscale = nullptr, float* __restrict__ ga = nullptr) {
+                                                             const float* __restrict__ gscale = nullptr, float* __restrict__ ga = nullptr, int det = 0) {
     __shared__ float red[16];
     float acc = 0.f;
     const float gs = ga ? scale * (gscale ? gscale[0] : 1.f) : 0.f;  // ga: the gradient gscale * scale * sign(a - b) in the same pass (unmasked)
@@ -43,7 +69,7 @@ __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __rest
             if (ga) reinterpret_cast<float4*>(ga)[i] = make_float4(sgn(d0) * gs, sgn(d1) * gs, sgn(d2) * gs, sgn(d3) * gs);
         }
         const float s4 = block_sum(acc, red);
-        if (threadIdx.x == 0) atomicAdd(out, s4 * scale);
+        red_finish(out, s4 * scale, det);
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -56,7 +82,7 @@ __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __rest
         acc += d;
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+    red_finish(out, s * scale, det);
 }
 
 __global__ __launch_bounds__(RED_THREADS) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -115,7 +141,7 @@ __device__ __forceinline__ void put8(float* p, const float (&v)[8]) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                               int64_t total, float scale, float* out,
-                                                              const float* __restrict__ gscale = nullptr, float gsc = 0.f, T* __restrict__ ga = nullptr) {
+                                                              const float* __restrict__ gscale = nullptr, float gsc = 0.f, T* __restrict__ ga = nullptr, int det = 0) {
     __shared__ float red[16];
     float acc = 0.f;
     const float gs = ga ? 2.f * gsc * (gscale ? gscale[0] : 1.f) : 0.f;
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restric
         }
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, s * scale);
+    red_finish(out, s * scale, det);
 }
 
 template <typename T, bool VEC>
@@ -213,7 +239,7 @@ __device__ __forceinline__ float tile_wy(const float* gt, float gamma, int ly, i
     return __expf(-gamma * fabsf(-g[-SM_GW] + 2.f * g[0] - g[SM_GW]));
 }
 
-__global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, float scale, float* out) {
+__global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, float scale, float* out, int det = 0) {
     __shared__ float red[16];
     __shared__ float gt[SM_GH * SM_GW], dt[SM_DH * SM_DW];
     const int Wc = s.x1 - s.x0;
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, f
         }
     }
     const float r = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, r * scale);
+    red_finish(out, r * scale, det);
 }
 
 // gather form of the adjoint: every pixel sums its own four terms and the one term each of its
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, f
 // fwd_out != nullptr: the loss itself (smooth_fwd_kernel's sum, times scale) is accumulated from the same tiles
 __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, float scale,
                                                                  const float* __restrict__ gscale,
-                                                                 float* __restrict__ gdisp, int accumulate, float* fwd_out = nullptr) {
+                                                                 float* __restrict__ gdisp, int accumulate, float* fwd_out = nullptr, int det = 0) {
     __shared__ float gt[SM_GH * SM_GW], dt[SM_DH * SM_DW];
     __shared__ float red[16];
     float facc = 0.f;
@@ -279,7 +305,7 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, f
     if (fwd_out) {  // block-uniform
         __syncthreads();
         const float r = block_sum(facc, red);
-        if (threadIdx.x == 0) atomicAdd(fwd_out, r * scale);
+        red_finish(fwd_out, r * scale, det);
     }
 }
 
@@ -468,7 +494,7 @@ extern "C" int falnet_l1_fwd(const float* a, const float* b, const float* mask, 
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, mask, C, HW,
-                       total, scale, out);
+                       total, scale, out, (const float*)nullptr, (float*)nullptr, falnet_deterministic());
     FALNET_RETURN_LAUNCH();
 }
 
@@ -490,7 +516,7 @@ extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cp
     const int64_t total = npix * Cpad;
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total);
-#define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out)
+#define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out, (const float*)nullptr, 0.f, (T*)nullptr, falnet_deterministic())
 #define MSE_FWD_T(T) if (vec) MSE_FWD(T, true); else MSE_FWD(T, false)
     FALNET_DISPATCH_DTYPE(dtype, MSE_FWD_T);
 #undef MSE_FWD_T
@@ -521,7 +547,7 @@ extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
     const int64_t ftiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((x1 - x0 + SM_TX - 1) / SM_TX);
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(ftiles < RED_BLOCKS ? ftiles : RED_BLOCKS)), dim3(RED_THREADS), 0,
-                       (hipStream_t)stream, s, scale, out);
+                       (hipStream_t)stream, s, scale, out, falnet_deterministic());
     FALNET_RETURN_LAUNCH();
 }
 
@@ -593,6 +619,23 @@ extern "C" int falnet_adam_step_guarded(float* p, const float* g, float* m, floa
     FALNET_CHECK_ARG(scaler, "adam_step_guarded: scaler is NULL");
     return adam_dev_launch(p, g, m, v, n, state, b1, b2, eps, grad_scale, scaler, stream);
 }
+// Tail of a fused training step: out = {S0 + a * S1, S0, S1}, then S0 = S1 = 0 for the next step (one launch instead of a clone, an
+// axpy and a fill).
+__global__ void step_scalars_kernel(float* S, float a, float* out) {
+    const float s0 = S[0], s1 = S[1];
+    out[0] = s0 + a * s1;
+    out[1] = s0;
+    out[2] = s1;
+    S[0] = 0.f;
+    S[1] = 0.f;
+}
+extern "C" int falnet_step_scalars(float* S, float a, float* out, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(S && out, "step_scalars: bad argument");
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, S, a, out);
+    FALNET_RETURN_LAUNCH();
+}
+
 extern "C" int falnet_grad_guard(const float* g, int64_t n, float* scaler, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(g && scaler && n > 0 && (n & 3) == 0 && ((uintptr_t)g & 15) == 0, "grad_guard: bad argument (n % 4 == 0, 16-B aligned)");
@@ -635,7 +678,7 @@ extern "C" int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, i
     FALNET_CHECK_ARG(a && b && out && ga && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
-                       out, gscale, ga);
+                       out, gscale, ga, falnet_deterministic());
     FALNET_RETURN_LAUNCH();
 }
 
@@ -646,7 +689,7 @@ extern "C" int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, in
     const int64_t total = npix * Cpad;
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total);
-#define MSE_FB(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale_out, out, gscale, scale_grad, (T*)ga)
+#define MSE_FB(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale_out, out, gscale, scale_grad, (T*)ga, falnet_deterministic())
 #define MSE_FB_T(T) if (vec) MSE_FB(T, true); else MSE_FB(T, false)
     FALNET_DISPATCH_DTYPE(dtype, MSE_FB_T);
 #undef MSE_FB_T
@@ -661,6 +704,6 @@ extern "C" int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B,
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
     const int64_t btiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((W + SM_TX - 1) / SM_TX);
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)(btiles < RED_BLOCKS ? btiles : RED_BLOCKS)), dim3(RED_THREADS), 0, (hipStream_t)stream, s,
-                       scale, gscale, gdisp, 0, out);
+                       scale, gscale, gdisp, 0, out, falnet_deterministic());
     FALNET_RETURN_LAUNCH();
 }

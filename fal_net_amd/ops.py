@@ -23,6 +23,10 @@ TIMER = None
 # Plan-build-time kernel selection: every conv launch tries the applicable kernel variants a few times on its
 # own (scratch) buffers and keeps the fastest (static plan => decided once).  FALNET_AUTOTUNE=0 disables.
 AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
+# Deterministic mode (FALNET_DETERMINISTIC=1): kernel choices come from the autotune cache or the library's heuristic -- never from
+# timing launches, whose winner can differ from run to run --, no split-K (f32 atomics), one writer per element in the slab reduce,
+# bias gradients through the two-pass ordered form; the library side is falnet_set_deterministic (fal_net_amd/_lib.py sets it).
+DETERMINISTIC = L.DETERMINISTIC
 
 
 # ---- persistent autotune choices --------------------------------------------------------------------------------------
@@ -336,9 +340,13 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
         hit = cache_get(key)
         if hit is not None:
             d.variant, d.ksplit = int(hit[0]), int(hit[1])
+            if DETERMINISTIC and d.ksplit > 1:
+                d.variant, d.ksplit = 1, 1  # the cached choice was the gather kernel with split-K: same kernel, one K pass
             if lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:  # stale entry (kernel table changed): re-tune
                 hit = None
-        if hit is None:
+        if hit is None and DETERMINISTIC:
+            d.variant, d.ksplit = 0, 1  # the library's heuristic: reproducible, no timing
+        elif hit is None:
             d.variant, d.ksplit = _autotune_conv(lib, d, ref, B * TH * TW, w_rows, Cout)
             cache_put(key, [int(d.variant), int(d.ksplit)])
     if pool_out is not None and lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:
@@ -374,6 +382,8 @@ def best_of(*calls, reps=5, key=None):
         hit = cache_get(key)
         if hit is not None and 0 <= int(hit) < len(calls):
             return calls[int(hit)]
+    if DETERMINISTIC:
+        return calls[0]  # no timing-based choice
 
     def t(c):
         c()
@@ -407,6 +417,8 @@ def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1, s2d=False):
     ksplit > 1: split-K over blockIdx.z with one fused epilogue; the members share the plan's split-K workspace, each with its
     own region (raises ValueError when it does not fit)."""
     lib = L.lib()
+    if ksplit > 1 and DETERMINISTIC:
+        raise ValueError("split-K is not available in deterministic mode")
     n = len(calls)
     arr = (L.Conv * n)()
     off = 0
@@ -694,7 +706,7 @@ class WgradBatch:
             for it in (all_items if _REDUCE_PER_LAYER else []):
                 one = (L.ReduceDesc * 1)()
                 base = lib.falnet_wgrad_reduce_blocks(it["cout"], it["cin_total"], 1)
-                groups = max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
+                groups = 1 if DETERMINISTIC else max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
                 r = one[0]
                 r.partial, r.grad = it["partial"], it["grad"].data_ptr()
                 r.nsplit, r.ntaps, r.w_rows, r.cin_total = it["nsplit"], it["ntaps"], it["w_rows"], it["cin_total"]
@@ -711,7 +723,7 @@ class WgradBatch:
                 # slab groups: enough blocks to pull the slabs at the HBM rate (a block keeps <= 18 16-B loads per thread in
                 # flight), at least four slabs per group; groups > 1 makes the kernel add with atomics
                 base = lib.falnet_wgrad_reduce_blocks(it["cout"], it["cin_total"], 1)
-                groups = max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
+                groups = 1 if DETERMINISTIC else max(1, min(it["nsplit"] // 4, (_REDUCE_BLOCKS + base - 1) // base))
                 blocks = base
                 r = red[i]
                 r.partial, r.grad = it["partial"], it["grad"].data_ptr()
@@ -736,8 +748,14 @@ class WgradBatch:
                 if n:
                     L.check(lib.falnet_wgrad_reduce_batched(L.ptr(red_dev), n, blocks, int(self.accumulate), L.stream_ptr()), "wgrad_reduce_batched")
 
-            def bias_all(bias_dev=bias_dev, n=len(biases), blocks=bblk):
-                if n:
+            bias_ws = torch.empty(max(bblk, 1) * 512, dtype=torch.float32, device=self.device) if DETERMINISTIC and biases else None
+            self._tables.append(bias_ws)
+
+            def bias_all(bias_dev=bias_dev, n=len(biases), blocks=bblk, bias_ws=bias_ws):
+                if n and bias_ws is not None:  # deterministic mode: per-block partials, added in block order
+                    L.check(lib.falnet_bias_grad_batched_det(L.ptr(bias_dev), n, blocks, code, L.ptr(bias_ws), bias_ws.numel(), L.stream_ptr()),
+                            "bias_grad_batched_det")
+                elif n:
                     L.check(lib.falnet_bias_grad_batched(L.ptr(bias_dev), n, blocks, code, L.stream_ptr()), "bias_grad_batched")
             out[bucket] = (_timed("wgrad_reduce_batched", 0, 0, reduce_all, "wgrad_reduce_batched"),
                            _timed("bias_grad_batched", 0, 0, bias_all, "bias_grad_batched"))

@@ -253,11 +253,11 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     plan = model._plan(B, H, W, dev)
     plan._ensure_backward()
     b = plan.buf
-    sc = loss_scaler(model)
-    if sc is None:
+    scaler = loss_scaler(model)
+    if scaler is None:
         seed_l1, seed_p, seed_sm = _seed(dev, 1.0), _seed(dev, a_p), _seed(dev, a_sm)
     else:  # f16: the upstream scalars carry the device-resident loss scale
-        sd3 = sc.seeds(1.0, a_p, a_sm)
+        sd3 = scaler.seeds(1.0, a_p, a_sm)
         seed_l1, seed_p, seed_sm = sd3[0:], sd3[1:], sd3[2:]
     joins = []
     if a_p > 0:
@@ -274,10 +274,11 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     rpan, ldisp = b["p_im0"], b["disp"]
     rt = right.detach().contiguous()
     st = L.stream_ptr()
-    S = plan.buf.get("step_scalars")
+    S = plan.buf.get("step_scalars")  # [rec = L1 + a_p * perceptual, sm]: zero on entry (falnet_step_scalars re-zeroes it at the end of every step)
     if S is None:
         S = plan.buf["step_scalars"] = torch.zeros(2, device=dev)
-    S.zero_()  # [rec = L1 + a_p * perceptual, sm]
+        plan.buf["step_out"] = torch.zeros(4, 3, device=dev)  # ring of result triples {loss, rec, sm}: a step's scalars stay valid for three more steps
+        plan._step_out_i = 0
     n_img = B * C * H * W
     # every loss term AND its adjoint in one pass over its operands (the upstream scalars -- loss scale, a_p, a_sm -- are known now)
     g_pan, g_disp = b["g_pan"], b["g_disp"]
@@ -315,11 +316,12 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
         g_pan.add_(vplan.g_in)
         vplan.busy = False
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
-    Sc = S.clone()  # the accumulators are reused by the next step
-    out = {"loss": torch.add(Sc[0], Sc[1], alpha=a_sm), "rec": Sc[0], "sm": Sc[1] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp,
-           "scaler": sc}
+    plan._step_out_i = (plan._step_out_i + 1) % 4
+    Sc = plan.buf["step_out"][plan._step_out_i]
+    L.check(lib.falnet_step_scalars(L.ptr(S), float(a_sm), L.ptr(Sc), st), "step_scalars")  # {rec + a_sm sm, rec, sm}; S -> 0
+    out = {"loss": Sc[0], "rec": Sc[1], "sm": Sc[2] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp, "scaler": scaler}
     if optimize:
-        opt.step(allreduce_gradients(model), scaler=sc)
+        opt.step(allreduce_gradients(model), scaler=scaler)
     return out
 
 

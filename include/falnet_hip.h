@@ -50,6 +50,16 @@ int falnet_channel_pad(int dtype);
  * (forward runs on the Python main thread, backward on autograd's worker thread: no thread-local HIP state is assumed).
  * falnet_set_device is for callers that use the NULL stream from a thread whose current device is not the tensors'. */
 int falnet_set_device(int device);
+/* Deterministic mode (process-wide switch, default off): every result becomes bit-identical from run to run for identical inputs,
+ * launch sequence and kernel choices.  What changes: scalar loss reductions add their per-workgroup partials in workgroup order
+ * (last-arriver pattern over a static scratch: run them on ONE stream per device); falnet_wgrad_fuses_bias reports 0 (the fused
+ * bias gradient adds with atomics); split-K convolution launches (ksplit > 1) are refused with -2; falnet_bias_grad_batched is
+ * refused in favour of falnet_bias_grad_batched_det; falnet_wgrad_reduce / falnet_bias_grad use a single writer per element.  The
+ * CALLER keeps `groups` = 1 in its falnet_reduce_t tables and makes its kernel choices reproducible (fal_net_amd.ops with
+ * FALNET_DETERMINISTIC=1: cached or heuristic variants, no timing).  Throughput drops (no split-K on the deep levels, a second
+ * pass for the bias gradients): a debugging / regression-hunting switch, like torch.use_deterministic_algorithms. */
+int falnet_set_deterministic(int on);
+int falnet_get_deterministic(void);
 
 /* One input of a convolution: NHWC tensor (or a per-sample constant when sy = sx = 0). */
 typedef struct {
@@ -211,6 +221,10 @@ int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total
  * (atomics: the caller zeroes those); accumulate != 0: every entry adds */
 int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, int accumulate, void* stream);
 int falnet_bias_grad_batched(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
+/* the same sums without atomics: every block stores its partial sums to ws[block][512] (ws_floats >= 512 * total_blocks, channels
+ * <= 512), a second launch adds them to db in block order */
+int falnet_bias_grad_batched_det(const falnet_biasgrad_t* descs_dev, int n, int total_blocks, int dtype, float* ws, int64_t ws_floats,
+                                 void* stream);
 
 /*
  * OIHW f32 master weights -> packed compute-dtype operands.
@@ -301,6 +315,9 @@ int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, flo
                        const float* gscale, void* ga, int dtype, void* stream);
 int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale, float* out,
                           const float* gscale, float* gdisp, void* stream);
+/* Tail of a fused step (Train_Stage1_K.py:258 `loss = rec_loss + a_sm * sm_loss`): S = {rec, sm} as accumulated by the *_fwd_bwd entry
+ * points above -> out = {rec + a * sm, rec, sm}; S is left {0, 0} for the next step. */
+int falnet_step_scalars(float* S, float a, float* out, void* stream);
 /* mixing for masked perceptual input: out = m*a + (1-m)*b (loss_functions.py:55); and grad wrt a: ga = m*g */
 int falnet_mask_mix(const float* a, const float* b, const float* m, float* out, int B, int C, int64_t HW, void* stream);
 

@@ -32,9 +32,9 @@ def run(dtype, overlap):
     for _ in range(1):
         out = train.stage1_step(m, opt, left.cuda(), right.cuda(), mx.cuda())
         if overlap:
-            assert m.bucket_hook is not None
+            assert getattr(m, 'bucket_hook', None) is not None
     torch.cuda.synchronize()
-    return float(out["loss"]), m.flat_gradients().clone(), m.flat_parameters().clone(), (m.bucket_hook is not None)
+    return float(out["loss"]), m.flat_gradients().clone(), m.flat_parameters().clone(), (getattr(m, 'bucket_hook', None) is not None)
 
 
 def main():

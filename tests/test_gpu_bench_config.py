@@ -35,9 +35,10 @@ def _stage1(dtype):
     left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)  # bench.py's rank-0 batch
     m = _build(dtype)
     out = train.stage1_step(m, train.FlatAdam(m), left.to(DEV), right.to(DEV), mx.to(DEV), optimize=False)
+    inv = 1.0 / float(out["scaler"].state[0]) if out.get("scaler") is not None else 1.0  # f16: the raw gradients carry the loss scale
     res = {"loss": float(out["loss"]), "rec": float(out["rec"]), "sm": float(out["sm"]), "ldisp": out["ldisp"].clone().cpu(),
-           "rpan": out["rpan"].clone().cpu(), "flat_grad": m.flat_gradients().clone(),
-           "gnorm": {k: float(p.grad.norm()) for k, p in m.named_parameters() if p.grad is not None}}
+           "rpan": out["rpan"].clone().cpu(), "flat_grad": m.flat_gradients().clone() * inv,
+           "gnorm": {k: float(p.grad.norm()) * inv for k, p in m.named_parameters() if p.grad is not None}}
     del m
     LF.set_compute_dtype(torch.float32)
     return res
@@ -95,7 +96,7 @@ def _stage2(dtype):
         q.requires_grad_(False)
     out = train.stage2_step(m, fix, train.FlatAdam(m, lr=5e-5), left.to(DEV), right.to(DEV), mx.to(DEV))
     res = {k: float(out[k]) for k in ("loss", "rec", "sm", "mirror")}
-    res.update(ldisp=out["ldisp"].detach().clone().cpu(), rdisp=out["rdisp"].detach().clone().cpu(), flat_grad=m.flat_gradients().clone())
+    res.update(ldisp=out["ldisp"].detach().clone().cpu(), rdisp=out["rdisp"].detach().clone().cpu(), flat_grad=m.flat_gradients().clone())  # (cosine: scale-free)
     del m, fix
     LF.set_compute_dtype(torch.float32)
     return res

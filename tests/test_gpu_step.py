@@ -494,3 +494,17 @@ def test_overlapped_allreduce_equals_single_allreduce_world1():
         assert abs(x["loss"][0] - x["loss"][1]) <= (1e-5 if name == "f32" else 5e-3) * abs(x["loss"][1]), (name, x)
         assert x["grad_rel"] < tol, (name, x)
         assert x["w_maxabs"] <= 2.1e-4, (name, x)  # one Adam step of lr = 1e-4: at most a flipped +-lr on sign-unstable elements
+
+
+def test_deterministic_mode_is_bit_identical():
+    """FALNET_DETERMINISTIC=1: two fresh model instances, two optimiser steps each (Stage-1 in f32 and bf16, Stage-2 in f32) from the
+    same weights and inputs give bit-identical losses, gradients, weights and disparities -- ordered scalar reductions, no
+    split-K / fused-bias atomics, single-writer slab reduce, cached-or-heuristic kernel choices (no timing)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_deterministic.py")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for name, x in res.items():
+        assert x["identical"], (name, x)
