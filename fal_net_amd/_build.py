@@ -24,6 +24,25 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_ab(tag="ab", defines=(), verbose=True):
+    """Experiment build: the same sources with -DFALNET_AB (the FALNET_* kernel switches of include/falnet_hip.h are honoured) plus
+    extra -D flags -> fal_net_amd/libfalnet_hip_<tag>.so, selected at run time with FALNET_LIB=<path>.  Never the product library."""
+    obj_dir = os.path.join(CSRC, "_obj_" + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = FLAGS + ["-DFALNET_AB"] + ["-D" + d for d in defines]
+    lib = os.path.join(HERE, f"libfalnet_hip_{tag}.so")
+
+    def run(src):
+        cmd = [HIPCC] + flags + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", os.path.join(obj_dir, src + ".o")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, SOURCES))
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [os.path.join(obj_dir, s + ".o") for s in SOURCES], check=True)
+    return lib
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_epilogue.h"), os.path.join(HERE, "..", "include", "falnet_hip.h")]
@@ -49,5 +68,10 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--ab" in sys.argv:  # python -m fal_net_amd._build --ab [tag] [-DNAME[=V] ...]
+        rest = [a for a in sys.argv[sys.argv.index("--ab") + 1:]]
+        tag = next((a for a in rest if not a.startswith("-D")), "ab")
+        print(build_ab(tag, [a[2:] for a in rest if a.startswith("-D")]))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -467,7 +467,7 @@ def test_f16_overflow_skips_the_step_and_backs_the_scale_off(fused):
         train.stage1_step(m, opt, left, right, mx)
         assert sc.check()[0] >= 8192.0 * 2
         # a scale at its floor that still overflows is a diverged run: check() raises
-        sc.state[0], sc.min_scale = 2.0 ** 40, 2.0 ** 40
+        sc.state[0], sc.min_scale, sc.max_scale = 2.0 ** 40, 2.0 ** 40, 2.0 ** 41
         train.stage1_step(m, opt, left, right, mx)
         with pytest.raises(FloatingPointError):
             sc.check()

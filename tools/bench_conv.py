@@ -24,7 +24,12 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("iconv4 128+256->256 @32x64", [128, 256], 256, 32, 64, None),
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
 ]
-VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dmapc", 17), ("dma128", 18)]
+if os.environ.get("BENCH_VARIANTS"):  # e.g. BENCH_VARIANTS=dma,ws
+    VARIANTS = [v for v in VARIANTS if v[0] in os.environ["BENCH_VARIANTS"].split(",")]
+if os.environ.get("BENCH_LAYERS"):  # substring filter, comma separated
+    LAYERS = [l for l in LAYERS if any(k in l[0] for k in os.environ["BENCH_LAYERS"].split(","))]
+NOCHECK = os.environ.get("BENCH_NOCHECK") == "1"  # timing probes that deliberately compute wrong values
 lib = L.lib()
 for name, groups, cout, H, W, up in LAYERS:
     cin = sum(groups)
@@ -59,6 +64,8 @@ for name, groups, cout, H, W, up in LAYERS:
                 times[v].append(e0.elapsed_time(e1) / 5)
             if rnd == 0:
                 if pooled is not None:
+                    pass
+                elif NOCHECK:
                     pass
                 elif ref is None:
                     ref = out.float().clone()
