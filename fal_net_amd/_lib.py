@@ -18,6 +18,16 @@ CPAD = 32  # channel padding granule of NHWC tensors / packed weights (falnet_ch
 # FALNET_DETERMINISTIC=1: bit-identical results from run to run (include/falnet_hip.h: falnet_set_deterministic; host side in ops.py)
 DETERMINISTIC = os.environ.get("FALNET_DETERMINISTIC") == "1"
 
+def ab(name, default):
+    """Value of an EXPERIMENT switch (kernel-selection / scheduling A/B knobs used by tools/ab_*.sh and the tuning notes in DESIGN.md).
+    They are honoured only when FALNET_AB=1 is set: an ordinary process (training, bench, tests) always runs the tuned defaults and
+    cannot be steered off them by a stray environment variable.  Product switches (FALNET_LIB, FALNET_AUTOTUNE*, FALNET_DETERMINISTIC,
+    FALNET_F16_*, FALNET_FORCE_DIST, FALNET_VGG19_WEIGHTS, FALNET_HW_QUEUES, FALNET_FUSED_STEP) are read directly."""
+    if os.environ.get("FALNET_AB") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
 # FALNET_LIB: alternative build of the same C-ABI (kernel A/B experiments); default = the in-tree library
 _LIB_PATH = os.environ.get("FALNET_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfalnet_hip.so")
 

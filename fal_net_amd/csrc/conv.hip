@@ -2720,9 +2720,7 @@ static int g_patch_kcb = [] { const char* e = falnet_ab_env("FALNET_PATCH_KCB");
 
 
 bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // conv_dma.hip
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool producer_consumer);
-bool falnet_conv_dma128_applicable(const falnet_conv_t& p);                 // 128 output channels per workgroup
-int falnet_conv_dma128_launch(const falnet_conv_t& p, int flip, hipStream_t st);
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st);
 bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n);         // four parity classes of a stride-2 data gradient in one pass
 int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st);
 bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p);                // forward 3x3 stride-2
@@ -2764,7 +2762,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16, "conv2d: unknown variant %d", variant);
     if (variant == 15) {  // LDS-DMA forward 3x3 stride-2 (conv_dma.hip)
         if (!falnet_conv_s2f_dma_applicable(p)) {
             falnet_set_error("conv2d: variant 15 needs a canonical 16-bit 3x3 stride-2 pad-1 NHWC launch (>= 8 x 32 outputs) with sources at the input size");
@@ -2776,27 +2774,15 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
         return 0;
     }
-    if (variant == 18) {  // LDS-DMA, 16x32 positions x 128 channels per workgroup (conv_dma.hip: conv3x3_dma128_kernel)
-        if (!(dense3x3 && falnet_conv_dma128_applicable(p))) {
-            falnet_set_error("conv2d: variant 18 needs a variant-13 launch with w_rows %% 128 == 0 and more than 64 output channels");
-            return -2;
-        }
-        c.flip = flip;
-        c.swap = 0;
-        c.patch = 5;
-        c.bn = 128; c.kcb = 64; c.tps = 9; c.adb = 0; c.th = 16; c.nwaves = 8;
-        return 0;
-    }
-    if (variant == 13 || variant == 17) {  // LDS-DMA, double-buffered, persistent: 16x32 positions x 64 channels per workgroup (conv_dma.hip);
-        // 17 = the same with four loader waves + four MFMA waves (c.adb = 1)
+    if (variant == 13) {  // LDS-DMA, double-buffered, persistent: 16x32 positions x 64 channels per workgroup (conv_dma.hip)
         if (!(dense3x3 && falnet_conv_dma_applicable(p))) {
-            falnet_set_error("conv2d: variants 13 / 17 need a 16-bit dense 3x3 stride-1 launch (>= 16 x 32 positions) with sources at the launch size or half of it");
+            falnet_set_error("conv2d: variant 13 needs a 16-bit dense 3x3 stride-1 launch (>= 16 x 32 positions) with sources at the launch size or half of it");
             return -2;
         }
         c.flip = flip;
         c.swap = 0;
         c.patch = 3;
-        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = variant == 17; c.th = 16; c.nwaves = 8;
+        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
     if (variant == 10 || variant == 16) {
@@ -2871,12 +2857,8 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 5)
-        snprintf(buf, len, "_Z21conv3x3_dma128_kernelI%sEv13falnet_conv_tiiii", t);
-    else if (c.patch == 4)
+    if (c.patch == 4)
         snprintf(buf, len, "_Z22conv3x3_s2f_dma_kernelI%sLi%dEEv13falnet_conv_tiii", t, c.bn);
-    else if (c.patch == 3 && c.adb)
-        snprintf(buf, len, "_Z21conv3x3_dma_pc_kernelI%sEv13falnet_conv_tiiii", t);
     else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
     else if (c.patch == 2)
@@ -2921,9 +2903,8 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
-    if (c.patch == 5) return falnet_conv_dma128_launch(p, c.flip, st);
     if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
-    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st, c.adb != 0);
+    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st);
     if (c.patch == 2) {
         const int ws_th = c.th;
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;

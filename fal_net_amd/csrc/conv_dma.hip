@@ -44,21 +44,6 @@ __device__ __forceinline__ void cd_glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-// the same piece with a wave-UNIFORM 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit vector add, no 64-bit
-// address registers per piece.  Lanes switched off by EXEC fetch nothing and write nothing.
-__device__ __forceinline__ void cd_glds16_s(const void* sbase, unsigned voff_bytes, unsigned lds_dst) {
-    unsigned keep;
-    {   // the base IS wave-uniform, but hipcc's divergence analysis does not always see it (cursor state through loop phis): pin it to SGPRs
-        const unsigned long long u = reinterpret_cast<unsigned long long>(sbase);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        sbase = reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
-    }
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff_bytes), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-
 #define CD_PW 34  // patch columns: 32 + the +-1 halo
 
 template <typename T, int TH, int NWAVES>
@@ -101,10 +86,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         const int tap = wid >> 2, co = n0 + ((wid & 3) << 4) + l4;  // four 16-row pieces per tap tile
         const int gseg = segpos ^ ((lane >> 4) & 3);                 // (row >> 2) & 3 = (l4 >> 2) & 3: pieces start at multiples of 16
         w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
-#if defined(FALNET_DMA_PROBE) && (FALNET_DMA_PROBE & 1)
-        // TIMING PROBE (wrong results): every weight piece is one contiguous 1-KiB run -- what whole-line weight fetches would cost
-        w_off[k] = (int64_t)(n0 % 64) * 0 + (int64_t)wid * 512 + lane * 8;
-#endif
     }
     int64_t a_off[KP];  // of the issue cursor's (tile, source), from the sample's base: recomputed when either changes (twice per tile at most)
     const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
@@ -130,11 +111,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
             a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8)
                           : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
-#if defined(FALNET_DMA_PROBE) && (FALNET_DMA_PROBE & 2)
-            // TIMING PROBE (wrong results): the tile's patch pieces are contiguous 1-KiB runs starting at the tile's first pixel
-            a_off[k] = (int64_t)((ty0 >> hs) * (int)S.sy + (tx0 >> ws) * (int)S.sx) + (int64_t)(wave + NWAVES * k) * 512 + lane * 8;
-            if (a_off[k] + 4096 > (int64_t)S.H * S.sy) a_off[k] -= 40960;
-#endif
         }
     };
     struct Cur { int tile, c, s, c0, kofs; };      // issue cursor: tile, chunk, source, channel offset, weight-row offset
@@ -164,12 +140,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
         } else {
             const int wid = wave + NWAVES * (i - KP);
-#if defined(FALNET_DMA_PROBE) && (FALNET_DMA_PROBE & 4)
-            if (wid & 1) return;  // TIMING PROBE (wrong results): half of the weight pieces are never fetched
-#endif
-#if defined(FALNET_DMA_PROBE) && (FALNET_DMA_PROBE & 8)
-            return;  // TIMING PROBE (wrong results): no weight piece is fetched (39 of 75 KB per chunk)
-#endif
             if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
         }
     };
@@ -312,452 +282,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #undef CD_STAMP
 }
 
-// ============================================================================================================================
-// Producer / consumer form of the kernel above (falnet_conv_t::variant 17): the same tile (16 x 32 positions x 64 channels), the
-// same two 75-KB LDS buffers, one barrier per chunk -- but the eight waves are SPECIALISED:
-//   * waves 4-7 (one per SIMD) are LOADERS: right behind the barrier that publishes chunk i they issue every LDS-DMA piece of chunk
-//     i + 1 (19 pieces each), wait for them (vmcnt(0)) and arrive at the next barrier.  A piece holds its wave 150-300 cycles in
-//     issue while the CU's memory path drains (in-kernel stamps of the kernel above): here that wait blocks a wave that has nothing
-//     else to do, instead of one whose MFMAs then leave the matrix pipe idle;
-//   * waves 0-3 (one per SIMD) are CONSUMERS: four 32-position rows x two 32-channel tiles each (eight accumulator tiles = 128
-//     registers), nothing but fragment reads and MFMAs in the chunk loop: 6 ds_read_b128 per 8 MFMAs (0.75 per MFMA against 1.0),
-//     no address arithmetic, no vector-memory instruction.  One wave per SIMD owns the matrix pipe: no second wave whose MFMA phase
-//     collides with it.
-// Everything else (persistent tile walk, source-side swizzle, zero page, fused epilogue per 32-channel slice) is as above.
-template <typename T>
-__global__ __launch_bounds__(512) void conv3x3_dma_pc_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
-    constexpr int TH = 16, NCW = 4, NLW = 4, BN = 64, MT = TH / NCW, NT = BN / 32;
-    static_assert(MT == 4 && sizeof(T) == 2, "four 32-position rows per consumer wave, 16-bit operands");
-    constexpr int KCV = 32;
-    constexpr int NPIX = (TH + 2) * CD_PW;
-    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
-    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= NCW;
-    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
-    const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * BN;
-    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
-
-    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
-    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
-    const int nchunks = (C0 + C1) / KCV;
-    int my_tiles = 0;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
-    const int total = my_tiles * nchunks;
-    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
-        const int tix = tile % tiles_x;
-        const int q = tile / tiles_x;
-        ty0 = (q % tiles_y) * TH;
-        tx0 = tix * 32;
-        b = q / tiles_y;
-    };
-
-    if (loader) {
-        // ------------------------------------------------------------------------------------------------ producer waves
-        const int lw = wave - NCW;
-        constexpr int KP = (A_PIECES + NLW - 1) / NLW, KW = (B_PIECES + NLW - 1) / NLW;
-        const int l4 = lane >> 2, segpos = lane & 3;
-        const T* const wptr = reinterpret_cast<const T*>(p.weight);
-        const T* const zero_t = reinterpret_cast<const T*>(zero_page);
-        int64_t w_off[KW];
-#pragma unroll
-        for (int k = 0; k < KW; ++k) {
-            const int wid = lw + NLW * k;
-            const int tap = wid >> 2, co = n0 + ((wid & 3) << 4) + l4;
-            const int gseg = segpos ^ ((lane >> 4) & 3);
-            w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
-        }
-        int64_t a_off[KP];
-        const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
-        int64_t sbat[2] = {0, 0};
-        auto tile_offsets = [&](int tile, int s2) {
-            int b, ty0, tx0;
-            tile_coords(tile, b, ty0, tx0);
-            const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
-            sbat[s2] = (int64_t)b * S.sb;
-            const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                const int pix = 16 * (lw + NLW * k) + l4;
-                const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
-                const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
-                const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
-                a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8)
-                              : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
-            }
-        };
-        struct Cur { int tile, c, s, c0, kofs; };
-        auto advance = [&](Cur& q) {
-            if (++q.c == nchunks) {
-                q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
-                q.tile += gridDim.x;
-                if (q.tile < ntiles) tile_offsets(q.tile, 0);
-                return;
-            }
-            q.c0 += KCV;
-            q.kofs += KCV;
-            if (q.s == 0 && q.c0 >= C0) {
-                q.s = 1;
-                q.c0 = 0;
-                tile_offsets(q.tile, 1);
-            }
-        };
-        auto issue = [&](const Cur& q, int buf) {
-            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
-            const T* wbase = wptr + q.kofs;
-            const unsigned dst0 = lds_base + buf * BUF;
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                const int id = lw + NLW * k;
-                if (id < A_PIECES) cd_glds16(sbase + a_off[k], dst0 + id * 1024);
-            }
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int wid = lw + NLW * k;
-                if (wid < B_PIECES) cd_glds16(wbase + w_off[k], dst0 + A_BYTES + wid * 1024);
-            }
-        };
-        Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
-        if (total > 0) {
-            tile_offsets(qi.tile, 0);
-            issue(qi, 0);
-            advance(qi);
-        }
-        for (int it = 0; it < total; ++it) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it` are in LDS
-            __builtin_amdgcn_s_barrier();                     // chunk `it` published; every consumer is done with buffer (it + 1) & 1
-            if (it + 1 < total) {
-                issue(qi, (it + 1) & 1);
-                advance(qi);
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- consumer waves
-    int a_addr[MT + 2][3];  // pixel row (4 wave + rs) of the patch, column shift dx; k-step 1 = the same address with bit 5 flipped
-#pragma unroll
-    for (int rs = 0; rs < MT + 2; ++rs)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int pp = (wave * MT + rs) * CD_PW + dx + r;
-            a_addr[rs][dx] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
-        }
-    int b_lane[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b_lane[ks] = A_BYTES + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
-
-    f32x16 acc[NT][MT][1];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
-    int ctile = blockIdx.x, cc = 0;
-    for (int it = 0; it < total; ++it) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own fragment reads of chunk it - 1 are done
-        __builtin_amdgcn_s_barrier();
-        int bo = (it & 1) * BUF;
-        asm volatile("" : "+s"(bo));
-        const char* const Bf = lds + bo;
-        // 18 steps (tap, 16-channel half) of 8 MFMAs; the six fragment reads of step i + 1 are issued in front of the MFMAs of step i
-        s16x8_t fa[2][MT], fb[2][NT];
-        auto load_step = [&](int st, int set) {
-            const int t = st >> 1, ks = st & 1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const s16x8_t*>(Bf + (a_addr[mt + t / 3][t % 3] ^ (ks << 5)));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const s16x8_t*>(Bf + b_lane[ks] + (t * BN + nt * 32) * 64);
-        };
-        load_step(0, 0);
-#pragma unroll
-        for (int st = 0; st < 18; ++st) {
-            if (st + 1 < 18) load_step(st + 1, (st + 1) & 1);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][mt][0] = H16<T>::mma(fb[st & 1][nt], fa[st & 1][mt], acc[nt][mt][0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads of the next step
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
-        }
-        if (++cc == nchunks) {
-            cc = 0;
-            int b, ty0, tx0;
-            tile_coords(ctile, b, ty0, tx0);
-            ctile += gridDim.x;
-            const int cstride = p.out_cstride;
-            const int x = tx0 + r;
-            const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
-            auto pixoff = [&](int mt) -> int64_t {
-                const int y = ty0 + wave * MT + mt;
-                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
-            };
-            auto pooloff = [&](int mt) -> int64_t {
-                const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
-                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
-            };
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float bias[1][16];
-                load_bias16<1>(p, n0 + 32 * nt, h, bias);
-                epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff, pooloff);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
-            }
-        }
-    }
-}
-
-// ============================================================================================================================
-// 128 output channels per workgroup (falnet_conv_t::variant 18).  The 64-channel kernel above is bound by what a CU can take in
-// from L2: 75 KB (39 KB of halo patch + 36 KB of weights) per 18.9 MFLOP chunk at the ~10-11 B/clk a CU sustains by LDS-DMA
-// (timing probes: a loader-wave split of the same tile is 8 % SLOWER, the same kernel with half / none of its weight pieces
-// fetched is proportionally faster) -- its MFMA pipe waits.  A tile of 16 x 32 positions x 128 channels re-uses the patch for twice
-// the channels: 111 KB per 37.7 MFLOP, 26 % fewer staged bytes per FLOP, 0.75 instead of 1.0 fragment reads per MFMA.
-// LDS (150 KB, as above): the patch stays double-buffered (2 x 39 KB); the 72 KB of weights of a chunk have ONE buffer that is
-// refilled in two halves behind two barriers per chunk --
-//     barrier A(c): patch(c) and taps 0-4 of chunk c are in LDS           -> issue taps 5-8 of chunk c, then patch(c+1)
-//     steps 0-9   : taps 0-4                                              (one DMA piece per MFMA step, as above)
-//     barrier M(c): taps 5-8 landed (counted vmcnt: the younger patch pieces stay in flight), nobody reads taps 0-4 any more
-//                                                                         -> issue taps 0-4 of chunk c+1
-//     steps 10-17 : taps 5-8
-// so every piece still has half a chunk (>= 2 300 MFMA cycles per wave) to land.  Eight waves = two 32-position rows x four
-// 32-channel tiles each (eight accumulator tiles, 128 registers); everything else (persistent walk, source-side swizzle, zero
-// page, epilogue per 32-channel slice) as above.  Needs w_rows % 128 == 0.
-template <typename T>
-__global__ __launch_bounds__(512) void conv3x3_dma128_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
-    constexpr int TH = 16, NWAVES = 8, BN = 128, MT = TH / NWAVES, NT = BN / 32;
-    static_assert(MT == 2 && sizeof(T) == 2, "two 32-position rows per wave, 16-bit operands");
-    constexpr int KCV = 32;
-    constexpr int NPIX = (TH + 2) * CD_PW;
-    constexpr int A_PIECES = (NPIX + 15) / 16, A_BYTES = A_PIECES * 1024;  // 39 KiB
-    constexpr int W_LO = 5 * BN / 16, W_HI = 4 * BN / 16;                   // pieces of taps 0-4 / 5-8 (16 weight rows each)
-    constexpr int W_OFF = 2 * A_BYTES;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * A_BYTES + (W_LO + W_HI) * 1024];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
-    const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * BN;
-    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
-
-    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
-    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
-    const int nchunks = (C0 + C1) / KCV;
-    int my_tiles = 0;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
-    const int total = my_tiles * nchunks;
-
-    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KLO = W_LO / NWAVES, KHI = W_HI / NWAVES;  // 5, 5, 4 pieces per wave
-    static_assert(W_LO % NWAVES == 0 && W_HI % NWAVES == 0, "weight halves split evenly over the waves");
-    const int l4 = lane >> 2, segpos = lane & 3;
-    const T* const wptr = reinterpret_cast<const T*>(p.weight);
-    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
-    // weight piece k of this wave (k < KLO: taps 0-4, else taps 5-8) = tap k, rows n0 + 16 wave + l4 (piece id = 8 tap + wave): ONE per-lane
-    // byte offset; the tap's base is wave-uniform (every row exists: w_rows % 128 == 0)
-    const unsigned w_lane = (unsigned)((((n0 + 16 * wave + l4) * p.w_taps) * p.cin_total + (segpos ^ ((lane >> 4) & 3)) * 8) * (int)sizeof(T));
-    const int w_tapstride = flip ? -p.cin_total : p.cin_total, w_tap0 = flip ? 8 * p.cin_total : 0;
-    unsigned a_off[KP];  // BYTE offset of this lane's 16 B inside the sample (32-bit: falnet_conv_dma_applicable); the sample's base is wave-uniform
-    unsigned a_ok = 0;   // bit k: piece k of this lane lies inside the image.  Lanes outside fetch NOTHING (EXEC): their 16 B of the patch
-                         // buffer are zeroed by a ds_write for the first two chunks of a tile (one per buffer) and stay zero for the rest of it
-    const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
-    int64_t sbat[2] = {0, 0};
-    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
-        const int tix = tile % tiles_x;
-        const int q = tile / tiles_x;
-        ty0 = (q % tiles_y) * TH;
-        tx0 = tix * 32;
-        b = q / tiles_y;
-    };
-    auto tile_offsets = [&](int tile, int s2) {
-        int b, ty0, tx0;
-        tile_coords(tile, b, ty0, tx0);
-        const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
-        sbat[s2] = (int64_t)b * S.sb;
-        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int pix = 16 * (wave + NWAVES * k) + l4;
-            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
-            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
-            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
-            a_off[k] = ok ? (unsigned)(((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ ((pc >> 2) & 3)) * 8) * (int)sizeof(T)) : 0u;  // (swizzle by patch COLUMN, see aa[])
-            a_ok = (a_ok & ~(1u << k)) | ((ok ? 1u : 0u) << k);
-        }
-    };
-    // Two issue cursors: the PATCH cursor runs one chunk ahead (patch(c+1) is requested during chunk c), the weight halves follow
-    // the compute cursor: taps 5-8 of chunk c during its first half, taps 0-4 of chunk c+1 during its second half.
-    struct Cur { int tile, c, s, c0, kofs; };
-    auto advance = [&](Cur& q, bool offsets) {
-        if (++q.c == nchunks) {
-            q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
-            q.tile += gridDim.x;
-            if (offsets && q.tile < ntiles) tile_offsets(q.tile, 0);
-            return;
-        }
-        q.c0 += KCV;
-        q.kofs += KCV;
-        if (q.s == 0 && q.c0 >= C0) {
-            q.s = 1;
-            q.c0 = 0;
-            if (offsets) tile_offsets(q.tile, 1);
-        }
-    };
-    auto issue_patch = [&](const Cur& q, int buf, int i) {  // piece i (< KP) of the patch cursor's chunk
-        const int id = wave + NWAVES * i;
-        if (id >= A_PIECES) return;  // (wave-uniform)
-        const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;  // wave-uniform
-        const unsigned dst = lds_base + buf * A_BYTES + id * 1024;
-        if ((a_ok >> i) & 1) cd_glds16_s(sbase, a_off[i], dst);
-        else if (q.c < 2) *reinterpret_cast<uint4*>(lds + buf * A_BYTES + id * 1024 + lane * 16) = make_uint4(0, 0, 0, 0);
-    };
-    auto issue_w = [&](int kofs, int k) {  // weight piece k of this wave (tap k) at K offset kofs
-        cd_glds16_s(wptr + (kofs + w_tap0 + k * w_tapstride), w_lane, lds_base + W_OFF + (8 * k + wave) * 1024);
-    };
-
-    // Patch fragment addresses.  The four 16-B segments of a pixel row are XOR-swizzled with ((column >> 2) & 3) of the patch COLUMN (the
-    // 64-channel kernel swizzles by the linear pixel index): the swizzle then does not depend on the patch row, so a fragment address is
-    // aa[dx] (column dx + r, this wave's first row, current buffer) + rs * 34 * 64 as a ds_read IMMEDIATE -- 3 address registers instead of
-    // 12 (+ 12 for the k-step-1 forms); any 16 consecutive columns still cover all 16 (64-B slot, segment) pairs: conflict-free.
-    int aa[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const int c = dx + r;
-        aa[dx] = (wave * MT * CD_PW + c) * 64 + ((h ^ ((c >> 2) & 3)) << 4);
-    }
-    // weight fragment bases: one per k-step and weight HALF, so that every (tap, channel tile) offset is a ds_read immediate (< 64 KiB)
-    int b_lane[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        b_lane[0][ks] = W_OFF + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
-        b_lane[1][ks] = b_lane[0][ks] + 5 * BN * 64;
-        // opaque to the optimiser: it otherwise derives the k-step-1 addresses as (k-step-0 address + offset) ^ 32 -- one VGPR per
-        // (tap, channel tile) instead of one base + ds_read immediates -- and spills them
-        asm volatile("" : "+v"(b_lane[0][ks]));
-        asm volatile("" : "+v"(b_lane[1][ks]));
-    }
-
-    f32x16 acc[NT][MT][1];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
-
-    Cur qp = {(int)blockIdx.x, 0, 0, 0, 0};  // patch cursor
-    int wk = 0;                               // K offset (weight-row element offset) of the compute cursor's chunk
-    if (total > 0) {
-        tile_offsets(qp.tile, 0);
-#pragma unroll
-        for (int i = 0; i < KP; ++i) issue_patch(qp, 0, i);
-#pragma unroll
-        for (int k = 0; k < KLO; ++k) issue_w(0, k);
-        advance(qp, true);
-    }
-    int ctile = blockIdx.x, cc = 0;
-    const int npatch_mine = wave + NWAVES * (KP - 1) < A_PIECES ? KP : KP - 1;  // patch pieces this wave issues per chunk
-    for (int it = 0; it < total; ++it) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own pieces of patch(it) and taps 0-4 landed; own reads of chunk it-1 done
-        __builtin_amdgcn_s_barrier();                                // A(it)
-        const bool more = it + 1 < total;
-        const int wk_next = (cc + 1 == nchunks) ? 0 : wk + KCV;
-        const char* const Bf = lds;
-        // pixel fragments: two register sets (the next step's pair is requested in front of this step's MFMAs); weight fragments: ONE set,
-        // requested at the top of their step -- a second set would push the loop over the 256 registers a wave has at two waves per SIMD
-        // (spilled DMA addresses reloaded from scratch beside every piece); the partner wave's MFMAs cover this wave's wait for them
-        s16x8_t fa[2][MT], fb[NT];
-        auto load_a = [&](int st, int set) {
-            const int t = st >> 1, ks = st & 1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const s16x8_t*>(Bf + (aa[t % 3] ^ (ks << 5)) + (mt + t / 3) * (CD_PW * 64));
-        };
-        auto load_b = [&](int st) {
-            const int t = st >> 1, ks = st & 1, hf = t >= 5 ? 1 : 0;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) fb[nt] = *reinterpret_cast<const s16x8_t*>(Bf + b_lane[hf][ks] + ((t - 5 * hf) * BN + nt * 32) * 64);
-        };
-        auto mma_step = [&](int st) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[nt][mt][0] = H16<T>::mma(fb[nt], fa[st & 1][mt], acc[nt][mt][0]);
-        };
-        // ---- first half: taps 0-4 (steps 0-9); DMA: taps 5-8 of THIS chunk (steps 0-3), then the next chunk's patch (steps 4-8) ----
-        load_a(0, 0);
-#pragma unroll
-        for (int st = 0; st < 10; ++st) {
-            load_b(st);
-            if (st + 1 < 10) load_a(st + 1, (st + 1) & 1);
-            if (st < KHI) issue_w(wk, KLO + st);
-            else if (st < KHI + KP && more) issue_patch(qp, (it + 1) & 1, st - KHI);
-            mma_step(st);
-            __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-        }
-        if (more) advance(qp, true);
-        // ---- M(it): taps 5-8 in LDS (this wave's patch pieces, issued after them, may still be in flight) ----
-        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (npatch_mine == KP) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        static_assert(KP == 5, "the counted waits above assume five patch pieces per wave");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- second half: taps 5-8 (steps 10-17); DMA: taps 0-4 of the next chunk ----
-        load_a(10, 0);
-#pragma unroll
-        for (int st = 10; st < 18; ++st) {
-            load_b(st);
-            if (st + 1 < 18) load_a(st + 1, (st + 1) & 1);
-            if (st - 10 < KLO && more) issue_w(wk_next, st - 10);
-            mma_step(st);
-            __builtin_amdgcn_sched_group_barrier(0x100, NT + MT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
-        }
-        wk = wk_next;
-        {
-            const int delta = (it & 1) ? -A_BYTES : A_BYTES;  // the next chunk's patch sits in the other buffer
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) aa[dx] += delta;
-        }
-        if (++cc == nchunks) {
-            cc = 0;
-            int b, ty0, tx0;
-            tile_coords(ctile, b, ty0, tx0);
-            ctile += gridDim.x;
-            const int cstride = p.out_cstride;
-            const int x = tx0 + r;
-            const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
-            auto pixoff = [&](int mt) -> int64_t {
-                const int y = ty0 + wave * MT + mt;
-                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
-            };
-            auto pooloff = [&](int mt) -> int64_t {
-                const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
-                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
-            };
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float bias[1][16];
-                load_bias16<1>(p, n0 + 32 * nt, h, bias);
-                epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff, pooloff);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
-            }
-        }
-    }
-}
-
 // dense 3x3 stride-1 launch in bf16 / f16 with 32-channel-granular sources at the launch size or exactly half of it (the
 // caller has verified the canonical tap order and passes flip)
 bool falnet_conv_dma_applicable(const falnet_conv_t& p) {
@@ -776,27 +300,7 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p) {
     return true;
 }
 
-// variant 18: 128 output channels per workgroup
-bool falnet_conv_dma128_applicable(const falnet_conv_t& p) {
-    return falnet_conv_dma_applicable(p) && p.w_rows % 128 == 0 && p.Cout > 64 && (int64_t)p.w_rows * p.w_taps * p.cin_total < (1ll << 31);
-}
-int falnet_conv_dma128_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
-    constexpr int TH = 16;
-    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + TH - 1) / TH;
-    const int ntiles = p.B * tiles_x * tiles_y;
-    const int ny = (p.Cout + 127) / 128;
-    int gx = 256 / ny;
-    if (gx < 1) gx = 1;
-    if (gx > ntiles) gx = ntiles;
-    const dim3 grid((unsigned)gx, (unsigned)ny);
-    if (p.dtype == FALNET_F16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma128_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma128_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-    FALNET_RETURN_LAUNCH();
-}
-
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool producer_consumer) {
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
     constexpr int TH = 16;
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + TH - 1) / TH;
     const int ntiles = p.B * tiles_x * tiles_y;
@@ -805,13 +309,6 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, boo
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-    if (producer_consumer) {  // variant 17: four loader waves + four MFMA waves
-        if (p.dtype == FALNET_F16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_pc_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_pc_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-        FALNET_RETURN_LAUNCH();
-    }
     if (p.dtype == FALNET_F16)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<f16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
     else

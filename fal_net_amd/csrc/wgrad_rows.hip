@@ -329,10 +329,15 @@ __global__ __launch_bounds__(WR_THREADS, 2) void wgrad3x3_rows_kernel(const faln
 
 struct Wr8Item { int u, n, T, t, b, x0, y0; };  // rows [y0, y0+n) of strip x0 of sample b; t = step inside it (two rows per step)
 
-template <typename T, int D, int ABL = 0, bool STAGGER = true, bool ILV = true>
+// SPB = steps per barrier.  A step (two image rows) is only 18 MFMAs per wave -- the LDS-DMA conv kernels run 72 between barriers --, and
+// every barrier costs the arrival skew of eight waves plus the refill of the fragment pipeline.  With SPB = 2 the ring has D + 2 slots
+// (D = 4 steps of prefetch: 6 x 18 KB, inside the 147 KB the epilogue reduction needs anyway), a barrier stands only in front of the even
+// steps, and the counted vmcnt in front of it retires the pieces of BOTH steps of the pair: step g issues into slot (g + D) mod NS, last
+// read during step g - SPB, i.e. before the most recent barrier.
+template <typename T, int D, int ABL = 0, bool STAGGER = true, bool ILV = true, int SPB = 1>
 __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
-    constexpr int NS = D + 1;
-    static_assert(D >= 1 && D <= 3, "prefetch distance");
+    constexpr int NS = D + SPB;
+    static_assert(D >= 1 && D <= 4 && SPB >= 1 && SPB <= 2 && D >= SPB, "prefetch distance / steps per barrier");
     constexpr int LDS_BYTES = NS * WR8_SLOT > WR8_RED ? NS * WR8_SLOT : WR8_RED;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -545,22 +550,25 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
     for (int g = 0; g <= nst; ++g) {
         const bool do_issue = ABL != 1 && ABL != 4 && ABL != 5 && g + D < nst;
         if (g < nst) {
-            // this wave's pieces of step g have landed once at most k steps' worth of younger pieces are outstanding
-            const int k = min(D - 1, nst - 1 - g);
+          if (SPB == 1 || (g & (SPB - 1)) == 0) {
+            // this wave's pieces of steps g .. g + SPB - 1 have landed once at most k steps' worth of younger pieces are outstanding
+            // (issued so far: steps <= g + D - 1)
+            const int k = max(0, min(D - SPB, nst - g - SPB));
             if (ABL == 1 || ABL == 4 || ABL == 5) {
             } else if (pw == 0) {
-                if (k >= 2) wr_vmcnt<(D >= 3 ? 6 : 0)>();
-                else if (k == 1) wr_vmcnt<(D >= 2 ? 3 : 0)>();
+                if (k >= 2) wr_vmcnt<(D - SPB >= 2 ? 6 : 0)>();
+                else if (k == 1) wr_vmcnt<(D - SPB >= 1 ? 3 : 0)>();
                 else wr_vmcnt<0>();
             } else {
-                if (k >= 2) wr_vmcnt<(D >= 3 ? 4 : 0)>();
-                else if (k == 1) wr_vmcnt<(D >= 2 ? 2 : 0)>();
+                if (k >= 2) wr_vmcnt<(D - SPB >= 2 ? 4 : 0)>();
+                else if (k == 1) wr_vmcnt<(D - SPB >= 1 ? 2 : 0)>();
                 else wr_vmcnt<0>();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of step g - 1 are done (slot reuse)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of the previous steps are done (slot reuse)
             stamp(0);
             __builtin_amdgcn_s_barrier();
             stamp(1);
+          }
             if (!ILV && do_issue && !lag) {  // un-interleaved order: every piece of step g + D before the fragment reads
                 issue(ci_, islot);
                 advance_issue(g);
@@ -707,26 +715,43 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
     const int ntiles = ntci * ntco;
     const int nstrips = (p.TW + WR_TW - 1) / WR_TW;
     const dim3 grid((unsigned)(ntiles * p.nsplit));
-    static const int abl = [] { const char* e = falnet_ab_env("FALNET_WR_ABL"); return e ? atoi(e) : 0; }();
-    static const int form = [] { const char* e = falnet_ab_env("FALNET_WR_FORM"); return e ? atoi(e) : 8; }();  // 8: eight-wave form (default), 4: four waves
 #define WR_LAUNCH8(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<TT, DD, AA>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
+#ifdef FALNET_AB
+    // Experiment build only (python -m fal_net_amd._build --ab): timing ablations / stamp builds that do NOT compute the gradient
+    // (FALNET_WR_ABL) and the four-wave form (FALNET_WR_FORM=4).  The product library contains none of these instantiations.
+    static const int abl = [] { const char* e = falnet_ab_env("FALNET_WR_ABL"); return e ? atoi(e) : 0; }();
+    static const int form = [] { const char* e = falnet_ab_env("FALNET_WR_FORM"); return e ? atoi(e) : 8; }();
 #define WR_LAUNCH4(TT, DD, AA) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows_kernel<TT, DD, AA>), grid, dim3(WR_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips)
     if (form == 4) {
         if (p.dtype == FALNET_F16) WR_LAUNCH4(f16_t, 3, 0);
         else WR_LAUNCH4(bf16_t, 3, 0);
-    } else if (p.dtype == FALNET_F16) {
-        WR_LAUNCH8(f16_t, 2, 0);
-    } else if (abl == 1) WR_LAUNCH8(bf16_t, 2, 1);
-    else if (abl == 2) WR_LAUNCH8(bf16_t, 2, 2);
-    else if (abl == 3) WR_LAUNCH8(bf16_t, 2, 3);
-    else if (abl == 13) WR_LAUNCH8(bf16_t, 3, 0);
-    else if (abl == 4) WR_LAUNCH8(bf16_t, 2, 4);
-    else if (abl == 5) WR_LAUNCH8(bf16_t, 2, 5);
-    else if (abl == 9) WR_LAUNCH8(bf16_t, 2, 9);
-    else if (abl == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, true, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else if (abl == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, true>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else if (abl == 29) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 9, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        FALNET_RETURN_LAUNCH();
+    }
+    if (p.dtype != FALNET_F16 && abl != 0) {
+        if (abl == 1) WR_LAUNCH8(bf16_t, 2, 1);
+        else if (abl == 2) WR_LAUNCH8(bf16_t, 2, 2);
+        else if (abl == 3) WR_LAUNCH8(bf16_t, 2, 3);
+        else if (abl == 13) WR_LAUNCH8(bf16_t, 3, 0);
+        else if (abl == 4) WR_LAUNCH8(bf16_t, 2, 4);
+        else if (abl == 5) WR_LAUNCH8(bf16_t, 2, 5);
+        else if (abl == 9) WR_LAUNCH8(bf16_t, 2, 9);
+        else if (abl == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, true, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else if (abl == 22) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, true>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 0, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else if (abl == 29) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 2, 9, false, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else {
+            falnet_set_error("wgrad rows: unknown FALNET_WR_ABL=%d", abl);
+            return -1;
+        }
+        FALNET_RETURN_LAUNCH();
+    }
+#endif
+#ifdef FALNET_WR_SPB1  // A/B build: one barrier per step (D = 2), the round-2 form
+    if (p.dtype == FALNET_F16) WR_LAUNCH8(f16_t, 2, 0);
     else WR_LAUNCH8(bf16_t, 2, 0);
+#else
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+#endif
     FALNET_RETURN_LAUNCH();
 }

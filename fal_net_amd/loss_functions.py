@@ -69,7 +69,7 @@ class _VggPlan:
                 if cur is x0:
                     self.c3_call = ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)")
                     self.fwd.append(self.c3_call)
-                elif last and os.environ.get("FALNET_FUSED_POOL", "1") == "1":
+                elif last and L.ab("FALNET_FUSED_POOL", "1") == "1":
                     try:  # 2x2 max pool in the conv epilogue: the full-resolution map is not re-read (nor written at all for labels)
                         self.fwd.append(_conv(*args, y, h, w, pc.cout, pc.cout, pool_out=pooled, **kw))
                         fused = True

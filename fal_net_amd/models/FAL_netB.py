@@ -99,7 +99,7 @@ class BackBone(nn.Module):
 
 _TAIL_MAIN = ""  # default of FALNET_TAIL_MAIN: extra weight gradients for the main stream's tail beside level 0's (re-tuned after the later kernel
 # changes made the MAIN stream the longer chain again: "conv1,conv1_1.conv1" was +0.7 % once, now -0.6 %)
-_TAIL_LEVELS = int(os.environ.get("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
+_TAIL_LEVELS = int(L.ab("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
 class FalnetPlan:
@@ -191,10 +191,10 @@ class FalnetPlan:
             multi = ops.conv_multi_call(members, name="dgrad(s2 x4) " + name)
             multis = [multi]
             if (len(members) == 4 and self.dtype in ops.H16 and IH % 2 == 0 and IW % 2 == 0 and OH >= 16 and OW >= 32
-                    and os.environ.get("FALNET_S2D_DMA", "1") == "1"):
+                    and L.ab("FALNET_S2D_DMA", "1") == "1"):
                 # all four classes from ONE staged gout patch (conv_dma.hip): the gather form re-reads gout per tap and channel slice
                 multis.append(ops.conv_multi_call(members, name="dgrad(s2 x4, dma) " + name, s2d=True))
-            if ops.AUTOTUNE and os.environ.get("FALNET_S2_SPLITK", "1") == "1":
+            if ops.AUTOTUNE and L.ab("FALNET_S2_SPLITK", "1") == "1":
                 # small levels: the four classes as ONE split-K launch + ONE epilogue instead of one long-K launch or 4 x (split-K + epilogue)
                 wgs = 4 * ((B * ((IH + 1) // 2) * ((IW + 1) // 2) + 127) // 128) * ((cg + ops.gather_bn(cg, cg) - 1) // ops.gather_bn(cg, cg))
                 for k in (2, 4, 8):
@@ -212,7 +212,7 @@ class FalnetPlan:
                     c()
             import os as _os
             s2key = f"s2dgrad|t{L.dtype_code(self.dtype)}|B{B}|{IH}x{IW}|{pc.cout_pad}>{cg}|a{int(addend is not None)}{int(actout is not None)}|n{len(multis)}d"
-            chosen = ops.best_of(*multis, separate, key=s2key) if (ops.AUTOTUNE and _os.environ.get('FALNET_S2_MULTI') != '1') else multi
+            chosen = ops.best_of(*multis, separate, key=s2key) if (ops.AUTOTUNE and L.ab('FALNET_S2_MULTI', None) != '1') else multi
             if chosen is separate:
                 self.bwd_body.extend(singles)
             else:
@@ -291,7 +291,7 @@ class FalnetPlan:
             a[i], h_[i], c[i] = self._act(f"a{i}", hh, ww, ch), self._act(f"h{i}", hh, ww, ch), self._act(f"c{i}", hh, ww, ch)
             if i == 0:
                 # bf16: conv0's weight gradient reads the planar f32 image itself (falnet_wgrad variant 6): no NHWC copy of the image
-                self._c3_wgrad = dt in ops.H16 and W >= 16 and os.environ.get("FALNET_WGRAD_C3", "1") == "1"
+                self._c3_wgrad = dt in ops.H16 and W >= 16 and L.ab("FALNET_WGRAD_C3", "1") == "1"
                 srcs, ih, iw = [ops.planar_src(left) if self._c3_wgrad else ops.nhwc_src(x0)], H, W
             elif i == 1:
                 ih, iw = sizes[0]
@@ -308,7 +308,7 @@ class FalnetPlan:
             self._conv_fwd(pcs[rname + ".conv1"], [ops.nhwc_src(a[i])], hh, ww, h_[i], L.ACT_ELU, name=rname + ".conv1")
             self._conv_fwd(pcs[rname + ".conv2"], [ops.nhwc_src(h_[i])], hh, ww, c[i], L.ACT_ELU, addend=a[i],
                            name=rname + ".conv2")
-            if i == int(os.environ.get("FALNET_MID_HOOK_LEVEL", "2")):
+            if i == int(L.ab("FALNET_MID_HOOK_LEVEL", "2")):
                 # from here on (levels 3-6 of the encoder, 6-3 of the decoder) the launches are small and leave most CUs
                 # idle: the trainer's mid-forward hook starts independent heavy work (the label's VGG features) HERE, on
                 # another stream, instead of beside the chip-filling level-0..2 layers
@@ -423,7 +423,7 @@ class FalnetPlan:
                 else:
                     tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
                     fused = False
-                    if (2 * bh, 2 * bw) == (hh, ww) and os.environ.get("FALNET_FUSED_UPSUM", "1") == "1":
+                    if (2 * bh, 2 * bw) == (hh, ww) and L.ab("FALNET_FUSED_UPSUM", "1") == "1":
                         try:  # exact 2x: the 2x2 block sum and elu'(below) ride in the data-gradient epilogue (no full-res g_up)
                             self._dgrad(pcd, 0, g_dpre, None, hh, ww, name=dname, sum2x2_into=tgt, sum2x2_actout=below)
                             fused = True
@@ -445,9 +445,9 @@ class FalnetPlan:
                 if i == _TAIL_LEVELS - 1:
                     self._finish.append((2, len(self.bwd_body)))
                 self._bucket = 1 if i >= 4 else (2 if i >= _TAIL_LEVELS else 3)
-                tail = i == 0 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1"
+                tail = i == 0 and L.ab("FALNET_TAIL_BALANCE", "1") == "1"
                 # more weight gradients for the main stream's idle tail (names, comma separated): the side stream is the longer chain
-                extra = os.environ.get("FALNET_TAIL_MAIN", _TAIL_MAIN).split(",") if os.environ.get("FALNET_TAIL_BALANCE", "1") == "1" else []
+                extra = L.ab("FALNET_TAIL_MAIN", _TAIL_MAIN).split(",") if L.ab("FALNET_TAIL_BALANCE", "1") == "1" else []
                 cname, rname, ch = self._enc[i]
                 hh, ww = sizes[i]
                 gz = gc[i]
@@ -478,7 +478,7 @@ class FalnetPlan:
                 if bucket in finals:
                     red, bias = finals[bucket]
 
-                    if bucket == 3 and os.environ.get("FALNET_TAIL_BALANCE", "1") == "1":
+                    if bucket == 3 and L.ab("FALNET_TAIL_BALANCE", "1") == "1":
                         # last bucket: the bias gradients only need the data gradients -> main stream (idle by now), beside the
                         # side stream's last weight gradients and slab reduce; run_backward fires the bucket hook after the join
                         self.bwd_body.append(bias)
@@ -773,7 +773,7 @@ class FAL_net(nn.Module):
         # map: the plans run a single 3x3 convolution with the composed weights Wc = W1x1 . W3x3 straight into the planar f32
         # logits (no NHWC intermediate, no 1x1 launches in forward / dgrad / wgrad); the weight gradients are split back by
         # two small matrix products (dW3x3 = W1x1^T dWc, dW1x1 = dWc W3x3^T).  FALNET_COMPOSE_LOGITS=0 keeps the two launches.
-        self._compose_logits = os.environ.get("FALNET_COMPOSE_LOGITS", "1") == "1"
+        self._compose_logits = L.ab("FALNET_COMPOSE_LOGITS", "1") == "1"
         if self._compose_logits:
             w3, w1 = bb.iconv1.weight, self.conv0.weight
             dev = w3.device

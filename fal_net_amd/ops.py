@@ -39,14 +39,14 @@ DETERMINISTIC = L.DETERMINISTIC
 #     no longer pin a variant after a kernel rewrite.
 #   * The packaged file is READ-ONLY for ordinary processes (tests, training, bench): new choices live in memory only.  It is
 #     written when FALNET_AUTOTUNE_CACHE=<path> names a file explicitly (tools/regen_cache.sh) or FALNET_AUTOTUNE_CACHE_WRITE=1.
-#   * FALNET_AUTOTUNE_CACHE=0 disables it; so does any non-default candidate-gating switch (FALNET_NO_DMA, FALNET_WS2,
-#     FALNET_S2F_DMA, FALNET_S2D_DMA, FALNET_S2_SPLITK, FALNET_GATHER_NARROW): an A/B run must tune, not replay.
+#   * FALNET_AUTOTUNE_CACHE=0 disables it; so does any non-default candidate-gating experiment switch (FALNET_AB=1 with FALNET_NO_DMA,
+#     FALNET_WS2, FALNET_S2F_DMA, FALNET_S2D_DMA, FALNET_S2_SPLITK, FALNET_GATHER_NARROW): an A/B run must tune, not replay.
 _PKG_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_cache.json")
 _CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", _PKG_CACHE)
 _CACHE_WRITABLE = ("FALNET_AUTOTUNE_CACHE" in os.environ and _CACHE_PATH != "0") or os.environ.get("FALNET_AUTOTUNE_CACHE_WRITE") == "1"
 _GATES = {"FALNET_NO_DMA": "0", "FALNET_WS2": "1", "FALNET_S2F_DMA": "1", "FALNET_S2D_DMA": "1", "FALNET_S2_SPLITK": "1",
           "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_DMA128": "1"}
-if any(os.environ.get(k, v) != v for k, v in _GATES.items()):
+if os.environ.get("FALNET_AB") == "1" and any(os.environ.get(k, v) != v for k, v in _GATES.items()):
     _CACHE_PATH = "0"
 _CACHE = None
 _CACHE_DIRTY = False
@@ -403,7 +403,7 @@ def best_of(*calls, reps=5, key=None):
     return calls[times.index(min(times))]
 
 
-GATHER_NARROW = os.environ.get("FALNET_GATHER_NARROW", "0") == "1"  # opt-in: autotune also tries 32 / 64-channel gather workgroups on small layers (same-box A/B: no gain)
+GATHER_NARROW = L.ab("FALNET_GATHER_NARROW", "0") == "1"  # opt-in: autotune also tries 32 / 64-channel gather workgroups on small layers (same-box A/B: no gain)
 
 
 def gather_bn(w_rows, Cout):
@@ -462,11 +462,11 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
                 if M * w_rows * 4 <= d.splitk_ws_bytes and Cout % 8 == 0:
                     cands += [(v, k) for k in (2, 4) if w2 * k <= 2048]
     cands += [(2, 1), (3, 1), (4, 1), (6, 1), (7, 1), (10, 1)]
-    if os.environ.get("FALNET_WS2", "1") == "1":
+    if L.ab("FALNET_WS2", "1") == "1":
         cands += [(16, 1)]  # two-phase weight-stationary
-    if os.environ.get("FALNET_NO_DMA", "0") != "1":
+    if L.ab("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
-        if d.isy == 2 and os.environ.get("FALNET_S2F_DMA", "1") == "1":
+        if d.isy == 2 and L.ab("FALNET_S2F_DMA", "1") == "1":
             cands += [(15, 1)]  # LDS-DMA forward 3x3 stride-2
     if wgs < 512:
         cands += [(8, 1), (9, 1)]
@@ -519,7 +519,7 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
         if nsplit >= 8:
             nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
-        variant, sym = 7, f"_Z21wgrad3x3_rows8_kernelI{tn}Li2ELi0EEv14falnet_wgrad_tiiii"
+        variant, sym = 7, f"_Z21wgrad3x3_rows8_kernelI{tn}Li4ELi0ELb1ELb1ELi2EEv14falnet_wgrad_tiiii"
     elif dense:
         co2 = _wgrad_co2(dtype, dense, cin_pad, cout_pad)
         tiles = (cin_pad // 32) * (cout_pad // 32) // (2 if co2 else 1)
@@ -601,15 +601,15 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
     return call
 
 
-_FUSED_BIAS = os.environ.get("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients inside the halo weight-gradient kernels
-_WGRAD_WGS = int(os.environ.get("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
+_FUSED_BIAS = L.ab("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients inside the halo weight-gradient kernels
+_WGRAD_WGS = int(L.ab("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
 
 
-_WGRAD_ROWS_WGS = int(os.environ.get("FALNET_WGRAD_ROWS_WGS", "128"))  # workgroups (one per CU, eight waves) per row-streaming weight-gradient launch: half the chip,
+_WGRAD_ROWS_WGS = int(L.ab("FALNET_WGRAD_ROWS_WGS", "128"))  # workgroups (one per CU, eight waves) per row-streaming weight-gradient launch: half the chip,
 # the other half runs the data-gradient chain beside it (same-box A/B: 128 beats 256 by 3 % on the step and halves the slab bytes)
-_REDUCE_PER_LAYER = os.environ.get("FALNET_REDUCE_PER_LAYER", "0") == "1"
-_REDUCE_BLOCKS = int(os.environ.get("FALNET_REDUCE_BLOCKS", "64"))  # blocks per layer of the batched slab reduce (split over slab groups)
-_WGRAD_ROWS_MIN_ROWS = int(os.environ.get("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
+_REDUCE_PER_LAYER = L.ab("FALNET_REDUCE_PER_LAYER", "0") == "1"
+_REDUCE_BLOCKS = int(L.ab("FALNET_REDUCE_BLOCKS", "64"))  # blocks per layer of the batched slab reduce (split over slab groups)
+_WGRAD_ROWS_MIN_ROWS = int(L.ab("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
 
 
 def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
@@ -620,9 +620,9 @@ def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         return False
     if any(not ((s.H == IH or 2 * s.H == IH) and (s.W == IW or 2 * s.W == IW)) or s.C % 32 for s in srcs):
         return False
-    if str(cin_pad) in os.environ.get("FALNET_WGRAD_ROWS_SKIP_CIN", "").split(","):  # A/B: leave layers of this input width on the patch kernel
+    if str(cin_pad) in L.ab("FALNET_WGRAD_ROWS_SKIP_CIN", "").split(","):  # A/B: leave layers of this input width on the patch kernel
         return False
-    return os.environ.get("FALNET_WGRAD_ROWS", "1") == "1"
+    return L.ab("FALNET_WGRAD_ROWS", "1") == "1"
 
 
 def _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
@@ -630,7 +630,7 @@ def _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
     the input size (or per-sample constants)."""
     return (dtype in H16 and len(taps) == 9 and stride_in == 2 and TW >= 32 and TH == (IH + 1) // 2 and TW == (IW + 1) // 2
             and all((s.H == IH and s.W == IW) or (s.sy == 0 and s.sx == 0) for s in srcs)
-            and os.environ.get("FALNET_WGRAD_S2", "1") == "1")
+            and L.ab("FALNET_WGRAD_S2", "1") == "1")
 
 
 def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
@@ -638,7 +638,7 @@ def _wgrad_co2(dtype, dense, cin_pad, cout_pad):
     (1.7 instead of 2.7 transposed LDS reads per MFMA).  In isolation -17 % on 64 -> 64 channel layers and -4 % on 128 -> 128;
     in the step (weight gradients are the longest chain of backward) +2.1 % pairs/s with the cut at 128 input channels, a little
     less with no cut (same-box A/B)."""
-    return dense and dtype in H16 and cin_pad <= int(os.environ.get("FALNET_WGRAD_CO2_MAXCIN", "128")) and cout_pad % 64 == 0 and os.environ.get("FALNET_WGRAD_CO2", "1") == "1"
+    return dense and dtype in H16 and cin_pad <= int(L.ab("FALNET_WGRAD_CO2_MAXCIN", "128")) and cout_pad % 64 == 0 and L.ab("FALNET_WGRAD_CO2", "1") == "1"
 
 
 class WgradBatch:
@@ -646,7 +646,7 @@ class WgradBatch:
     region, so they can run back to back) followed by ONE batched slab reduce and ONE batched bias-gradient launch
     that add into the (pre-zeroed or accumulating) flat gradient buffer."""
 
-    SLAB_CAP = int(os.environ.get("FALNET_SLAB_CAP_MB", "32")) << 20  # bytes of partial slabs per layer
+    SLAB_CAP = int(L.ab("FALNET_SLAB_CAP_MB", "32")) << 20  # bytes of partial slabs per layer
 
     def __init__(self, dtype, device):
         self.dtype, self.device = dtype, device

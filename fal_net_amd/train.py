@@ -58,7 +58,7 @@ class FlatAdam:
             L.check(L.lib().falnet_adam_step_guarded(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
                                                      b1, b2, self.eps, float(grad_scale), L.ptr(scaler.state), st), "adam_step_guarded")
             scaler.update()
-        if _os.environ.get("FALNET_PACK_AFTER_ADAM", "1") == "1":
+        if L.ab("FALNET_PACK_AFTER_ADAM", "1") == "1":
             self.model.repack_after_optimizer()  # the raw-pointer update is invisible to autograd's version counters
         else:
             self.model.mark_weights_changed()
@@ -261,7 +261,7 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
         seed_l1, seed_p, seed_sm = sd3[0:], sd3[1:], sd3[2:]
     joins = []
     if a_p > 0:
-        if _os.environ.get("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
+        if L.ab("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
             model._mid_forward_hook = lambda: joins.append(vgg_label_async(right))
         else:
             joins.append(vgg_label_async(right))
@@ -277,8 +277,6 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     S = plan.buf.get("step_scalars")  # [rec = L1 + a_p * perceptual, sm]: zero on entry (falnet_step_scalars re-zeroes it at the end of every step)
     if S is None:
         S = plan.buf["step_scalars"] = torch.zeros(2, device=dev)
-        plan.buf["step_out"] = torch.zeros(4, 3, device=dev)  # ring of result triples {loss, rec, sm}: a step's scalars stay valid for three more steps
-        plan._step_out_i = 0
     n_img = B * C * H * W
     # every loss term AND its adjoint in one pass over its operands (the upstream scalars -- loss scale, a_p, a_sm -- are known now)
     g_pan, g_disp = b["g_pan"], b["g_disp"]
@@ -316,8 +314,7 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
         g_pan.add_(vplan.g_in)
         vplan.busy = False
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
-    plan._step_out_i = (plan._step_out_i + 1) % 4
-    Sc = plan.buf["step_out"][plan._step_out_i]
+    Sc = torch.empty(3, device=dev)  # a fresh triple per step (callers keep loss tensors across steps); no launch: caching allocator
     L.check(lib.falnet_step_scalars(L.ptr(S), float(a_sm), L.ptr(Sc), st), "step_scalars")  # {rec + a_sm sm, rec, sm}; S -> 0
     out = {"loss": Sc[0], "rec": Sc[1], "sm": Sc[2] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp, "scaler": scaler}
     if optimize:
@@ -340,7 +337,7 @@ def stage1_step(model, opt, left, right, max_disp, a_p=0.01, a_sm=0.2 * 2 / 512,
     # main stream reaches the small deep layers (beside the chip-filling shallow ones the overlap would only time-slice)
     joins = []
     if a_p > 0:
-        if _os.environ.get("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
+        if L.ab("FALNET_LABEL_VGG_MID", "1") == "1" and ops.TIMER is None:
             model._mid_forward_hook = lambda: joins.append(vgg_label_async(right))
         else:
             joins.append(vgg_label_async(right))

@@ -118,10 +118,6 @@ typedef struct {
                                   13 LDS-DMA double-buffered persistent kernel (16-bit operands, 16x32 positions x 64 channels per
                                   workgroup, sources at the launch size or exactly half of it);
                                   15 forward 3x3 stride-2 by LDS-DMA (parity-de-interleaved patch, 16-channel chunks);
-                                  18 = 13 with 128 output channels per workgroup (w_rows % 128 == 0): the halo patch is staged once per
-                                  128 channels (26 % fewer LDS-DMA bytes per FLOP), weights refilled in two halves behind two barriers;
-                                  17 = 13 as a producer / consumer workgroup: four loader waves issue every LDS-DMA piece, four MFMA waves
-                                  (four rows x 64 channels each) do nothing but fragment reads and MFMAs;
                                   16 = 10 with two groups of four waves half a period apart (one in its MFMAs while the other stores,
                                   loads and runs the epilogue), half-height tiles;
                                   -2 is returned when the variant does not apply */

@@ -116,6 +116,7 @@ def test_composed_logits_conv_matches_two_launch_form(monkeypatch):
     left, right, mn, mx = synthetic.synthetic_pair(2, 64, 96, seed=11)
     res = {}
     for flag in ("0", "1"):
+        monkeypatch.setenv("FALNET_AB", "1")  # experiment switches are honoured only with FALNET_AB=1
         monkeypatch.setenv("FALNET_COMPOSE_LOGITS", flag)
         m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(7)}, 7).to(DEV).train()
         pan, disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV), ret_disp=True, ret_pan=True)

@@ -307,6 +307,7 @@ def test_pack_after_optimizer_tracks_weight_changes(monkeypatch):
     left, right, mx = left.to(DEV), right.to(DEV), mx.to(DEV)
 
     def run(flag):
+        monkeypatch.setenv("FALNET_AB", "1")  # experiment switches are honoured only with FALNET_AB=1
         monkeypatch.setenv("FALNET_PACK_AFTER_ADAM", flag)
         m = build(7).train()
         opt = train.FlatAdam(m, lr=1e-3, betas=(0.5, 0.999))
