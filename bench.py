@@ -73,6 +73,47 @@ def hbm_traffic_from_profiles(kernel_symbol):
     return None
 
 
+def hbm_traffic_live(kernel_symbol, args):
+    """HBM bytes per launch of the dominant kernel measured in THIS run on THIS box: two short child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only -- no trace domains), exactly as
+    tools/profile_round.sh / MI355X_MICROARCH.md prescribe (FETCH_SIZE doubled: gfx950 reports half the bytes of wide coalesced
+    reads).  Returns None when rocprofv3 is unavailable or a pass fails (the caller then falls back to the committed profile)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    sums = {}
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
+             "--workload", args.workload, "--dtype", args.dtype, "--batch", str(args.batch)]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="falnet_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and row["Kernel_Name"].split("(")[0][:100] == kernel_symbol[:100]:
+                    tot += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None
+            sums[counter] = (tot * 1024.0 / n, n)  # rocprofv3 reports KiB
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = 2.0 * sums["FETCH_SIZE"][0], sums["WRITE_SIZE"][0]
+    return {"bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write, "launches_sampled": sums["FETCH_SIZE"][1],
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this bench run (FETCH_SIZE x2, gfx950)"}
+
+
 def host_cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -246,6 +287,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profiles/ file instead of two live rocprofv3 --pmc child passes (~25 s each)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured hipGraph (measured slower than eager launches on ROCm 7.0: off by default)")
     ap.add_argument("--launch-table", default=None, help="write the per-launch time table of the instrumented pass here")
@@ -370,7 +413,7 @@ def main():
         mfma_fl = sum(a["flops"] for a in agg.values()) / 3
         result["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": hbm_traffic_from_profiles(dom_tag),
+            "traffic": (None if args.no_live_traffic else hbm_traffic_live(dom_tag, args)) or hbm_traffic_from_profiles(dom_tag),
             "kernel": dom_tag, "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "kernel_ms_per_step": d["ms"] / 3, "all_kernels_ms_per_step": total_ms,
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,
