@@ -2719,8 +2719,8 @@ static bool g_disable_patch = [] { const char* e = falnet_ab_env("FALNET_DISABLE
 static int g_patch_kcb = [] { const char* e = falnet_ab_env("FALNET_PATCH_KCB"); return e ? atoi(e) : 128; }();
 
 
-bool falnet_conv_dma_applicable(const falnet_conv_t& p);                    // conv_dma.hip
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st);
+bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh);        // conv_dma.hip
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool small_tile);
 bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n);         // four parity classes of a stride-2 data gradient in one pass
 int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st);
 bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p);                // forward 3x3 stride-2
@@ -2762,7 +2762,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17, "conv2d: unknown variant %d", variant);
     if (variant == 15) {  // LDS-DMA forward 3x3 stride-2 (conv_dma.hip)
         if (!falnet_conv_s2f_dma_applicable(p)) {
             falnet_set_error("conv2d: variant 15 needs a canonical 16-bit 3x3 stride-2 pad-1 NHWC launch (>= 8 x 32 outputs) with sources at the input size");
@@ -2774,15 +2774,16 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
         return 0;
     }
-    if (variant == 13) {  // LDS-DMA, double-buffered, persistent: 16x32 positions x 64 channels per workgroup (conv_dma.hip)
-        if (!(dense3x3 && falnet_conv_dma_applicable(p))) {
-            falnet_set_error("conv2d: variant 13 needs a 16-bit dense 3x3 stride-1 launch (>= 16 x 32 positions) with sources at the launch size or half of it");
+    if (variant == 13 || variant == 17) {  // LDS-DMA, double-buffered, persistent: 16x32 (13) or 4x32 (17) positions x 64 channels per workgroup (conv_dma.hip)
+        if (!(dense3x3 && falnet_conv_dma_applicable(p, variant == 17 ? 4 : 16)) || (variant == 17 && p.pool_out)) {
+            falnet_set_error("conv2d: variant %d needs a 16-bit dense 3x3 stride-1 launch (>= %d x 32 positions%s) with sources at the launch size or half of it",
+                             variant, variant == 17 ? 4 : 16, variant == 17 ? ", no fused pool" : "");
             return -2;
         }
         c.flip = flip;
         c.swap = 0;
         c.patch = 3;
-        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = 16; c.nwaves = 8;
+        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = variant == 17 ? 4 : 16; c.nwaves = variant == 17 ? 4 : 8;
         return 0;
     }
     if (variant == 10 || variant == 16) {
@@ -2860,7 +2861,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     if (c.patch == 4)
         snprintf(buf, len, "_Z22conv3x3_s2f_dma_kernelI%sLi%dEEv13falnet_conv_tiii", t, c.bn);
     else if (c.patch == 3)
-        snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi16ELi8EEv13falnet_conv_tiiii", t);
+        snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi%dELi%dEEv13falnet_conv_tiiii", t, c.th, c.nwaves);
     else if (c.patch == 2)
     {
         const int m16 = (int)(falnet_mfma16_enabled() && pp->dtype != FALNET_F32);
@@ -2904,7 +2905,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
     if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
-    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st);
+    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st, c.th == 4);
     if (c.patch == 2) {
         const int ws_th = c.th;
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;

@@ -46,10 +46,14 @@ __device__ __forceinline__ void cd_glds16(const void* gsrc, unsigned lds_dst) {
 
 #define CD_PW 34  // patch columns: 32 + the +-1 halo
 
+// <T, 16, 8>: the 16 x 32 tile described above.  <T, 4, 4> (variant 17): 4 x 32 positions, four waves of ONE row each, 2 x 49 KB of LDS -- the
+// 16 x 32-pixel maps of level 4 are a single 16-row tile per sample (32 workgroups at B = 8), with four-row tiles 128: 29 -> 17 us on the
+// 256-channel layers there.  (Measured on that form and dropped: a third chunk buffer with two chunks in flight, 18.6 vs 17.4 us -- a one-row
+// wave is held by the ISSUE of its 12-13 DMA pieces per chunk, ~200 cycles each beside 36 MFMAs, not by their latency.)
 template <typename T, int TH, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
     constexpr int BN = 64, MT = TH / NWAVES, NT = BN / 32;
-    static_assert(MT == 2 && sizeof(T) == 2, "two 32-position rows per wave, 16-bit operands");
+    static_assert((MT == 1 || MT == 2) && sizeof(T) == 2, "one or two 32-position rows per wave, 16-bit operands");
     constexpr int KCV = 32;                                   // input channels per chunk (64 B per pixel / weight row)
     constexpr int NPIX = (TH + 2) * CD_PW;
     constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
@@ -163,9 +167,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
     };
 
     // ---- fragment read addresses (bytes inside a buffer): pixel rows  p = (2 wave + mt + dy) * 34 + dx + r ----
-    int a_addr[4][3];  // k-step 0; k-step 1 is the same address with bit 5 flipped (segment (2 ks + h) ^ q)
+    int a_addr[MT + 2][3];  // k-step 0; k-step 1 is the same address with bit 5 flipped (segment (2 ks + h) ^ q)
 #pragma unroll
-    for (int rs = 0; rs < 4; ++rs)
+    for (int rs = 0; rs < MT + 2; ++rs)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int pp = (wave * MT + rs) * CD_PW + dx + r;
@@ -218,9 +222,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         int bo = (it & 1) * BUF;
         asm volatile("" : "+s"(bo));
         const char* const Bf = lds;
-        int aa[4][3], bb[2];
+        int aa[MT + 2][3], bb[2];
 #pragma unroll
-        for (int rs = 0; rs < 4; ++rs)
+        for (int rs = 0; rs < MT + 2; ++rs)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) aa[rs][dx] = a_addr[rs][dx] + bo;
 #pragma unroll
@@ -284,14 +288,14 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 
 // dense 3x3 stride-1 launch in bf16 / f16 with 32-channel-granular sources at the launch size or exactly half of it (the
 // caller has verified the canonical tap order and passes flip)
-bool falnet_conv_dma_applicable(const falnet_conv_t& p) {
+bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh) {
     // (32-bit element offsets inside a sample / the packed weight)
     for (int s = 0; s < p.nsrc; ++s)
         if ((int64_t)p.src[s].H * p.src[s].sy >= (1ll << 31)) return false;
     if ((int64_t)p.w_rows * p.w_taps * p.cin_total >= (1ll << 31)) return false;
     if ((p.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;  // the zero page must cover one row of channels
     if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
-    if (p.nsrc < 1 || p.nsrc > 2 || p.w_taps != 9 || p.OH < 16 || p.OW < 32) return false;
+    if (p.nsrc < 1 || p.nsrc > 2 || p.w_taps != 9 || p.OH < min_oh || p.OW < 32) return false;
     for (int s = 0; s < p.nsrc; ++s) {
         const falnet_src_t& S = p.src[s];
         if (S.C % 32 || S.C <= 0) return false;
@@ -300,7 +304,23 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p) {
     return true;
 }
 
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
+// small_tile: variant 17 -- 4 x 32 positions per workgroup, four waves of ONE row each (conv3x3_dma_kernel<T, 4, 4>): the 16 x 32-pixel maps of
+// encoder / decoder level 4 are a single 16-row tile per sample (32 workgroups at B = 8 for 256 channels), with four-row tiles 128.
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool small_tile) {
+    if (small_tile) {
+        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 3) / 4;
+        const int ntiles = p.B * tiles_x * tiles_y;
+        const int ny = (p.Cout + 63) / 64;
+        int gx = 256 / ny;
+        if (gx < 1) gx = 1;
+        if (gx > ntiles) gx = ntiles;
+        const dim3 grid((unsigned)gx, (unsigned)ny);
+        if (p.dtype == FALNET_F16)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<f16_t, 4, 4>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<bf16_t, 4, 4>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+        FALNET_RETURN_LAUNCH();
+    }
     constexpr int TH = 16;
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + TH - 1) / TH;
     const int ntiles = p.B * tiles_x * tiles_y;

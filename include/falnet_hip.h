@@ -118,6 +118,7 @@ typedef struct {
                                   13 LDS-DMA double-buffered persistent kernel (16-bit operands, 16x32 positions x 64 channels per
                                   workgroup, sources at the launch size or exactly half of it);
                                   15 forward 3x3 stride-2 by LDS-DMA (parity-de-interleaved patch, 16-channel chunks);
+                                  17 = 13 on 4x32-position tiles with four waves (one row each): small maps (levels 4-6) get 4x the workgroups;
                                   16 = 10 with two groups of four waves half a period apart (one in its MFMAs while the other stores,
                                   loads and runs the epilogue), half-height tiles;
                                   -2 is returned when the variant does not apply */

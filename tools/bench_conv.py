@@ -23,8 +23,10 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("conv3_1 256->256 @32x64", [256], 256, 32, 64, None),
     ("iconv4 128+256->256 @32x64", [128, 256], 256, 32, 64, None),
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
+    ("iconv5 128+256->256 @16x32", [128, 256], 256, 16, 32, None),
+    ("deconv4 256->128 @32x64 (up)", [256], 128, 32, 64, (16, 32)),
 ]
-VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dma4", 17), ("gather", 1)]
 if os.environ.get("BENCH_VARIANTS"):  # e.g. BENCH_VARIANTS=dma,ws
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["BENCH_VARIANTS"].split(",")]
 if os.environ.get("BENCH_LAYERS"):  # substring filter, comma separated
