@@ -357,6 +357,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    issued = time.perf_counter() - t0  # host time to ISSUE the K steps (no synchronisation inside the loop): the launch-bound share of a step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -379,7 +380,7 @@ def main():
         "config": {"workload": f"{stage} training step ({cfg_name}), batch {args.batch}/GPU, "
                                f"{args.height}x{args.width}, N={args.levels}, seeded weights, seeded VGG19",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss,
-                   "launch": "hipGraph replay" if graphed else "eager"},
+                   "launch": "hipGraph replay" if graphed else "eager", "host_issue_ms_per_step": issued * 1e3 / args.steps},
     }
 
     if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":

@@ -170,8 +170,40 @@ def check(rc, what=""):
         raise RuntimeError(f"libfalnet_hip {what} failed (rc={rc}): {msg}")
 
 
+# Launch stream.  Every kernel launch names its stream explicitly (C-ABI), so a plan replay does not need torch's notion of a current
+# stream per launch: `stream_scope` pins the pointer once for a whole forward / backward replay (torch.cuda.current_stream() builds a
+# Stream object per call: ~1.5 us x 300 launches), and `on_stream` redirects the launches of a `with` block to another stream (the
+# weight-gradient side stream) without torch.cuda.stream()'s context switch (~10 us per launch group).  Outside such scopes the current
+# torch stream is looked up per call, as before.
+_PINNED = None
+
+
 def stream_ptr():
+    if _PINNED is not None:
+        return _PINNED
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class stream_scope:
+    """Pin stream_ptr() to the CURRENT torch stream (or to `stream`) for the duration of the block; scopes nest."""
+
+    def __init__(self, stream=None):
+        self._s = stream
+
+    def __enter__(self):
+        global _PINNED
+        self._old = _PINNED
+        s = self._s if self._s is not None else torch.cuda.current_stream()
+        _PINNED = C.c_void_p(s.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        global _PINNED
+        _PINNED = self._old
+        return False
+
+
+on_stream = stream_scope  # `with L.on_stream(side): launch()` -- launches of the block go to `side`
 
 
 def ptr(t):

@@ -102,6 +102,19 @@ _TAIL_MAIN = ""  # default of FALNET_TAIL_MAIN: extra weight gradients for the m
 _TAIL_LEVELS = int(L.ab("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
+class _WgradPart:
+    """One input-channel group of a two-source convolution presented to ops.WgradBatch as a layer of its own: `cin` stays the row stride
+    of the full OIHW gradient, the group's channels are the packed columns [0, c_pad) -> real columns [0, c_real) of the gradient VIEW
+    the caller passes (offset to the group's first input channel)."""
+
+    def __init__(self, pc, c_real, c_pad):
+        self.cout, self.cin, self.cin_pad, self.bias, self.taps, self.ksize, self.stride = pc.cout, pc.cin, c_pad, pc.bias, pc.taps, pc.ksize, pc.stride
+        self._g = (c_real, c_pad)
+
+    def group_channels(self):
+        return self._g
+
+
 class FalnetPlan:
     """Static launch plan of FAL_net.forward / backward for one (B, H, W, dtype, device)."""
 
@@ -223,6 +236,23 @@ class FalnetPlan:
         self._buckets_seen = getattr(self, "_buckets_seen", set()) | {self._bucket}
         gw = self.model._grad_view(pc.weight)
         gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
+        if (len(srcs) == 2 and pc.groups_pad == [64, 32] and pc.stride == 1 and pc.taps == 9 and self.dtype in ops.H16
+                and L.ab("FALNET_SPLIT_WGRAD_96", "1") == "1"):
+            # 64 + 32 input channels (the logits conv over concat(deconv1, conv0_1)): the row-streaming kernel works on 64 x 64 channel
+            # blocks, so its second input-channel block would be half padding -- two of every four waves idle through the full-resolution
+            # pass (294 us, the longest weight gradient of the step).  One launch per source instead: the 64-channel source on the
+            # row-streaming kernel, the 32-channel source on the 32 x 64 halo-patch kernel; each reduces into its own input-channel
+            # columns of the same OIHW gradient (row stride = all 96 channels).
+            taps = [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)]
+            calls = []
+            for gi, (src, c_real, c_pad, col0) in enumerate(((srcs[0], pc.groups_real[0], 64, 0), (srcs[1], pc.groups_real[1], 32, pc.groups_real[0]))):
+                part = _WgradPart(pc, c_real, c_pad)
+                calls.append(self.wbatch.add([src], IH, IW, gout, taps, 1, self.B, OH, OW, part, gw[:, col0:], gb if gi == 0 else None,
+                                             name=f"wgrad {name}[{'deconv' if gi == 0 else 'skip'}]",
+                                             flops=2 * self.B * OH * OW * pc.cout * c_real * 9, bucket=self._bucket))
+            for c in calls:
+                self._side_call(c)
+            return
         call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
                                pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
                                bucket=self._bucket)
@@ -245,8 +275,12 @@ class FalnetPlan:
                 return
             ev.record()
             side.wait_event(ev)
-            with torch.cuda.stream(side):
-                c()
+            if getattr(c, "needs_torch_stream", False):  # the bucket hook (torch.distributed collectives run on torch's current stream)
+                with torch.cuda.stream(side), L.on_stream(side):
+                    c()
+            else:
+                with L.on_stream(side):  # C-ABI launches name their stream: no torch stream switch needed
+                    c()
         self.bwd_body.append(run)
 
     # ---- plan construction ----
@@ -492,6 +526,7 @@ class FalnetPlan:
                         if bucket == 0 and getattr(self.model, "_compose_logits", False):
                             self._split_logits_grad()
                         self.model._bucket_ready(bucket)
+                    finish.needs_torch_stream = True
                     self._side_call(finish)
             self.bwd_body.extend(body[pos:])
 
@@ -531,17 +566,18 @@ class FalnetPlan:
             for call in self.pack:
                 call()
         hook, mid = getattr(self.model, "_mid_forward_hook", None), getattr(self, "_mid_index", -1)
-        for i, call in enumerate(self.fwd):
-            if hook is not None and i == mid:
-                self.model._mid_forward_hook = None  # one shot
-                hook()
-            call()
-        if ret_pan or ret_subocc:
-            self.head_full()
-        else:
-            self.head_disp_only()
-        if ret_subocc:
-            self.head_masks()
+        with L.stream_scope():  # one stream lookup for the whole replay
+            for i, call in enumerate(self.fwd):
+                if hook is not None and i == mid:
+                    self.model._mid_forward_hook = None  # one shot
+                    hook()  # (launches on its own stream: train.vgg_label_async redirects with L.on_stream)
+                call()
+            if ret_pan or ret_subocc:
+                self.head_full()
+            else:
+                self.head_disp_only()
+            if ret_subocc:
+                self.head_masks()
         return self.generation
 
     def run_backward(self, g_disp, g_pan, in_place=False):
@@ -567,9 +603,10 @@ class FalnetPlan:
             self._side_stream.wait_stream(main)  # the previous step's Adam / repack must not be overtaken
         else:
             self._side_stream = None
-        self.head_bwd[(g_disp is not None, g_pan is not None)]()
-        for call in self.bwd_body:
-            call()
+        with L.stream_scope():  # one stream lookup for the whole replay; side calls redirect their launches with L.on_stream
+            self.head_bwd[(g_disp is not None, g_pan is not None)]()
+            for call in self.bwd_body:
+                call()
         if self._side_stream is not None:
             main.wait_stream(self._side_stream)
         if getattr(self, "_deferred_ready", None) is not None:
@@ -637,8 +674,13 @@ class FAL_net(nn.Module):
 
     # ---- flat parameter / gradient storage ----
     def _trainable_named(self):
-        """Parameters that receive gradients (amask_conv never does: FAL_netB.py:128)."""
-        return [(n, p) for n, p in self.named_parameters() if "amask_conv" not in n]
+        """Parameters that receive gradients (amask_conv never does: FAL_netB.py:128).  Cached: the module tree is fixed after
+        construction (the Parameter objects survive .to() / load_state_dict), and a step asks for this list half a dozen times
+        (named_parameters() walks the whole tree: ~1 ms of host time per step)."""
+        c = getattr(self, "_trainable_cache", None)
+        if c is None:
+            c = self._trainable_cache = [(n, p) for n, p in self.named_parameters() if "amask_conv" not in n]
+        return c
 
     def _ensure_flat(self, device):
         named = self._trainable_named()

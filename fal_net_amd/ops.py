@@ -620,6 +620,8 @@ def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
     32-pixel strips, sources at the launch size or exactly half of it."""
     if not (dense and dtype in (torch.bfloat16, torch.float16) and TW >= 32 and max(cin_pad, cout_pad) >= 64):
         return False
+    if cin_pad == 32:  # a 32-channel source under a 64 x 64 block: half of the block's waves idle -> the 32 x 64 halo-patch kernel (variant 3)
+        return False
     if any(not ((s.H == IH or 2 * s.H == IH) and (s.W == IW or 2 * s.W == IW)) or s.C % 32 for s in srcs):
         return False
     if str(cin_pad) in L.ab("FALNET_WGRAD_ROWS_SKIP_CIN", "").split(","):  # A/B: leave layers of this input width on the patch kernel

@@ -216,7 +216,7 @@ def vgg_label_async(label, borrow=True):
     main = torch.cuda.current_stream()
     aux = _aux_stream(label.device)
     aux.wait_stream(main)
-    with torch.cuda.stream(aux):
+    with torch.cuda.stream(aux), L.on_stream(aux):  # (torch stream for the allocator / record_stream, pinned pointer for the launches)
         feats = vgg(label, borrow=borrow)  # consumed by this step's perceptual loss only
 
     def join():
@@ -246,6 +246,11 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     plans' gradient buffers, the plan's backward.  No autograd graph, no scalar aten launches (the autograd form spends ~30
     launches of 4-5 us on `l1 + a_p * perc`, `rec + a_sm * sm`, output clones, gradient sums and seed fills).  `rpan` /
     `ldisp` in the result alias the plan's output buffers: valid until the model's next forward of this shape."""
+    with L.stream_scope():  # one stream lookup for the ~330 launches of the step
+        return _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize)
+
+
+def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize):
     from . import loss_functions as LF
     lib = L.lib()
     B, C, H, W = left.shape
