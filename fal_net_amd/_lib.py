@@ -118,6 +118,7 @@ SIGNATURES = {
     "falnet_mse_fwd": [_P, _P, _L, _I, _F, _P, _I, _I, _P],
     "falnet_mse_bwd": [_P, _P, _L, _I, _F, _P, _P, _I, _P],
     "falnet_l1_fwd_bwd": [_P, _P, _I, _I, _L, _F, _P, _P, _P, _P],
+    "falnet_l1_fwd_bwd_add": [_P, _P, _I, _I, _L, _F, _P, _P, _P, _P, _P],
     "falnet_mse_fwd_bwd": [_P, _P, _L, _I, _F, _P, _F, _P, _P, _I, _P],
     "falnet_smooth_fwd_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "falnet_smooth_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],

@@ -55,25 +55,30 @@ static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
 __global__ __launch_bounds__(RED_THREADS) void l1_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ mask, int C, int64_t HW,
                                                              int64_t total, float scale, float* out,
-                                                             const float* __restrict__ gscale = nullptr, float* __restrict__ ga = nullptr, int det = 0) {
+                                                             const float* __restrict__ gscale = nullptr, float* __restrict__ ga = nullptr, int det = 0,
+                                                             const float* __restrict__ gadd = nullptr) {
     __shared__ float red[16];
     float acc = 0.f;
-    const float gs = ga ? scale * (gscale ? gscale[0] : 1.f) : 0.f;  // ga: the gradient gscale * scale * sign(a - b) in the same pass (unmasked)
-    if (!mask && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(ga)) & 15) == 0) {  // 16-byte loads
+    const float gs = ga ? scale * (gscale ? gscale[0] : 1.f) : 0.f;  // ga: the gradient gscale * scale * sign(a - b) (+ gadd) in the same pass (unmasked)
+    if (!mask && (total & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(ga) | reinterpret_cast<uintptr_t>(gadd)) & 15) == 0) {  // 16-byte loads
         const float4* a4 = reinterpret_cast<const float4*>(a);
         const float4* b4 = reinterpret_cast<const float4*>(b);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total >> 2); i += (int64_t)gridDim.x * blockDim.x) {
             const float4 x = a4[i], y = b4[i];
             const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
             acc += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
-            if (ga) reinterpret_cast<float4*>(ga)[i] = make_float4(sgn(d0) * gs, sgn(d1) * gs, sgn(d2) * gs, sgn(d3) * gs);
+            if (ga) {
+                const float4 o = gadd ? reinterpret_cast<const float4*>(gadd)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                reinterpret_cast<float4*>(ga)[i] = make_float4(sgn(d0) * gs + o.x, sgn(d1) * gs + o.y, sgn(d2) * gs + o.z, sgn(d3) * gs + o.w);
+            }
         }
         const float s4 = block_sum(acc, red);
         red_finish(out, s4 * scale, det);
         return;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        if (ga) ga[i] = sgn(a[i] - b[i]) * gs;
+        if (ga) ga[i] = sgn(a[i] - b[i]) * gs + (gadd ? gadd[i] : 0.f);
         float d = fabsf(a[i] - b[i]);
         if (mask) {
             const int64_t bi = i / (C * HW), p = i % HW;
@@ -678,7 +683,17 @@ extern "C" int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, i
     FALNET_CHECK_ARG(a && b && out && ga && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
-                       out, gscale, ga, falnet_deterministic());
+                       out, gscale, ga, falnet_deterministic(), (const float*)nullptr);
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_l1_fwd_bwd_add(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale,
+                                     const float* gadd, float* ga, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(a && b && out && ga && gadd && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd_add: bad argument");
+    const int64_t total = (int64_t)B * C * HW;
+    hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
+                       out, gscale, ga, falnet_deterministic(), gadd);
     FALNET_RETURN_LAUNCH();
 }
 

@@ -285,8 +285,9 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
     n_img = B * C * H * W
     # every loss term AND its adjoint in one pass over its operands (the upstream scalars -- loss scale, a_p, a_sm -- are known now)
     g_pan, g_disp = b["g_pan"], b["g_disp"]
-    L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(g_pan), st),
-            "l1_fwd_bwd")  # loss_functions.py:53
+    if a_p <= 0:  # no perceptual term: the L1 gradient is the whole gradient of the synthesised view
+        L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(g_pan), st),
+                "l1_fwd_bwd")  # loss_functions.py:53
     vplan = None
     if a_p > 0:
         vm = LF.vgg._get()
@@ -316,7 +317,9 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
     if vplan is not None:
         for c in vplan.bwd:
             c()
-        g_pan.add_(vplan.g_in)
+        # L1 term (loss_functions.py:53) and its gradient, with the VGG gradient of the synthesised view added in the same pass
+        L.check(lib.falnet_l1_fwd_bwd_add(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(vplan.g_in), L.ptr(g_pan), st),
+                "l1_fwd_bwd_add")
         vplan.busy = False
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
     Sc = torch.empty(3, device=dev)  # a fresh triple per step (callers keep loss tensors across steps); no launch: caching allocator

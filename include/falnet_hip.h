@@ -312,6 +312,10 @@ int falnet_smooth_bwd(const float* img, const float* disp, int B, int H, int W, 
  * gradient exactly as the *_bwd entry point writes it (assigned, not accumulated). */
 int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale, float* ga,
                       void* stream);
+/* falnet_l1_fwd_bwd with another gradient of the same tensor added in the same pass: ga = gscale * scale * sign(a - b) + gadd (gadd may not
+ * alias ga) -- the perceptual (VGG) gradient of the synthesised view joins the L1 gradient without an extra add launch */
+int falnet_l1_fwd_bwd_add(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale,
+                          const float* gadd, float* ga, void* stream);
 int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale_out, float* out, float scale_grad,
                        const float* gscale, void* ga, int dtype, void* stream);
 int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale, float* out,
