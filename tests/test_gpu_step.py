@@ -509,3 +509,25 @@ def test_deterministic_mode_is_bit_identical():
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     for name, x in res.items():
         assert x["identical"], (name, x)
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_data_parallel_two_ranks_one_gpu(dtype_name, tmp_path):
+    """World size 2 with real kernels (two processes on cuda:0, gloo transport: RCCL refuses two ranks on one device): start-up
+    broadcast + checksum from diverged weights, the overlapped bucket all-reduce fired from the weight-gradient side stream, 1/world in
+    Adam.  After two steps both ranks hold bit-identical parameters, and they equal the single-process update on the whole batch
+    (mean losses over equal shards): f32 to the reordering of f32 atomics, bf16 to its rounding."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "dp2.json"
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dp2_gloo_gpu.py"), str(out), dtype_name],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.load(open(out))
+    print(res)
+    assert res["same_params_across_ranks"]
+    # per-rank mean losses differ from the full-batch mean (different pairs); their average is the full-batch loss of the FIRST step
+    assert res["grad_cos"] > (0.9999 if dtype_name == "f32" else 0.99)
+    assert res["grad_rel"] < (2e-3 if dtype_name == "f32" else 0.15)
+    assert res["w_maxabs"] <= 4.2e-4  # two Adam steps of lr = 1e-4: at most +-lr per step on sign-unstable elements
