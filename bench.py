@@ -304,14 +304,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FALNET_DIST_BACKEND=gloo (tests): the N > 1 path of this script on a box with fewer GPUs than ranks -- ranks then share devices
+    # (RCCL itself refuses two ranks on one device and stays the backend of every real run)
+    backend = os.environ.get("FALNET_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from fal_net_amd import loss_functions as LF
     from fal_net_amd import ops, synthetic, train

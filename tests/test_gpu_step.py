@@ -531,3 +531,27 @@ def test_data_parallel_two_ranks_one_gpu(dtype_name, tmp_path):
     assert res["grad_cos"] > (0.9999 if dtype_name == "f32" else 0.99)
     assert res["grad_rel"] < (2e-3 if dtype_name == "f32" else 0.15)
     assert res["w_maxabs"] <= 4.2e-4  # two Adam steps of lr = 1e-4: at most +-lr per step on sign-unstable elements
+
+
+def test_bench_two_ranks_reports_allreduce():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on the one GPU of a test box over gloo
+    (FALNET_DIST_BACKEND): the line must carry n_gpus = 2, the whole-job rate, and the `allreduce` block -- both ranks seen, parameters still
+    identical across ranks after the timed steps, isolated times per bucket, the step time without the collective and the exposed part."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, FALNET_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "128",
+           "--no-cpu-baseline", "--no-roofline", "--dtype", "f32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    a = d["allreduce"]
+    assert a["ranks_seen"] == 2 and a["param_checksum_equal"] is True and a["bytes"] > 60e6 and len(a["buckets_bytes"]) == 4
+    assert sum(a["buckets_bytes"]) == a["bytes"]
+    assert a["isolated_ms"]["whole_buffer"] > 0 and a["ms_per_step_without_collective"] > 0 and np.isfinite(a["exposed_ms"])
+    assert abs(d["value"] - 2 * 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # whole-job pairs/s = world * batch / step time
