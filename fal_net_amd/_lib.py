@@ -49,7 +49,8 @@ class Conv(C.Structure):
                 ("addend", C.c_void_p), ("act", C.c_int32), ("actout", C.c_void_p),
                 ("actout_kind", C.c_int32), ("dtype", C.c_int32), ("ksplit", C.c_int32), ("splitk_ws", C.c_void_p),
                 ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32), ("pool_out", C.c_void_p),
-                ("pool_mode", C.c_int32), ("pool_actout_kind", C.c_int32), ("pool_actout", C.c_void_p)]
+                ("pool_mode", C.c_int32), ("pool_actout_kind", C.c_int32), ("pool_actout", C.c_void_p), ("weight_up2", C.c_void_p),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
 
 
 class Wgrad(C.Structure):
@@ -71,6 +72,11 @@ class PackDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32),
                 ("taps", C.c_int32), ("c0_real", C.c_int32), ("c0_pad", C.c_int32), ("cin_pad", C.c_int32),
                 ("cout_pad", C.c_int32), ("block_begin", C.c_int32)]
+
+
+class PackUp2Desc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wu", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
+                ("block_begin", C.c_int32)]
 
 
 class BiasGradDesc(C.Structure):
@@ -97,6 +103,7 @@ SIGNATURES = {
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
     "falnet_pack_weights_batched": [_P, _I, _I, _I, _P],
+    "falnet_pack_up2_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_blocks": [_I, _I, _I],
     "falnet_bias_grad_batched": [_P, _I, _I, _I, _P],

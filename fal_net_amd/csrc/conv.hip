@@ -2614,6 +2614,42 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
     else pack_tile<T, 1>(d, rel, tile);
 }
 
+// Sub-pixel weights of the deconv layers (conv_dma.hip: conv3x3_up2_dma_kernel): wu[co][pair][ci], pair = 4 (2 py + px) + 2 a + b
+template <typename T>
+__global__ __launch_bounds__(256) void pack_up2_batched_kernel(const falnet_pack_up2_t* __restrict__ descs, int n) {
+    __shared__ int entry_begin[64];
+    const int li = find_entry(descs, n, entry_begin);
+    const falnet_pack_up2_t d = descs[li];
+    const int rel = blockIdx.x - d.block_begin;
+    const int ncb = d.cin_pad / 32;
+    const int co0 = (rel / ncb) * 32, ci0 = (rel % ncb) * 32;
+    T* wu = reinterpret_cast<T*>(d.wu);
+    for (int e = threadIdx.x; e < 32 * 16 * 32; e += blockDim.x) {
+        const int ci = ci0 + (e & 31), pair = (e >> 5) & 15, co = co0 + (e >> 9);
+        float v = 0.f;
+        if (co < d.cout && ci < d.cin) {
+            const int cls = pair >> 2, a = (pair >> 1) & 1, b = pair & 1, py = cls >> 1, px = cls & 1;
+            // 3x3 taps that coincide on low-resolution neighbour a (rows) / b (columns) for output parity py / px
+            const int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+            const int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+            const float* w = d.w + ((int64_t)co * d.cin + ci) * 9;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) v += w[ky * 3 + kx];
+        }
+        wu[((int64_t)co * 16 + pair) * d.cin_pad + ci] = from_f32<T>(v);
+    }
+}
+
+extern "C" int falnet_pack_up2_batched(const falnet_pack_up2_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_up2_batched: bad argument");
+    FALNET_CHECK_ARG(dtype == FALNET_BF16 || dtype == FALNET_F16, "pack_up2_batched: 16-bit operand types only");
+#define PACKU_L(T) hipLaunchKernelGGL(pack_up2_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
+    FALNET_DISPATCH_16(dtype, PACKU_L);
+#undef PACKU_L
+    FALNET_RETURN_LAUNCH();
+}
+
 extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0, "pack_weights_batched: bad argument (taps must be 9, 3 or 1, n <= 64)");
@@ -2721,6 +2757,11 @@ static int g_patch_kcb = [] { const char* e = falnet_ab_env("FALNET_PATCH_KCB");
 
 bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh);        // conv_dma.hip
 int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool small_tile);
+bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // deconv forward in sub-pixel form (variant 18)
+int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
+bool falnet_conv_deep_applicable(const falnet_conv_t& p);                   // maps of <= 128 positions: one-shot LDS-DMA, K slices, last-arriver epilogue (variant 19)
+int falnet_conv_deep_launch(const falnet_conv_t& p, hipStream_t st);
+int falnet_conv_deep_mtiles(const falnet_conv_t& p);
 bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n);         // four parity classes of a stride-2 data gradient in one pass
 int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st);
 bool falnet_conv_s2f_dma_applicable(const falnet_conv_t& p);                // forward 3x3 stride-2
@@ -2762,7 +2803,19 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19, "conv2d: unknown variant %d", variant);
+    if (variant == 19) {  // levels 5-6: K-sliced one-shot LDS-DMA kernel with the epilogue in the last slice (conv_dma.hip: conv3x3_deep_kernel)
+        if (!falnet_conv_deep_applicable(p)) {
+            falnet_set_error("conv2d: variant 19 needs a 16-bit nine-tap stride-1/2 launch on maps of at most 128 positions (128 %% (TH TW) == 0), dense NHWC output, "
+                             "w_rows %% 64 == 0, ksplit = cin_total / 32 or / 64 (a multiple of 4), scratch for the partial tiles and the split-K workspace");
+            return -2;
+        }
+        c.flip = 0;
+        c.swap = 0;
+        c.patch = 6;
+        c.bn = 64; c.kcb = p.ksplit * 32 == p.cin_total ? 1 : 2; c.tps = 9; c.adb = 1; c.th = 0; c.nwaves = falnet_conv_deep_mtiles(p);
+        return 0;
+    }
     if (variant == 15) {  // LDS-DMA forward 3x3 stride-2 (conv_dma.hip)
         if (!falnet_conv_s2f_dma_applicable(p)) {
             falnet_set_error("conv2d: variant 15 needs a canonical 16-bit 3x3 stride-2 pad-1 NHWC launch (>= 8 x 32 outputs) with sources at the input size");
@@ -2772,6 +2825,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.swap = 0;
         c.patch = 4;
         c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
+        return 0;
+    }
+    if (variant == 18) {  // deconv forward in sub-pixel form (conv_dma.hip: conv3x3_up2_dma_kernel)
+        if (!(dense3x3 && flip == 0 && !p.addend && !p.actout && falnet_conv_up2_dma_applicable(p))) {
+            falnet_set_error("conv2d: variant 18 needs a 16-bit dense 3x3 forward launch over ONE source at exactly half the launch size, weight_up2 set, no residual / activation-gradient operand");
+            return -2;
+        }
+        c.flip = 0;
+        c.swap = 0;
+        c.patch = 5;
+        c.bn = 32; c.kcb = 64; c.tps = 16; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
     if (variant == 13 || variant == 17) {  // LDS-DMA, double-buffered, persistent: 16x32 (13) or 4x32 (17) positions x 64 channels per workgroup (conv_dma.hip)
@@ -2858,7 +2922,11 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 4)
+    if (c.patch == 6)
+        snprintf(buf, len, "_Z19conv3x3_deep_kernelI%sLi%dELi%dEEv13falnet_conv_t18falnet_deep_geom_t", t, c.kcb, c.nwaves);
+    else if (c.patch == 5)
+        snprintf(buf, len, "_Z22conv3x3_up2_dma_kernelI%sEv13falnet_conv_tiiiii", t);
+    else if (c.patch == 4)
         snprintf(buf, len, "_Z22conv3x3_s2f_dma_kernelI%sLi%dEEv13falnet_conv_tiii", t, c.bn);
     else if (c.patch == 3)
         snprintf(buf, len, "_Z18conv3x3_dma_kernelI%sLi%dELi%dEEv13falnet_conv_tiiii", t, c.th, c.nwaves);
@@ -2897,13 +2965,15 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     FALNET_CHECK_ARG((int64_t)p.B * p.OH * p.OW * (p.out_layout == FALNET_OUT_PLANAR_F32 ? p.Cout : 1) < (1ll << 31), "conv2d: output too large for 32-bit pixel index");
     const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
     FALNET_CHECK_ARG(!planar || (!p.addend && !p.actout), "conv2d: planar output supports bias/act epilogue only");
-    if (p.ksplit > 1 && falnet_deterministic()) {
+    if (p.ksplit > 1 && p.variant != 19 && falnet_deterministic()) {  // (variant 19 sums its K slices in a fixed order)
         falnet_set_error("conv2d: split-K (f32 atomics) is not available in deterministic mode");
         return -2;
     }
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 6) return falnet_conv_deep_launch(p, st);
+    if (c.patch == 5) return falnet_conv_up2_dma_launch(p, st);
     if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
     if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st, c.th == 4);
     if (c.patch == 2) {

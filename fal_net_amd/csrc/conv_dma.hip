@@ -578,6 +578,548 @@ int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
 }
 
 // ============================================================================================================================
+// `deconv` forward (models/FAL_netB.py:52-58: F.interpolate(scale_factor=2, nearest) -> 3x3 conv) in SUB-PIXEL form (variant 18).
+//
+// A 3x3 convolution over a 2x nearest-upsampled map U(Y, X) = L(Y >> 1, X >> 1) reads, for output pixel (2i + py, 2j + px), only a 2 x 2
+// neighbourhood of the low-resolution map L: rows i + py - 1 + a, columns j + px - 1 + b (a, b in {0, 1}), because two of the three taps of a
+// row always fall on the same low-resolution pixel.  With the weights of coinciding taps summed,
+//     Weff[py][a] = { py = 0: (W[0], W[1] + W[2]);  py = 1: (W[0] + W[1], W[2]) }   (rows; columns alike),
+// the layer is four 2x2 convolutions of L, one per output parity class: 16 tap-MACs per output quad instead of 36 -- the same values (the
+// sums are formed in f32 before the weights are rounded to the compute type), 2.25x fewer MFMAs, and the upsampled map is never addressed.
+// Structure: the four-class stride-2 data-gradient kernel above.  A workgroup owns 16 x 32 LOW-resolution positions (= 32 x 64 outputs) x 32
+// output channels; per 32-channel chunk the (16+2) x (32+2) patch of L and the sixteen 32 x 32 (class, tap) weight tiles arrive by LDS-DMA
+// (double buffer, one barrier per chunk, persistent); four accumulator sets (class x 2 rows); bias / activation epilogue per class on the
+// interleaved output positions.  Weights: packed [CoutPad][16][CinTot] by falnet_pack_up2_batched, pair index = 4 class + 2 a + b.
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles, int GH, int GW) {
+    constexpr int TH = 16, NWAVES = 8, BN = 32, MT = 2, NPAIR = 16;
+    constexpr int KCV = 32;
+    constexpr int NPIX = (TH + 2) * CD_PW;
+    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = NPAIR * BN / 16, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    const falnet_src_t& S = p.src[0];
+    const int nchunks = S.C / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l4 = lane >> 2, segpos = lane & 3;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight_up2);
+    const T* const sptr = reinterpret_cast<const T*>(S.ptr);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    // weight piece wid = wave + NWAVES k is rows (wid & 1) 16 + l4 of (class, tap) pair wid >> 1 = (wave >> 1) + 4 k: one lane offset, uniform step
+    int64_t w_off0;
+    {
+        const int pair = wave >> 1, co = n0 + ((wave & 1) << 4) + l4;
+        const int gseg = segpos ^ ((lane >> 4) & 3);
+        w_off0 = co < p.w_rows ? (int64_t)(co * NPAIR + pair) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    const int w_step = (n0 + 32 <= p.w_rows) ? (NWAVES / 2) * p.cin_total : 0;  // (a partial last row block reads the zero page for every k)
+    static_assert(B_PIECES == KW * NWAVES, "weight pieces divide over the waves");
+    int64_t a_off[KP];
+    int64_t sbat = 0;
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile) {
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        sbat = (int64_t)b * S.sb;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int pix = 16 * (wave + NWAVES * k) + l4;
+            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
+            const bool ok = pix < NPIX && vy >= 0 && vy < GH && vx >= 0 && vx < GW;
+            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8) : (int64_t)(zero_t - (sptr + sbat));
+        }
+    };
+    struct Cur { int tile, c; };
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile);
+        }
+    };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {  // one piece per MFMA step (see conv3x3_dma_kernel)
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            if (id < A_PIECES) cd_glds16(sptr + sbat + q.c * KCV + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            cd_glds16(wptr + q.c * KCV + w_off0 + (i - KP) * w_step, dst0 + A_BYTES + wid * 1024);
+        }
+    };
+    auto issue = [&](const Cur& q, int buf) {
+#pragma unroll
+        for (int i = 0; i < KP + KW; ++i) issue_piece(q, buf, i);
+    };
+    // fragment read addresses: patch row (2 wave + rs), rs = mt + dy + 1 in 0..3; patch column r + dx + 1, dx + 1 in 0..2
+    int a_addr[4][3];
+#pragma unroll
+    for (int rs = 0; rs < 4; ++rs)
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int pp = (wave * MT + rs) * CD_PW + dxi + r;
+            a_addr[rs][dxi] = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
+        }
+    int b_lane[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_lane[ks] = A_BYTES + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4);
+
+    f32x16 acc[4][MT][1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[c][mt][0][j] = 0.f;
+    Cur qi = {(int)blockIdx.x, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile);
+        issue(qi, 0);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = it + 1 < total;
+        const char* const Bf = lds;
+        int (&aa)[4][3] = a_addr;  // the addresses already point into buffer it & 1 (toggled in place below: twelve registers less than a copy)
+        int (&bb)[2] = b_lane;
+        s16x8_t fa[2][MT], fb[2];
+        auto load_step = [&](int st, int set) {
+            const int pr_ = st >> 1, ks = st & 1;
+            const int cls = pr_ >> 2, a = (pr_ >> 1) & 1, b2 = pr_ & 1;
+            const int dyi = (cls >> 1) + a, dxi = (cls & 1) + b2;  // (py - 1 + a) + 1, (px - 1 + b) + 1
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const s16x8_t*>(Bf + (aa[mt + dyi][dxi] ^ (ks << 5)));
+            fb[set] = *reinterpret_cast<const s16x8_t*>(Bf + bb[ks] + (pr_ * BN) * 64);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int st = 0; st < 2 * NPAIR; ++st) {
+            if (st + 1 < 2 * NPAIR) load_step(st + 1, (st + 1) & 1);
+            if (st < KP + KW && more) issue_piece(qi, (it + 1) & 1, st);
+            const int cls = st >> 3;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[cls][mt][0] = H16<T>::mma(fb[st & 1], fa[st & 1][mt], acc[cls][mt][0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);
+        }
+        if (more) advance(qi);
+        {
+            const int d = (it & 1) ? -BUF : BUF;
+#pragma unroll
+            for (int rs = 0; rs < 4; ++rs)
+#pragma unroll
+                for (int dxi = 0; dxi < 3; ++dxi) a_addr[rs][dxi] += d;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b_lane[ks] += d;
+        }
+        if (++cc == nchunks) {
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            float bias[1][16];
+            load_bias16<1>(p, n0, h, bias);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int py = c >> 1, px = c & 1;
+                const int x = 2 * (tx0 + r) + px;
+                auto pixoff = [&](int mt) -> int64_t {
+                    const int y = 2 * (ty0 + wave * MT + mt) + py;
+                    if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                    return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                };
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[c], bias, n0, lane, pixoff);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[c][mt][0][j] = 0.f;
+            }
+        }
+    }
+}
+
+// variant 18: a dense 3x3 stride-1 forward launch whose ONE source is the launch size halved exactly (2x nearest upsampling), 16-bit, with
+// sub-pixel weights (falnet_conv_t::weight_up2)
+bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (!p.weight_up2 || p.nsrc != 1 || p.w_taps != 9 || p.out_layout != FALNET_OUT_NHWC || p.pool_out || p.ksplit > 1 || !p.out) return false;
+    const falnet_src_t& S = p.src[0];
+    if (S.C % 32 || S.C <= 0 || S.C != p.cin_total) return false;
+    if (2 * S.H != p.IH || 2 * S.W != p.IW || p.OH != p.IH || p.OW != p.IW || S.H < 4 || S.W < 32) return false;
+    if ((int64_t)S.H * S.sy >= (1ll << 31) || (int64_t)p.w_rows * 16 * p.cin_total >= (1ll << 31) || (p.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;
+    return true;
+}
+
+int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st) {
+    const int GH = p.src[0].H, GW = p.src[0].W;  // the low-resolution grid
+    const int tiles_x = (GW + 31) / 32, tiles_y = (GH + 15) / 16;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 31) / 32;
+    int gx = 256 / ny;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+    if (p.dtype == FALNET_F16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+    FALNET_RETURN_LAUNCH();
+}
+
+// ============================================================================================================================
+// The deepest levels (models/FAL_netB.py:107-119,130-137: conv5, conv5_1, conv6, conv6_1, deconv6, iconv6 and their data gradients at
+// 256 x 512 input: 8 x 16 and 4 x 8 maps, 512 channels) -- variant 19.
+//
+// These layers are 0.6-5 GFLOP with 2.4-7 MB of weights and at most 1024 output positions in the whole batch: no tiling of M x N fills 256
+// CUs, and the gather kernel's answer (split-K over blockIdx.z, one exposed global -> register -> LDS round trip per 32-channel K step,
+// atomics, a second launch for the epilogue) spends 24-31 us on 18 dependent memory round trips per workgroup.  A launch this small is a
+// LATENCY chain, not a throughput problem; this kernel keeps the chain at one memory round trip per stage:
+//   * a workgroup owns 128 or 256 output positions (whole images: 8 x 16 maps, or 4 x 8 maps four to the M tile) x 64 output channels x ONE
+//     K slice of 32 or 64 input channels over all nine taps.  Everything it will ever read -- the halo patch of its images for that slice and
+//     the nine 64-row weight tiles, 50-150 KB -- is requested by LDS-DMA up front, no buffer is reused.  SIXTEEN waves issue the pieces (a
+//     wave issues one 1-KiB piece per ~100 ns: four waves needed 2 us for 90 pieces), the first four or eight then run the MFMAs, the
+//     others leave at the barrier;
+//   * the K slices of a tile add their f32 partial sums into the all-zero split-K workspace (row = position, 32 consecutive channels per
+//     atomic instruction), and the slice that arrives LAST at the tile's counter applies the epilogue (bias / residual / activation /
+//     activation gradient; its operands were fetched at the start, behind the DMA), writes the NHWC output and returns workspace and
+//     counter to zero with the same atomic exchanges that read the sums: no second launch, no fence;
+//   * stride-2 forward launches (conv5, conv6) use the same kernel with a (2 TH + 1) x (2 TW + 1) patch per image; a source at half the
+//     launch size is read through the nearest-upsample map (deconv6).
+// Phase times of one workgroup (tools/deep_stamps.py, 512 -> 512 channels at 8 x 16): see DESIGN.md section 4.
+typedef unsigned deep_v4u __attribute__((ext_vector_type(4)));
+struct falnet_deep_geom_t {
+    int imgs, mtiles;        // images per M tile (MTILES x 32 positions), M tiles in the batch
+    int PH, PW;              // halo patch of one image
+    unsigned m_ppi, m_pw;    // floor(2^32 / d) + 1 for d = PH * PW and PW: x / d = umulhi(x, m) for x < 2^16
+    int a_pieces;            // 1-KiB pieces of one 32-channel patch plane
+};
+
+template <typename T, int NPL, int MTILES>
+__global__ __launch_bounds__(1024) void conv3x3_deep_kernel(const falnet_conv_t p, const falnet_deep_geom_t g) {
+    constexpr int BN = 64, NT = 2, NW = 16, BM = 32 * MTILES, ITEMS = BM * (BN / 8) / 1024;  // 8-channel epilogue items per thread: 1 or 2
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FALNET_DEEP_STAMPS  // profiling build (tools/deep_stamps.py): s_memrealtime (100 MHz) at the phase boundaries of every workgroup -> p.pool_actout
+    unsigned long long* const stamp_out = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.pool_actout)) + (size_t)blockIdx.x * 8;
+#define DEEP_STAMP(k) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (threadIdx.x == 0) stamp_out[k] = t_; } while (0)
+#else
+#define DEEP_STAMP(k) do { } while (0)
+#endif
+    DEEP_STAMP(0);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int nblocks = p.w_rows / BN, ksplits = p.ksplit;
+    // blockIdx.x = 8 q + x: tile (q / ksplits) 8 + x, K slice q % ksplits: all slices of a tile, and with tile = mtile * nblocks + nblock one
+    // or two channel blocks of weights, on ONE XCD (blockIdx.x % 8)
+    const int ntiles = g.mtiles * nblocks;
+    const int xq = blockIdx.x >> 3;
+    const int tile = (xq / ksplits) * 8 + (blockIdx.x & 7), ks_ = xq % ksplits;
+    if (tile >= ntiles) return;
+    const int mt = tile / nblocks, nb = tile - mt * nblocks;
+    const int n0 = nb * BN;
+    constexpr int KC = 32 * NPL;
+    const int cglob = ks_ * KC;  // first channel of the slice in the concatenated K axis
+    const int C0 = p.src[0].C;
+    const bool second = p.nsrc > 1 && cglob >= C0;
+    const T* const sp = reinterpret_cast<const T*>(second ? p.src[1].ptr : p.src[0].ptr);
+    const int64_t Ssb = second ? p.src[1].sb : p.src[0].sb, Ssy = second ? p.src[1].sy : p.src[0].sy, Ssx = second ? p.src[1].sx : p.src[0].sx;
+    const int SH = second ? p.src[1].H : p.src[0].H, SW = second ? p.src[1].W : p.src[0].W;
+    const int cloc = cglob - (second ? C0 : 0);
+    const int hs = SH != p.IH ? 1 : 0, wsft = SW != p.IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+    const int ppi = g.PH * g.PW, npix = g.imgs * ppi;
+    const int A_PLANE = g.a_pieces * 1024, W_BASE = NPL * A_PLANE;
+    const T* const zero_t = reinterpret_cast<const T*>(g_cd_zero);
+    const int l4 = lane >> 2, segpos = lane & 3;
+
+    // ---- every byte this workgroup reads, requested now by all sixteen waves ----
+    for (int a = wave; a < g.a_pieces; a += NW) {
+        const int pix = 16 * a + l4;
+        const int pi = (int)__umulhi((unsigned)pix, g.m_ppi);
+        const int rem = pix - pi * ppi;
+        const int pr = (int)__umulhi((unsigned)rem, g.m_pw);
+        const int pc = rem - pr * g.PW;
+        const int vy = pr - 1, vx = pc - 1, b = mt * g.imgs + pi;
+        const bool ok = pix < npix && b < p.B && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW;
+        const T* src = ok ? sp + (int64_t)b * Ssb + (int64_t)(vy >> hs) * Ssy + (int64_t)(vx >> wsft) * Ssx + cloc + (segpos ^ ((pix >> 2) & 3)) * 8 : zero_t;
+        const int step = ok ? 32 : 0;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) cd_glds16(src + pl * step, lds_base + pl * A_PLANE + a * 1024);
+    }
+    {
+        // weight piece id = (tap * NPL + plane) * 4 + quarter: rows 16 quarter + l4 of that 64-row tile; wave w takes ids w, w + 16, ...
+        const int gseg = segpos ^ ((l4 >> 2) & 3);
+        const T* const wbase = reinterpret_cast<const T*>(p.weight) + (int64_t)(n0 + l4) * p.w_taps * p.cin_total + cglob + gseg * 8;
+        const int64_t qstride = (int64_t)16 * p.w_taps * p.cin_total;
+        for (int id = wave; id < 9 * NPL * 4; id += NW) {
+            const int quarter = id & 3, tp = id >> 2, t = tp / NPL, pl = tp - t * NPL;
+            cd_glds16(wbase + quarter * qstride + (int64_t)p.tap_w[t] * p.cin_total + pl * 32, lds_base + W_BASE + id * 1024);
+        }
+    }
+    DEEP_STAMP(1);
+    const int hw = p.TH * p.TW;
+    const int64_t M = (int64_t)p.B * hw;
+    // epilogue operands of this thread's 8-channel items (needed only by the tile's last slice; fetched here, behind the DMA, because a
+    // dependent load after the counter is another exposed round trip)
+    const T* addend = reinterpret_cast<const T*>(p.addend);
+    const T* actout = reinterpret_cast<const T*>(p.actout);
+    uint4 e_add[ITEMS] = {}, e_act[ITEMS] = {};
+    float e_bias[8] = {};
+    int e_off[ITEMS];  // element offsets in the output (the dispatcher bounds the output at 2^31 elements)
+    {
+        const int n = n0 + (tid & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            e_off[it] = -1;
+            const int64_t m = (int64_t)mt * BM + ((tid + it * 1024) >> 3);
+            if (m >= M || n >= p.Cout) continue;
+            const int b = (int)(m / hw), qr = (int)(m - (int64_t)b * hw);
+            const int ty = qr / p.TW, tx = qr - ty * p.TW;
+            e_off[it] = ((b * p.OH + ty) * p.OW + tx) * p.out_cstride + n;
+            if (addend) e_add[it] = *reinterpret_cast<const uint4*>(addend + e_off[it]);
+            if (actout) e_act[it] = *reinterpret_cast<const uint4*>(actout + e_off[it]);
+        }
+        if (p.bias && n < p.Cout) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e_bias[k] = p.bias[n + k];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the whole LDS image is in place
+    DEEP_STAMP(2);
+
+    // partial tiles: scratch[slice][position][w_rows] f32
+    const __amdgpu_buffer_rsrc_t slab_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.scratch, 0, (int)p.scratch_bytes, 0x00020000);
+    const int w_rows = p.w_rows;
+    const int64_t slab_stride = (int64_t)g.mtiles * BM * w_rows;
+    if (wave < MTILES) {
+        // ---- fragment addresses: lane r of wave w holds position 32 w + r of the tile (operand B), weight row 32 nt + r (operand A) ----
+        int pp0;
+        {
+            const int q = 32 * wave + r;
+            const int qi = q / hw, qr = q - qi * hw;
+            const int ty = qr / p.TW, tx = qr - ty * p.TW;
+            pp0 = qi * ppi + ty * p.isy * g.PW + tx * p.isx;  // patch pixel under tap (-1, -1)
+        }
+        int b_addr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_addr[nt] = W_BASE + (32 * nt + r) * 64 + ((h ^ ((r >> 2) & 3)) << 4);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[nt][j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pp = pp0 + (p.tap_dy[t] + 1) * g.PW + p.tap_dx[t] + 1;
+            const int a_addr = pp * 64 + ((h ^ ((pp >> 2) & 3)) << 4);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const s16x8_t fa = *reinterpret_cast<const s16x8_t*>(lds + pl * A_PLANE + (a_addr ^ (ks << 5)));
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const s16x8_t fb = *reinterpret_cast<const s16x8_t*>(lds + (b_addr[nt] ^ (ks << 5)) + (t * NPL + pl) * (BN * 64));
+                        acc[nt] = H16<T>::mma(fb, fa, acc[nt]);  // D rows = output channels, D columns (lanes) = positions
+                    }
+                }
+        }
+        DEEP_STAMP(3);
+        // ---- this slice's partial tile -> scratch: the position on the lane, channels 8 (j >> 2) + 4 h + (j & 3) in its accumulators: 16-B
+        // agent-coherent stores (sc1: written through to the point of coherence, no L2 write-back / invalidate as a fence would need; 8-B
+        // stores cost 2.7x per byte) ----
+        const int64_t m = (int64_t)mt * BM + 32 * wave + r;
+        if (m < M) {
+            const unsigned row = (unsigned)(((int64_t)ks_ * slab_stride + m * w_rows + n0 + 4 * h) * 4);  // byte offset (scratch <= 2^31 bytes: dispatcher)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jg = 0; jg < 4; ++jg) {
+                    deep_v4u v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[nt][4 * jg + e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, slab_rsrc, row + (32 * nt + 8 * jg) * 4, 0, 16);  // aux 16 = sc1
+                }
+        }
+        DEEP_STAMP(4);
+    }
+    // ---- the last slice to arrive finishes the tile ----
+    // No release / acquire fence here: an agent-scope fence on gfx950 writes back and invalidates the XCD's whole L2 (buffer_wbl2 / buffer_inv
+    // sc1), per workgroup -- measured 99-146 us per launch instead of 20.  The protocol needs none: the partial tiles are written and read
+    // with agent-coherent accesses (sc1), a wave's stores are acknowledged when its s_waitcnt vmcnt(0) returns, and the counter increment
+    // follows the barrier that follows every wave's wait.  (First version: f32 atomics into the zeroed split-K workspace -- 4.2 M atomic lanes
+    // per 512-channel layer saturate the L2 atomic units: 8 us to acknowledge them, another 10 us for counter and read-back behind them.)
+    unsigned* const counter = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.splitk_ws) + p.splitk_ws_bytes) - 4096 + tile;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DEEP_STAMP(5);
+    __builtin_amdgcn_s_barrier();  // (also: every wave is past its last fragment read, the LDS image is dead)
+    volatile __attribute__((address_space(3))) int* const flag = reinterpret_cast<volatile __attribute__((address_space(3))) int*>((cd_lptr_t)lds);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = old + 1 == (unsigned)ksplits;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    DEEP_STAMP(6);
+    if (!flag[0]) return;
+    T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        if (e_off[it] < 0) continue;
+        const int i = tid + it * 1024;
+        const int64_t m = (int64_t)mt * BM + (i >> 3);
+        const unsigned src = (unsigned)((m * w_rows + n0 + (i & 7) * 8) * 4), sstep = (unsigned)(slab_stride * 4);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0.f;
+        for (int ks = 0; ks < ksplits; ks += 4) {  // slices in order: the sum does not depend on which slice finishes (ksplits % 4 == 0: dispatcher)
+            deep_v4u x[4][2];                        // eight 16-B agent-coherent loads in flight
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) x[q][k] = __builtin_amdgcn_raw_buffer_load_b128(slab_rsrc, src + (ks + q) * sstep + k * 16, 0, 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += __uint_as_float(x[q][k >> 2][k & 3]);
+        }
+        if (addend) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] += H16<T>::lo((&e_add[it].x)[k]);
+                v[2 * k + 1] += H16<T>::hi((&e_add[it].x)[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = apply_act(v[k] + e_bias[k], p.act);
+        if (actout) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] *= act_grad_from_out(H16<T>::lo((&e_act[it].x)[k]), p.actout_kind);
+                v[2 * k + 1] *= act_grad_from_out(H16<T>::hi((&e_act[it].x)[k]), p.actout_kind);
+            }
+        }
+        uint4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) (&o.x)[k] = pack16x2<T>(v[2 * k], v[2 * k + 1]);
+        *reinterpret_cast<uint4*>(out + e_off[it]) = o;
+    }
+    DEEP_STAMP(7);
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#undef DEEP_STAMP
+
+// geometry of a variant-19 launch; MTILES = 8 (256 positions per workgroup) when the 128-position form would need more than one round of
+// workgroups on the 256 CUs and the image fits
+static bool deep_geometry(const falnet_conv_t& p, falnet_deep_geom_t& g, int& npl, int& mtiles_wg, size_t& lds_bytes) {
+    const int hw = p.TH * p.TW;
+    if (hw <= 0 || hw > 128 || 128 % hw) return false;
+    if (p.ksplit * 32 == p.cin_total) npl = 1;
+    else if (p.ksplit * 64 == p.cin_total) npl = 2;
+    else return false;
+    g.PH = (p.TH - 1) * p.isy + 3;
+    g.PW = (p.TW - 1) * p.isx + 3;
+    const int ppi = g.PH * g.PW;
+    g.m_ppi = (unsigned)((1ull << 32) / (unsigned)ppi) + 1u;
+    g.m_pw = (unsigned)((1ull << 32) / (unsigned)g.PW) + 1u;
+    for (mtiles_wg = 8; mtiles_wg >= 4; mtiles_wg -= 4) {
+        g.imgs = 32 * mtiles_wg / hw;
+        g.mtiles = (p.B + g.imgs - 1) / g.imgs;
+        g.a_pieces = (g.imgs * ppi + 15) / 16;
+        lds_bytes = (size_t)npl * g.a_pieces * 1024 + (size_t)9 * npl * 4096;
+        const bool fits = lds_bytes <= 160 * 1024 && g.a_pieces * 16 < 65536;
+        if (mtiles_wg == 4) return fits;
+        const int wgs4 = (p.B * hw + 127) / 128 * (p.w_rows / 64) * p.ksplit;
+        if (fits && wgs4 > 256) return true;
+    }
+    return false;
+}
+
+// variant 19: canonical nine-tap launch on a map of at most 128 positions whose images tile 128 exactly, stride 1 or 2, dense NHWC output,
+// ksplit = cin_total / 32 or cin_total / 64 K slices (a multiple of 4), scratch for the partial tiles, the split-K workspace (all-zero between
+// launches) for the tile counters in its last 16 KiB
+bool falnet_conv_deep_applicable(const falnet_conv_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.ntaps != 9 || p.nsrc < 1 || p.nsrc > 2 || p.out_layout != FALNET_OUT_NHWC || p.pool_out || !p.out || !p.splitk_ws || !p.scratch) return false;
+    if (p.ksplit < 4 || p.ksplit % 4 || p.splitk_ws_bytes < 16384 || p.splitk_ws_bytes % 4) return false;
+    if (p.isy != p.isx || (p.isy != 1 && p.isy != 2) || p.osy != 1 || p.osx != 1 || p.ooy || p.oox) return false;
+    if (p.OH != p.TH || p.OW != p.TW || p.IH != p.TH * p.isy || p.IW != p.TW * p.isx) return false;
+    if (p.w_rows % 64 || p.Cout % 8 || p.Cout > p.w_rows || (int64_t)p.B * p.OH * p.OW * p.out_cstride >= (1ll << 31)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dy[t] < -1 || p.tap_dy[t] > 1 || p.tap_dx[t] < -1 || p.tap_dx[t] > 1 || p.tap_w[t] < 0 || p.tap_w[t] >= p.w_taps) return false;
+    falnet_deep_geom_t g;
+    int npl, mtw;
+    size_t lds_bytes;
+    if (!deep_geometry(p, g, npl, mtw, lds_bytes)) return false;
+    int csum = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const falnet_src_t& S = p.src[s];
+        if (S.C <= 0 || S.C % (32 * npl)) return false;
+        if (!((S.H == p.IH && S.W == p.IW) || (2 * S.H == p.IH && 2 * S.W == p.IW))) return false;
+        csum += S.C;
+    }
+    if (csum != p.cin_total || (p.cin_total + 64) * 2 > CD_ZERO_BYTES) return false;
+    if (g.mtiles * (p.w_rows / 64) > 4096) return false;  // tile counters: the last 16 KiB of the split-K workspace
+    const int64_t need = (int64_t)p.ksplit * g.mtiles * 32 * mtw * p.w_rows * 4;
+    return need <= p.scratch_bytes && p.scratch_bytes < (1ll << 31);
+}
+
+template <typename T, int NPL, int MTILES>
+static void deep_launch(const falnet_conv_t& p, const falnet_deep_geom_t& g, size_t lds_bytes, dim3 grid, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_deep_kernel<T, NPL, MTILES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_deep_kernel<T, NPL, MTILES>), grid, dim3(1024), lds_bytes, st, p, g);
+}
+
+int falnet_conv_deep_mtiles(const falnet_conv_t& p) {  // 4 or 8: the instantiation falnet_conv_deep_launch uses (kernel-name query)
+    falnet_deep_geom_t g;
+    int npl, mtw = 4;
+    size_t lds_bytes;
+    deep_geometry(p, g, npl, mtw, lds_bytes);
+    return mtw;
+}
+
+int falnet_conv_deep_launch(const falnet_conv_t& p, hipStream_t st) {
+    falnet_deep_geom_t g;
+    int npl, mtw;
+    size_t lds_bytes;
+    deep_geometry(p, g, npl, mtw, lds_bytes);
+    const int ntiles = g.mtiles * (p.w_rows / 64);
+    const dim3 grid((unsigned)((ntiles + 7) / 8 * 8 * p.ksplit));
+#define DEEP_L(T) do {                                                          \
+        if (npl == 1 && mtw == 4) deep_launch<T, 1, 4>(p, g, lds_bytes, grid, st);      \
+        else if (npl == 1) deep_launch<T, 1, 8>(p, g, lds_bytes, grid, st);             \
+        else if (mtw == 4) deep_launch<T, 2, 4>(p, g, lds_bytes, grid, st);             \
+        else deep_launch<T, 2, 8>(p, g, lds_bytes, grid, st);                           \
+    } while (0)
+    FALNET_DISPATCH_16(p.dtype, DEEP_L);
+#undef DEEP_L
+    FALNET_RETURN_LAUNCH();
+}
+
+// ============================================================================================================================
 // Forward 3x3 / stride-2 / pad-1 convolution (models/FAL_netB.py:101-111 conv1..conv4), 16-bit operands, LDS-DMA double buffer.
 //
 // A stride-2 output tile reads (2 TH + 1) x 65 input pixels for TH x 32 outputs -- four times the footprint of a stride-1 tile -- so

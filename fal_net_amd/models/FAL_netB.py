@@ -155,7 +155,8 @@ class FalnetPlan:
         self.fwd.append(self._conv_call(self.dtype, srcs, IH, IW, pc.wf, pc.cin_pad, ops.fwd_taps(pc.ksize), pc.taps,
                                       pc.cout_pad, pc.stride, B, OH, OW, out, OH, OW, out.shape[3], out.shape[3],
                                       bias=pc.bias, addend=addend, act=act, name="fwd " + name,
-                                      flops=2 * B * OH * OW * pc.cout * pc.cin * pc.taps))
+                                      flops=2 * B * OH * OW * pc.cout * pc.cin * pc.taps,
+                                      weight_up2=pc.wu if (len(srcs) == 1 and 2 * srcs[0].H == IH and 2 * srcs[0].W == IW) else None))
 
     def _dgrad(self, pc, group, gout, gin, IH, IW, addend=None, actout=None, name="", sum2x2_into=None, sum2x2_actout=None):
         """Append launches computing gin = dgrad_group(gout) [+ addend] [* elu'(actout)].
@@ -300,9 +301,17 @@ class FalnetPlan:
                                            n1, k3, w1_2d.shape[1], 0, name="compose logits weights")
             self.pack.append(compose_call)  # before the re-pack below: the composed f32 master changes with every update
         packed_now = [pc for k, pc in pcs.items() if not (compose and k in ("iconv1", "conv0_1x1"))]
+        for k, pc in pcs.items():
+            # sub-pixel weights for the nearest-upsample + 3x3 layers whose low-resolution map is at least 32 x 64 (falnet_conv2d variant 18;
+            # below that the 4 x 32-tile kernel wins and the per-step repack would be wasted): deconv<l> reads level l, H >> l
+            pc.up2 = (k.startswith("deconv") and k[6:].isdigit() and (H >> int(k[6:])) >= 32 and (W >> int(k[6:])) >= 64
+                      and L.ab("FALNET_UP2", "1") == "1")
         for pc in packed_now:
             pc.alloc(dt, dev)
         self.pack.append(ops.pack_all_call(packed_now, dt, dev))
+        up2 = ops.pack_up2_call(packed_now, dt, dev)
+        if up2 is not None:
+            self.pack.append(up2)
         self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)

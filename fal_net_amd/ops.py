@@ -45,12 +45,12 @@ _PKG_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_
 _CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", _PKG_CACHE)
 _CACHE_WRITABLE = ("FALNET_AUTOTUNE_CACHE" in os.environ and _CACHE_PATH != "0") or os.environ.get("FALNET_AUTOTUNE_CACHE_WRITE") == "1"
 _GATES = {"FALNET_NO_DMA": "0", "FALNET_WS2": "1", "FALNET_S2F_DMA": "1", "FALNET_S2D_DMA": "1", "FALNET_S2_SPLITK": "1",
-          "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_SMALL_TILE_DMA": "1"}
+          "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_SMALL_TILE_DMA": "1", "FALNET_UP2": "1", "FALNET_DEEP": "1"}
 if os.environ.get("FALNET_AB") == "1" and any(os.environ.get(k, v) != v for k, v in _GATES.items()):
     _CACHE_PATH = "0"
 _CACHE = None
 _CACHE_DIRTY = False
-_TUNE_SOURCES = ("conv.hip", "conv_dma.hip", "conv_epilogue.h", "common.h", "deep.hip")  # what a cached conv choice depends on
+_TUNE_SOURCES = ("conv.hip", "conv_dma.hip", "conv_epilogue.h", "common.h")  # what a cached conv choice depends on
 
 
 def cache_meta():
@@ -121,7 +121,8 @@ def conv_signature(d):
     taps = ",".join(f"{d.tap_dy[t]}:{d.tap_dx[t]}:{d.tap_w[t]}" for t in range(d.ntaps))
     flags = f"{int(bool(d.bias))}{int(bool(d.addend))}{d.act}{int(bool(d.actout))}{d.actout_kind}{int(bool(d.pool_out))}{d.pool_mode}{int(bool(d.pool_actout))}{int(bool(d.out))}"
     return (f"conv|t{d.dtype}|{srcs}|{d.IH}x{d.IW}|k{d.cin_total}|{taps}|w{d.w_taps}x{d.w_rows}|s{d.isy}|B{d.B}|{d.TH}x{d.TW}|"
-            f"o{d.osy},{d.ooy},{d.oox}|{d.OH}x{d.OW}|c{d.Cout},{d.out_cstride},{d.out_layout}|f{flags}|ws{int(d.splitk_ws_bytes > 0)}")
+            f"o{d.osy},{d.ooy},{d.oox}|{d.OH}x{d.OW}|c{d.Cout},{d.out_cstride},{d.out_layout}|f{flags}|ws{int(d.splitk_ws_bytes > 0)}"
+            + ("|up2" if d.weight_up2 else ""))
 
 
 def _timed(tag, flops, nbytes, launch, name=""):
@@ -195,6 +196,8 @@ class PackedConv:
         self.cin_pad = sum(self.groups_pad)
         self.cout_pad = pad_c(self.cout)
         self.wf = self.wd = None
+        self.wu = None      # sub-pixel weights [cout_pad][16][cin_pad] of a `deconv` layer (set `up2 = True` before alloc): falnet_conv2d variant 18
+        self.up2 = False
         self._packed_version = None
         self._dtype = None
 
@@ -202,6 +205,7 @@ class PackedConv:
         if self.wf is None or self._dtype != dtype or self.wf.device != device:
             self.wf = torch.zeros(self.cout_pad, self.taps, self.cin_pad, dtype=dtype, device=device)
             self.wd = torch.zeros(self.cin_pad, self.taps, self.cout_pad, dtype=dtype, device=device)
+            self.wu = torch.zeros(self.cout_pad, 16, self.cin_pad, dtype=dtype, device=device) if (self.up2 and dtype in H16 and self.taps == 9) else None
             self._dtype = dtype
             self._packed_version = None
 
@@ -266,6 +270,26 @@ def pack_all_call(pcs, dtype, device):
     return _timed("pack_weights_batched", 0, 0, launch, "pack_weights_batched")
 
 
+def pack_up2_call(pcs, dtype, device):
+    """ONE launch that rebuilds the sub-pixel weights (PackedConv.wu) of every `deconv` layer from its f32 OIHW master weight."""
+    lib = L.lib()
+    pcs = [pc for pc in pcs if pc.wu is not None]
+    if not pcs:
+        return None
+    descs = (L.PackUp2Desc * len(pcs))()
+    blk = 0
+    for i, pc in enumerate(pcs):
+        d = descs[i]
+        d.w, d.wu, d.cout, d.cin, d.cin_pad, d.cout_pad, d.block_begin = pc.weight.data_ptr(), pc.wu.data_ptr(), pc.cout, pc.cin, pc.cin_pad, pc.cout_pad, blk
+        blk += (pc.cout_pad // 32) * (pc.cin_pad // 32)
+    dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+    n, total, code = len(pcs), blk, L.dtype_code(dtype)
+
+    def launch(_keep=(dev, pcs)):
+        L.check(lib.falnet_pack_up2_batched(L.ptr(dev), n, total, code, L.stream_ptr()), "pack_up2_batched")
+    return _timed("pack_up2_batched", 0, 0, launch, "pack_up2_batched")
+
+
 def fwd_taps(ksize):
     """(dy, dx, packed-weight tap index) of a 'same'-padded kernel: 1, 3 (3x3) or (kh, kw) for the 3x1 / 1x3 convs."""
     if ksize == 1:
@@ -302,7 +326,7 @@ def _fill_taps(d, taps):
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
               act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
-              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE):
+              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE, weight_up2=None):
     """Build one falnet_conv2d launch; returns a zero-argument callable.  `pool_out`: fused 2x2 max pool of the output
     (halo-patch kernels only; `out` may then be None when only the pooled map is needed)."""
     lib = L.lib()
@@ -321,6 +345,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.pool_out = 0 if pool_out is None else pool_out.data_ptr()
     d.pool_mode, d.pool_actout_kind = pool_mode, pool_actout_kind
     d.pool_actout = 0 if pool_actout is None else pool_actout.data_ptr()
+    d.weight_up2 = 0 if weight_up2 is None else weight_up2.data_ptr()
     dev_t = out if out is not None else pool_out
     d.bias = 0 if bias is None else bias.data_ptr()
     d.addend = 0 if addend is None else addend.data_ptr()
@@ -333,14 +358,18 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     ws = _splitk_workspace(dev_t.device, ws_owner) if dev_t.is_cuda and out_layout == L.OUT_NHWC and pool_out is None else None
     d.splitk_ws = 0 if ws is None else ws.data_ptr()
     d.splitk_ws_bytes = 0 if ws is None else ws.numel() * 4
+    scratch = None
+    if ws is not None and dtype in H16 and TH * TW <= 128 and len(taps) == 9:  # the deepest levels: variant 19's partial tiles
+        scratch = _deep_scratch(dev_t.device, ws_owner)
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel() * 4
     ref = C.byref(d)
-    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout)
+    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout, weight_up2, scratch)
     if AUTOTUNE and autotune and dev_t.is_cuda:
         key = conv_signature(d)
         hit = cache_get(key)
         if hit is not None:
             d.variant, d.ksplit = int(hit[0]), int(hit[1])
-            if DETERMINISTIC and d.ksplit > 1:
+            if DETERMINISTIC and d.ksplit > 1 and d.variant != 19:  # (variant 19 sums its K slices in a fixed order)
                 d.variant, d.ksplit = 1, 1  # the cached choice was the gather kernel with split-K: same kernel, one K pass
             if lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:  # stale entry (kernel table changed): re-tune
                 hit = None
@@ -372,6 +401,15 @@ def _splitk_workspace(device, owner=None, nbytes=32 << 20):
     key = (device.type, device.index, owner)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)  # zero on entry by contract; launches leave it zero
+    return _SPLITK_WS[key]
+
+
+def _deep_scratch(device, owner=None, nbytes=32 << 20):
+    """Uninitialised scratch for the K-slice partial tiles of falnet_conv2d variant 19 (falnet_conv_t::scratch); one per (device, owner) like
+    the split-K workspace: launches that share it are stream-ordered."""
+    key = (device.type, device.index, owner, "deep")
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
     return _SPLITK_WS[key]
 
 
@@ -466,12 +504,17 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
         cands += [(16, 1)]  # two-phase weight-stationary
     if L.ab("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
+        if d.weight_up2:
+            cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < 1024 and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":
             cands += [(17, 1)]  # LDS-DMA on 4x32 tiles: the small maps of levels 3-4
         if d.isy == 2 and L.ab("FALNET_S2F_DMA", "1") == "1":
             cands += [(15, 1)]  # LDS-DMA forward 3x3 stride-2
     if wgs < 512:
         cands += [(8, 1), (9, 1)]
+    if d.TH * d.TW <= 128 and d.ntaps == 9 and L.ab("FALNET_DEEP", "1") == "1":
+        # levels 5-6: K-sliced one-shot LDS-DMA kernel (variant 19; its ksplit is the number of 32- or 64-channel K slices)
+        cands += [(19, d.cin_total // kc) for kc in (32, 64) if d.cin_total % (4 * kc) == 0]
     best, best_t = (1, 1), None
     for v, k in cands:
         d.variant, d.ksplit = v, k

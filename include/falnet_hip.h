@@ -118,9 +118,15 @@ typedef struct {
                                   13 LDS-DMA double-buffered persistent kernel (16-bit operands, 16x32 positions x 64 channels per
                                   workgroup, sources at the launch size or exactly half of it);
                                   15 forward 3x3 stride-2 by LDS-DMA (parity-de-interleaved patch, 16-channel chunks);
+                                  18 = `deconv` forward in sub-pixel form (one source at exactly half the launch size, weight_up2 set): four 2x2
+                                  convolutions of the low-resolution map, 16 instead of 36 tap-MACs per output quad (conv_dma.hip);
                                   17 = 13 on 4x32-position tiles with four waves (one row each): small maps (levels 4-6) get 4x the workgroups;
                                   16 = 10 with two groups of four waves half a period apart (one in its MFMAs while the other stores,
                                   loads and runs the epilogue), half-height tiles;
+                                  19 = the deepest levels (maps of at most 128 positions, 128 % (TH TW) == 0; stride 1 or 2; nine taps; 16-bit):
+                                  one-shot LDS-DMA of a 32- or 64-channel K slice per workgroup, `ksplit` = cin_total / 32 or / 64 slices,
+                                  f32 partial tiles in `scratch`, summed IN SLICE ORDER (deterministic) with the epilogue by the slice that
+                                  arrives last at the tile's counter (the last 16 KiB of splitk_ws) -- one launch (conv_dma.hip);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,
@@ -132,6 +138,13 @@ typedef struct {
     int32_t pool_mode;
     int32_t pool_actout_kind;  /* FALNET_ACT_* of pool_actout */
     const void* pool_actout;   /* NHWC like pool_out, or NULL */
+    const void* weight_up2;    /* variant 18 only, else NULL: sub-pixel weights [CoutPad][16][CinTot] in `dtype` of a 3x3 convolution over a 2x
+                                  nearest-upsampled source (falnet_pack_up2_batched): pair 4 (2 py + px) + 2 a + b holds the sum of the 3x3
+                                  taps that fall on low-resolution neighbour (a, b) for output parity (py, px) */
+    void* scratch;             /* variant 19 only, else NULL: uninitialised device scratch for the K-slice partial tiles,
+                                  ksplit * ceil(B TH TW / 128 | 256) * 128 | 256 * w_rows f32; contents are meaningless between launches;
+                                  launches that share it must be stream-ordered */
+    int64_t scratch_bytes;
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
 /* First layer: 3x3 / stride 1 / pad 1 convolution of a 3-channel planar f32 image (FAL_netB.py:99 conv0, VGG19 features[0];
@@ -218,6 +231,14 @@ typedef struct {
     int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps 9, 3 or 1 */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
+/* Sub-pixel weights of the `deconv` layers (falnet_conv_t::weight_up2; FAL_netB.py:52-58), all layers in one launch: entry i sums the f32 OIHW
+ * 3x3 master weights w into wu [cout_pad][16][cin_pad] (`dtype`; pair index 4 (2 py + px) + 2 a + b, rows / columns: py = 0 -> (W[0], W[1] + W[2]),
+ * py = 1 -> (W[0] + W[1], W[2])); an entry uses (cout_pad / 32) * (cin_pad / 32) blocks from block_begin. */
+typedef struct {
+    const float* w; void* wu;
+    int32_t cout, cin, cin_pad, cout_pad, block_begin;
+} falnet_pack_up2_t;
+int falnet_pack_up2_batched(const falnet_pack_up2_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 /* accumulate == 0: entries with groups == 1 OVERWRITE their gradient (plain stores), entries with groups > 1 add into it
  * (atomics: the caller zeroes those); accumulate != 0: every entry adds */
 int falnet_wgrad_reduce_batched(const falnet_reduce_t* descs_dev, int n, int total_blocks, int accumulate, void* stream);

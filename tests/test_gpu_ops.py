@@ -318,6 +318,152 @@ def test_conv_fused_upsample(dtype):
         assert rel(to_nchw(out, 32), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cin,cout,h,w,act,with_bias", [
+    (2, 64, 64, 16, 32, "elu", False),    # one tile exactly
+    (1, 128, 64, 24, 80, "elu", True),    # ragged tiles both ways, two row blocks of low-res tiles
+    (3, 256, 128, 5, 33, "none", True),   # minimum-ish heights, a single ragged column, 4 channel blocks, 8 chunks
+    (2, 96, 49, 9, 40, "elu", True),      # Cout not a multiple of 32 (zero rows of the packed weights), 3 chunks
+])
+def test_conv_subpixel_deconv_forward(B, cin, cout, h, w, act, with_bias, dtype):
+    """falnet_conv2d variant 18 (conv3x3_up2_dma_kernel + falnet_pack_up2_batched): the `deconv` forward (FAL_netB.py:52-58, nearest x2 then
+    3x3 conv) as four 2x2 convolutions of the low-resolution map with summed weights, against F.conv2d of the upsampled map AND against
+    the ordinary kernel (variant 13 / 1) on the same operands; the automatic choice must be able to run it."""
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + h)
+    x = torch.randn(B, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (0.5 / (cin ** 0.5))
+    bias = torch.randn(cout, generator=g) * 0.3 if with_bias else None
+    xr = x.to(dtype).float()  # what the kernels see
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wt, bias, padding=1)
+    ref = F.elu(ref) if act == "elu" else ref
+    wp = torch.nn.Parameter(wt.to(DEV))
+    bp = None if bias is None else torch.nn.Parameter(bias.to(DEV))
+    pc = ops.PackedConv("deconvT", wp, bp, [cin], 1)
+    bias_t = None
+    if bias is not None:  # the launches below run over the padded channel count: the bias vector is padded alike (zeros)
+        bias_t = torch.zeros(ops.pad_c(cout), device=DEV)
+        bias_t[:cout] = bias.to(DEV)
+    pc.up2 = True
+    pc.alloc(dtype, torch.device(DEV))
+    assert pc.wu is not None and tuple(pc.wu.shape) == (pc.cout_pad, 16, pc.cin_pad)
+    pc.pack_call()()
+    ops.pack_up2_call([pc], dtype, torch.device(DEV))()
+    # the packed sub-pixel weights: pair = 4 (2 py + px) + 2 a + b, row / column taps of coinciding source pixels summed in f32
+    rows = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    wu_ref = torch.zeros(pc.cout_pad, 16, pc.cin_pad)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    acc = sum(wt[:, :, ky, kx] for ky in rows[(py, a)] for kx in rows[(px, b)])
+                    wu_ref[:cout, 4 * (2 * py + px) + 2 * a + b, :cin] = acc
+    assert torch.equal(pc.wu.float().cpu(), wu_ref.to(dtype).float())
+    src = to_nhwc(x, dtype)
+    H, W = 2 * h, 2 * w
+    outs = {}
+    ops.AUTOTUNE = False
+    base = 13 if (H >= 16 and W >= 32) else 1  # the ordinary LDS-DMA kernel where it applies (>= 16 rows), else the gather kernel
+    for variant in (base, 18):
+        out = torch.full((B, H, W, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+        call = ops.conv_call(dtype, [ops.nhwc_src(src)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W,
+                             out, H, W, pc.cout_pad, pc.cout_pad, bias=bias_t, act=L.ACT_ELU if act == "elu" else L.ACT_NONE, weight_up2=pc.wu)
+        call.desc.variant = variant
+        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+        assert rc == 0, (variant, L.lib().falnet_last_error())
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all(), variant  # every output position and padded channel written
+        assert float(out[..., cout:].float().abs().max() if pc.cout_pad > cout else 0.0) == 0.0
+        outs[variant] = to_nchw(out, cout)
+        assert rel(outs[variant], ref) < TOL[dtype], variant
+    # the two kernels round differently summed weights: same tolerance class, not bit-equal
+    assert rel(outs[18], outs[base]) < 2 * TOL[dtype]
+    # without the sub-pixel weights the variant is refused, not silently replaced
+    call = ops.conv_call(dtype, [ops.nhwc_src(src)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W,
+                         out, H, W, pc.cout_pad, pc.cout_pad, bias=bias_t)
+    call.desc.variant = 18
+    assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) != 0
+
+
+DEEP_CASES = [  # B, groups, Cout, H, W (input), stride, upsampled first source, bias, act, residual, activation-gradient operand
+    (8, [512], 512, 8, 16, 1, False, True, L.ACT_ELU, False, False),    # conv5_1.conv1 at the bench size: one image per tile
+    (8, [512], 512, 4, 8, 1, False, True, L.ACT_NONE, True, True),      # conv6_1.conv2: four images per tile, residual + activation gradient
+    (3, [128], 64, 4, 8, 1, False, False, L.ACT_ELU, False, False),     # a partly filled tile (three of four images)
+    (5, [256, 512], 256, 8, 16, 1, False, True, L.ACT_ELU, False, False),  # iconv6: two sources, K slices never straddle them
+    (2, [512], 256, 8, 16, 1, True, True, L.ACT_ELU, False, False),     # deconv6: source at half size through the nearest-upsample map
+    (8, [256], 512, 16, 32, 2, False, True, L.ACT_ELU, False, False),   # conv5: stride 2, 17 x 33 patch per image
+    (6, [512], 512, 8, 16, 2, False, True, L.ACT_ELU, False, False),    # conv6: stride 2, four images per tile, ragged batch
+    (2, [128], 49, 8, 8, 1, False, True, L.ACT_NONE, False, False),     # 64 positions per image, Cout below the 64-row block
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", DEEP_CASES)
+def test_conv_deep_levels_kernel(case, dtype):
+    """falnet_conv2d variant 19 (conv3x3_deep_kernel: maps of at most 128 positions, one-shot LDS-DMA, K-slice partial tiles in scratch, ordered
+    sum + epilogue in the last slice to arrive) for both slice widths against F.conv2d on the rounded operands and against the gather kernel;
+    the split-K workspace (tile counters) must be all-zero again afterwards, and a second launch must give the SAME BITS (the slices are
+    summed in a fixed order, whichever finishes last)."""
+    B, groups, Cout, H, W, stride, ups, with_bias, act, res, actg = case
+    g = torch.Generator().manual_seed(B * 100 + Cout + H + stride)
+    cin = sum(groups)
+    xs = [torch.randn(B, c, (H // 2 if (ups and i == 0) else H), (W // 2 if (ups and i == 0) else W), generator=g) for i, c in enumerate(groups)]
+    w = torch.randn(Cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if with_bias else None
+    OH, OW = H // stride, W // stride
+    addend = torch.randn(B, Cout, OH, OW, generator=g) if res else None
+    yact = torch.randn(B, Cout, OH, OW, generator=g) if actg else None
+    full = [F.interpolate(x, scale_factor=2, mode="nearest") if (ups and i == 0) else x for i, x in enumerate(xs)]
+    ref = F.conv2d(torch.cat([x.to(dtype).float() for x in full], 1), w.to(dtype).float(), b, stride=stride, padding=1)
+    if res:
+        ref = ref + addend.to(dtype).float()
+    ref = F.elu(ref) if act == L.ACT_ELU else ref
+    if actg:  # ELU'(x) from the stored output y: clamp(y + 1, 0, 1) (conv_epilogue.h: act_grad_from_out)
+        ya = yact.to(dtype).float()
+        ref = ref * torch.clamp(ya + 1, 0, 1)
+    pc = packed(w, b, groups, stride, dtype)
+    srcs_t = [to_nhwc(x, dtype) for x in xs]
+    bias_t = None
+    if b is not None:
+        bias_t = torch.zeros(pc.cout_pad, device=DEV)
+        bias_t[:Cout] = pc.bias.data
+    add_t = to_nhwc(addend, dtype) if res else None
+    act_t = to_nhwc(yact, dtype) if actg else None
+    out = torch.empty(B, OH, OW, pc.cout_pad, dtype=dtype, device=DEV)
+    ops.AUTOTUNE = False
+    call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), pc.taps, pc.cout_pad, stride, B, OH, OW,
+                         out, OH, OW, pc.cout_pad, pc.cout_pad, bias=bias_t, addend=add_t, act=act, actout=act_t, actout_kind=L.ACT_ELU if actg else L.ACT_NONE,
+                         ws_owner=("test-deep", 0))
+    ws = ops._splitk_workspace(torch.device(DEV, torch.cuda.current_device()), ("test-deep", 0))
+    assert call.desc.splitk_ws == ws.data_ptr()
+    outs = {}
+    for variant, ksplit in [(1, 1), (19, pc.cin_pad // 32), (19, pc.cin_pad // 64)]:
+        if variant == 19 and (ksplit == 0 or ksplit % 4 or any(gp % (pc.cin_pad // ksplit) for gp in pc.groups_pad)):
+            continue  # (slice counts are multiples of 4; a 64-channel slice must not straddle two sources)
+        call.desc.variant, call.desc.ksplit = variant, ksplit
+        for rep in range(2):
+            out.fill_(float("nan"))
+            rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+            assert rc == 0, (variant, ksplit, L.lib().falnet_last_error())
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all(), (variant, ksplit)
+            got = to_nchw(out, Cout)
+            assert rel(got, ref) < TOL[dtype], (variant, ksplit, rep)
+            assert float(ws.abs().max()) == 0.0, (variant, ksplit, "workspace / counters not returned to zero")
+            if variant == 19:
+                if rep == 1:
+                    assert torch.equal(out, first), (ksplit, "run-to-run difference")
+                first = out.clone()
+        if pc.cout_pad > Cout:
+            assert float(out[..., Cout:].float().abs().max()) == 0.0
+        outs[(variant, ksplit)] = got
+    assert any(v == 19 for v, _ in outs), "variant 19 did not run"
+    for key, got in outs.items():
+        assert rel(got, outs[(1, 1)]) < TOL[dtype], key
+    # refused where it does not apply: a map the tile does not divide, and deterministic-mode semantics are covered by tests/_deterministic.py
+    call.desc.variant, call.desc.ksplit = 19, 3
+    assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) == -2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES[:7] + CONV_CASES[8:] + PATCH_CASES[:5] + PATCH_CASES[7:])
 def test_conv_backward(case, dtype):

@@ -25,8 +25,14 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
     ("iconv5 128+256->256 @16x32", [128, 256], 256, 16, 32, None),
     ("deconv4 256->128 @32x64 (up)", [256], 128, 32, 64, (16, 32)),
+    ("conv5_1 512->512 @8x16", [512], 512, 8, 16, None),
+    ("conv6_1 512->512 @4x8", [512], 512, 4, 8, None),
+    ("iconv6 256+512->256 @8x16", [256, 512], 256, 8, 16, None),
+    ("deconv6 512->256 @8x16 (up)", [512], 256, 8, 16, (4, 8)),
+    ("deconv3 256->128 @64x128 (up)", [256], 128, 64, 128, (32, 64)),
+    ("deconv2 128->64 @128x256 (up)", [128], 64, 128, 256, (64, 128)),
 ]
-VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dma4", 17), ("gather", 1)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dma4", 17), ("up2", 18), ("gather", 1), ("g8", 108), ("g16", 116), ("deep32", 1932), ("deep64", 1964)]
 if os.environ.get("BENCH_VARIANTS"):  # e.g. BENCH_VARIANTS=dma,ws
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["BENCH_VARIANTS"].split(",")]
 if os.environ.get("BENCH_LAYERS"):  # substring filter, comma separated
@@ -37,8 +43,11 @@ for name, groups, cout, H, W, up in LAYERS:
     cin = sum(groups)
     w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=DEV) * 0.05)
     pc = ops.PackedConv("t", w, None, groups, 1)
+    pc.up2 = up is not None and (2 * up[0], 2 * up[1]) == (H, W)
     pc.alloc(dtype, torch.device(DEV))
     pc.pack_call()()
+    if pc.wu is not None:
+        ops.pack_up2_call([pc], dtype, torch.device(DEV))()
     srcs_t = []
     for g in groups:
         h, ww = up if up else (H, W)
@@ -47,13 +56,17 @@ for name, groups, cout, H, W, up in LAYERS:
     ops.AUTOTUNE = False
     pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV) if os.environ.get('BENCH_POOL') else None  # BENCH_POOL=1: only the 2x2-pooled map is stored
     call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
-                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled, act={'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')])
+                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled, act={'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')], weight_up2=pc.wu)
     flops = 2.0 * B * H * W * cout * cin * 9
     times = {v: [] for v, _ in VARIANTS}
     ref = None
     for rnd in range(6):
         for v, var in VARIANTS:
-            call.desc.variant = var
+            call.desc.variant, call.desc.ksplit = var, 1
+            if var in (108, 116):  # gather with split-K 8 / 16
+                call.desc.variant, call.desc.ksplit = 1, var - 100
+            elif var in (1932, 1964):  # K-sliced one-shot kernel, 32- / 64-channel slices
+                call.desc.variant, call.desc.ksplit = 19, pc.cin_pad // (var - 1900)
             if lib.falnet_conv2d(call.ref, L.stream_ptr()) != 0:
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
