@@ -130,6 +130,8 @@ class FalnetPlan:
         self.generation = 0
         self.use_side_stream = True
         self._side = self._side_stream = None
+        self._side_pending, self._side_events, self._side_ev_next = [], [], 0
+        self._side_batch = max(1, int(L.ab("FALNET_SIDE_BATCH", "2")))
         self.buf = {}
         self.fwd, self.bwd_head, self.bwd_body, self.pack = [], [], [], []
         self._build()
@@ -266,23 +268,36 @@ class FalnetPlan:
     def _side_call(self, call):
         """Weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill the
         CUs that the small (latency-bound) dgrad launches leave idle.  Ordering: the side stream waits for the producer
-        of the launch's inputs (event on the main stream); run_backward joins the side stream at the end."""
-        ev = torch.cuda.Event()
-
-        def run(c=call, ev=ev):
-            side = self._side_stream
-            if side is None:
+        of the launch's inputs (event on the main stream); run_backward joins the side stream at the end.
+        An event record between two kernels of the main stream costs a ~6 us bubble there (rocprofv3 timeline), so side launches
+        are handed over in groups of `_side_batch`: one record / wait pair per group, taken behind the group's LAST producer."""
+        def run(c=call):
+            if self._side_stream is None:
                 c()
                 return
-            ev.record()
-            side.wait_event(ev)
+            self._side_pending.append(c)
+            if len(self._side_pending) >= self._side_batch or getattr(c, "needs_torch_stream", False):
+                self._flush_side()
+        self.bwd_body.append(run)
+
+    def _flush_side(self):
+        pend, side = self._side_pending, self._side_stream
+        if not pend:
+            return
+        if self._side_ev_next == len(self._side_events):
+            self._side_events.append(torch.cuda.Event())
+        ev = self._side_events[self._side_ev_next]
+        self._side_ev_next += 1
+        ev.record()
+        side.wait_event(ev)
+        for c in pend:
             if getattr(c, "needs_torch_stream", False):  # the bucket hook (torch.distributed collectives run on torch's current stream)
                 with torch.cuda.stream(side), L.on_stream(side):
                     c()
             else:
                 with L.on_stream(side):  # C-ABI launches name their stream: no torch stream switch needed
                     c()
-        self.bwd_body.append(run)
+        pend.clear()
 
     # ---- plan construction ----
     def _build(self):
@@ -432,6 +447,7 @@ class FalnetPlan:
                 if not self._c3_wgrad:
                     self._x0_convert()
                 self._x0_event.record()  # on the stream the conversion was launched on
+            x0_convert_and_mark.needs_torch_stream = True  # (the event is recorded on torch's current stream: make that the side stream)
             self._side_call(x0_convert_and_mark)
             if compose:
                 g_dlog = G0  # the composed conv's output gradient IS the head's gradient
@@ -612,10 +628,12 @@ class FalnetPlan:
             self._side_stream.wait_stream(main)  # the previous step's Adam / repack must not be overtaken
         else:
             self._side_stream = None
+        self._side_ev_next = 0
         with L.stream_scope():  # one stream lookup for the whole replay; side calls redirect their launches with L.on_stream
             self.head_bwd[(g_disp is not None, g_pan is not None)]()
             for call in self.bwd_body:
                 call()
+            self._flush_side()
         if self._side_stream is not None:
             main.wait_stream(self._side_stream)
         if getattr(self, "_deferred_ready", None) is not None:
