@@ -2756,7 +2756,7 @@ static int g_patch_kcb = [] { const char* e = falnet_ab_env("FALNET_PATCH_KCB");
 
 
 bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh);        // conv_dma.hip
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool small_tile);
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);
 bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // deconv forward in sub-pixel form (variant 18)
 int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
 bool falnet_conv_deep_applicable(const falnet_conv_t& p);                   // maps of <= 128 positions: one-shot LDS-DMA, K slices, last-arriver epilogue (variant 19)
@@ -2803,7 +2803,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20, "conv2d: unknown variant %d", variant);
     if (variant == 19) {  // levels 5-6: K-sliced one-shot LDS-DMA kernel with the epilogue in the last slice (conv_dma.hip: conv3x3_deep_kernel)
         if (!falnet_conv_deep_applicable(p)) {
             falnet_set_error("conv2d: variant 19 needs a 16-bit nine-tap stride-1/2 launch on maps of at most 128 positions (128 %% (TH TW) == 0), dense NHWC output, "
@@ -2838,16 +2838,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.bn = 32; c.kcb = 64; c.tps = 16; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
-    if (variant == 13 || variant == 17) {  // LDS-DMA, double-buffered, persistent: 16x32 (13) or 4x32 (17) positions x 64 channels per workgroup (conv_dma.hip)
-        if (!(dense3x3 && falnet_conv_dma_applicable(p, variant == 17 ? 4 : 16)) || (variant == 17 && p.pool_out)) {
+    if (variant == 13 || variant == 17 || variant == 20) {  // LDS-DMA, double-buffered, persistent: 16x32 (13), 4x32 (17) or 8x32 (20) positions x 64 channels per workgroup (conv_dma.hip)
+        const int th = variant == 17 ? 4 : (variant == 20 ? 8 : 16);
+        if (!(dense3x3 && falnet_conv_dma_applicable(p, th)) || (th != 16 && p.pool_out)) {
             falnet_set_error("conv2d: variant %d needs a 16-bit dense 3x3 stride-1 launch (>= %d x 32 positions%s) with sources at the launch size or half of it",
-                             variant, variant == 17 ? 4 : 16, variant == 17 ? ", no fused pool" : "");
+                             variant, th, th != 16 ? ", no fused pool" : "");
             return -2;
         }
         c.flip = flip;
         c.swap = 0;
         c.patch = 3;
-        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = variant == 17 ? 4 : 16; c.nwaves = variant == 17 ? 4 : 8;
+        c.bn = 64; c.kcb = 64; c.tps = 9; c.adb = 1; c.th = th; c.nwaves = th == 4 ? 4 : 8;
         return 0;
     }
     if (variant == 10 || variant == 16) {
@@ -2975,7 +2976,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     if (c.patch == 6) return falnet_conv_deep_launch(p, st);
     if (c.patch == 5) return falnet_conv_up2_dma_launch(p, st);
     if (c.patch == 4) return falnet_conv_s2f_dma_launch(p, st);
-    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st, c.th == 4);
+    if (c.patch == 3) return falnet_conv_dma_launch(p, c.flip, st, c.th);
     if (c.patch == 2) {
         const int ws_th = c.th;
         const int tiles_x = (p.OW + PT_TW - 1) / PT_TW, tiles_y = (p.OH + ws_th - 1) / ws_th;

@@ -304,35 +304,26 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh) {
     return true;
 }
 
-// small_tile: variant 17 -- 4 x 32 positions per workgroup, four waves of ONE row each (conv3x3_dma_kernel<T, 4, 4>): the 16 x 32-pixel maps of
-// encoder / decoder level 4 are a single 16-row tile per sample (32 workgroups at B = 8 for 256 channels), with four-row tiles 128.
-int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, bool small_tile) {
-    if (small_tile) {
-        const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 3) / 4;
-        const int ntiles = p.B * tiles_x * tiles_y;
-        const int ny = (p.Cout + 63) / 64;
-        int gx = 256 / ny;
-        if (gx < 1) gx = 1;
-        if (gx > ntiles) gx = ntiles;
-        const dim3 grid((unsigned)gx, (unsigned)ny);
-        if (p.dtype == FALNET_F16)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<f16_t, 4, 4>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<bf16_t, 4, 4>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-        FALNET_RETURN_LAUNCH();
-    }
-    constexpr int TH = 16;
+// th = 16: variant 13 (8 waves of two rows).  th = 4: variant 17 -- four waves of ONE row each: the 16 x 32-pixel maps of encoder / decoder
+// level 4 are a single 16-row tile per sample (32 workgroups at B = 8 for 256 channels), with four-row tiles 128.  th = 8: variant 20 -- eight
+// waves of one row each: the 32 x 64 maps of level 3 are 128 sixteen-row tiles x 4 channel blocks (two tiles per CU, half the CUs of the second
+// round idle) or 512 four-row tiles whose nine weight tiles (37 KB per 32-channel chunk) are staged for only 128 positions; eight-row tiles
+// are 256 x 4: every CU busy and 2x the positions per staged weight byte of the four-row form.
+template <typename T, int TH, int NWAVES>
+static void dma_launch_t(const falnet_conv_t& p, int flip, hipStream_t st) {
     const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + TH - 1) / TH;
     const int ntiles = p.B * tiles_x * tiles_y;
     const int ny = (p.Cout + 63) / 64;
-    int gx = 256 / ny;  // one persistent workgroup per CU (150 KB of LDS each)
+    int gx = 256 / ny;  // one persistent workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
-    const dim3 grid((unsigned)gx, (unsigned)ny);
-    if (p.dtype == FALNET_F16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<f16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<bf16_t, 16, 8>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma_kernel<T, TH, NWAVES>), dim3((unsigned)gx, (unsigned)ny), dim3(NWAVES * 64), 0, st, p, tiles_x, tiles_y, flip, ntiles);
+}
+
+int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th) {
+#define DMA_L(T) do { if (th == 4) dma_launch_t<T, 4, 4>(p, flip, st); else if (th == 8) dma_launch_t<T, 8, 8>(p, flip, st); else dma_launch_t<T, 16, 8>(p, flip, st); } while (0)
+    FALNET_DISPATCH_16(p.dtype, DMA_L);
+#undef DMA_L
     FALNET_RETURN_LAUNCH();
 }
 

@@ -45,7 +45,7 @@ _PKG_CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "autotune_
 _CACHE_PATH = os.environ.get("FALNET_AUTOTUNE_CACHE", _PKG_CACHE)
 _CACHE_WRITABLE = ("FALNET_AUTOTUNE_CACHE" in os.environ and _CACHE_PATH != "0") or os.environ.get("FALNET_AUTOTUNE_CACHE_WRITE") == "1"
 _GATES = {"FALNET_NO_DMA": "0", "FALNET_WS2": "1", "FALNET_S2F_DMA": "1", "FALNET_S2D_DMA": "1", "FALNET_S2_SPLITK": "1",
-          "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_SMALL_TILE_DMA": "1", "FALNET_UP2": "1", "FALNET_DEEP": "1"}
+          "FALNET_GATHER_NARROW": "0", "FALNET_S2_MULTI": None, "FALNET_SMALL_TILE_DMA": "1", "FALNET_UP2": "1", "FALNET_DEEP": "1", "FALNET_TILE8": "1"}
 if os.environ.get("FALNET_AB") == "1" and any(os.environ.get(k, v) != v for k, v in _GATES.items()):
     _CACHE_PATH = "0"
 _CACHE = None
@@ -507,7 +507,9 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < 1024 and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":
-            cands += [(17, 1)]  # LDS-DMA on 4x32 tiles: the small maps of levels 3-4
+            cands += [(17, 1)]  # LDS-DMA on 4x32 tiles: the 16x32 maps of level 4
+            if L.ab("FALNET_TILE8", "1") == "1":
+                cands += [(20, 1)]  # ... on 8x32 tiles: the 32x64 maps of level 3
         if d.isy == 2 and L.ab("FALNET_S2F_DMA", "1") == "1":
             cands += [(15, 1)]  # LDS-DMA forward 3x3 stride-2
     if wgs < 512:

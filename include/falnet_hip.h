@@ -121,6 +121,7 @@ typedef struct {
                                   18 = `deconv` forward in sub-pixel form (one source at exactly half the launch size, weight_up2 set): four 2x2
                                   convolutions of the low-resolution map, 16 instead of 36 tap-MACs per output quad (conv_dma.hip);
                                   17 = 13 on 4x32-position tiles with four waves (one row each): small maps (levels 4-6) get 4x the workgroups;
+                                  20 = 13 on 8x32-position tiles with eight waves (one row each): the 32x64 maps of level 3;
                                   16 = 10 with two groups of four waves half a period apart (one in its MFMAs while the other stores,
                                   loads and runs the epilogue), half-height tiles;
                                   19 = the deepest levels (maps of at most 128 positions, 128 % (TH TW) == 0; stride 1 or 2; nine taps; 16-bit):

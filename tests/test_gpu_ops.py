@@ -178,7 +178,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 14)) + [15, 16, 17]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17: LDS-DMA on 4x32 tiles
+    for variant in list(range(1, 14)) + [15, 16, 17, 20]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -194,6 +194,7 @@ def test_conv_every_kernel_variant(case, dtype):
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
     assert (13 in ran) == (dtype != torch.float32 and H >= 16)
     assert (17 in ran) == (dtype != torch.float32 and H >= 4 and W >= 32)
+    assert (20 in ran) == (dtype != torch.float32 and H >= 8 and W >= 32)
     assert (10 in ran) == (16 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
 
 
