@@ -1463,14 +1463,24 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
 #ifndef C3_OCC
 #define C3_OCC 2
 #endif
-#define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, next patch prefetched behind the epilogue
+#define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, ONE patch load for the whole 8 x 128 strip
 template <typename T, int NT>
 __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                                   const falnet_conv_t p, int groups_x, int tiles_y) {
-    constexpr int PH = PT_TH + 2, PW = PT_PW, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
+    // The (8+2) x (4*32+2) x 3 patch of the workgroup's four tiles is staged at once (16 loads per thread in flight, one barrier): the first
+    // version staged a tile at a time -- two barriers and an exposed global round trip per 8 x 32 tile, 3.8 us per tile for 0.5 us of work
+    // (2.2-2.9 TB/s of output against 5.2 TB/s for the same store shape alone, tools/ubench/store_pattern.hip).
+    constexpr int PH = PT_TH + 2, PW = C3_TPW * PT_TW + 2, NEL = 3 * PH * PW, SLOTS = (NEL + CONV_THREADS - 1) / CONV_THREADS;
     __shared__ __attribute__((aligned(16))) float patch[NEL];                       // [3][PH][PW] f32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+#ifdef C3_STAMPS
+    unsigned long long* const stamp_out = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.pool_actout)) + (size_t)blockIdx.x * 8;
+#define C3_STAMP(k) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (threadIdx.x == 0) stamp_out[k] = t_; } while (0)
+#else
+#define C3_STAMP(k) do { } while (0)
+#endif
+    C3_STAMP(0);
     int bid = blockIdx.x;
     const int gx = bid % groups_x;
     bid /= groups_x;
@@ -1478,29 +1488,21 @@ __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const 
     const int b = bid / tiles_y;
     const int ty0 = tiy * PT_TH;
     const int64_t HW = (int64_t)p.IH * p.IW;
-    // this thread's patch elements: (channel, row, column) are the same for every tile, only tx0 moves
-    int p_off[SLOTS], p_col[SLOTS];
+    const float* xb = x + (int64_t)b * 3 * HW;
+    const int tix0 = gx * C3_TPW, sx0 = tix0 * PT_TW;
+    // every global load of the workgroup is issued before the first is consumed: the strip's patch (16 per thread), then the B fragments
+    // straight from the f32 OIHW master weights (k = c*9 + tap is their flattening: lane (r, h) owns cout nt*32 + r and the k values its MFMA
+    // operand slot covers; 6.9 KB in all, L2-resident, but 32 uncoalesced loads per lane: 4.7 us when they started only after the patch
+    // had been stored), then the bias
+    float pv[SLOTS];
 #pragma unroll
     for (int u = 0; u < SLOTS; ++u) {
         const int i = tid + u * CONV_THREADS;
         const int c = i / (PH * PW), rem = i % (PH * PW), pr = rem / PW, pc = rem % PW;
-        const int vy = ty0 - 1 + pr;
-        p_col[u] = pc - 1;
-        p_off[u] = (i < NEL && vy >= 0 && vy < p.IH) ? (int)(c * HW + (int64_t)vy * p.IW) + pc - 1 : INT_MIN;  // (-1 is a valid offset)
+        const int vy = ty0 - 1 + pr, vx = sx0 - 1 + pc;
+        pv[u] = (i < NEL && vy >= 0 && vy < p.IH && vx >= 0 && vx < p.IW) ? xb[c * HW + (int64_t)vy * p.IW + vx] : 0.f;
     }
-    const float* xb = x + (int64_t)b * 3 * HW;
-    float pv[SLOTS];
-    auto patch_load = [&](int tx0) {
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const int vx = tx0 + p_col[u];
-            pv[u] = (p_off[u] != INT_MIN && vx >= 0 && vx < p.IW) ? xb[p_off[u] + tx0] : 0.f;
-        }
-    };
-    const int tix0 = gx * C3_TPW;
-    patch_load(tix0 * PT_TW);
-    // B fragments straight from the f32 OIHW master weights (k = c*9 + tap is their flattening): lane (r, h) owns
-    // cout nt*32 + r and the k values its MFMA operand slot covers; 6.9 KB in all, L2-resident
+    C3_STAMP(1);
     constexpr int KS = sizeof(T) == 2 ? 2 : 16, KJ = sizeof(T) == 2 ? 8 : 1;
     float wv[KS][NT][KJ];
 #pragma unroll
@@ -1512,6 +1514,13 @@ __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const 
                 const int co = nt * 32 + r, k = (ks * 2 + h) * KJ + j;
                 wv[ks][nt][j] = (co < p.Cout && k < 27) ? w_oihw[co * 27 + k] : 0.f;
             }
+    float bias[NT][16];
+    load_bias16<NT>(p, 0, h, bias);
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int i = tid + u * CONV_THREADS;
+        if (i < NEL) patch[i] = pv[u];
+    }
     s16x8_t bfr[sizeof(T) == 2 ? 2 : 1][NT];
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -1532,30 +1541,24 @@ __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const 
     };
     const int cstride = p.out_cstride;
     const int tiles_x = (p.OW + PT_TW - 1) / PT_TW;
-    float bias[NT][16];
-    load_bias16<NT>(p, 0, h, bias);
+    C3_STAMP(2);
+    __syncthreads();  // the strip's patch is in LDS
+    C3_STAMP(3);
     for (int tt = 0; tt < C3_TPW; ++tt) {
+        if (tt == 1) C3_STAMP(4);
         const int tix = tix0 + tt;
         if (tix >= tiles_x) break;  // workgroup-uniform
         const int tx0 = tix * PT_TW;
-        if (tt > 0) __syncthreads();  // every wave has read the previous patch
-#pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const int i = tid + u * CONV_THREADS;
-            if (i < NEL) patch[i] = pv[u];
-        }
-        __syncthreads();
-        if (tt + 1 < C3_TPW && tix + 1 < tiles_x) patch_load(tx0 + PT_TW);  // in flight behind the MFMAs and the epilogue
         // one output row (32 positions x 32 NT channels) at a time: accumulators + epilogue operands of ONE row in registers
         // (the whole 2-row tile at once needed 256 VGPRs + spills = 2 waves per SIMD for a kernel that only streams its output)
-#pragma unroll
+#pragma unroll 1
         for (int mt = 0; mt < MT; ++mt) {
             f32x16 acc[1][NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[0][nt][j] = 0.f;
-            const float* base = patch + (wave * MT + mt) * PW + r;
+            const float* base = patch + (wave * MT + mt) * PW + tt * PT_TW + r;
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -1579,7 +1582,11 @@ __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const 
             });
         }
     }
+    C3_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C3_STAMP(6);
 }
+#undef C3_STAMP
 
 // ------------------------------------------------------------------------------------------ wgrad
 // dW[co, tap, ci] = sum_p G[p, co] * In[nbr(p, tap), ci]: both operands are pixel-major (the contraction
@@ -2624,19 +2631,28 @@ __global__ __launch_bounds__(256) void pack_up2_batched_kernel(const falnet_pack
     const int ncb = d.cin_pad / 32;
     const int co0 = (rel / ncb) * 32, ci0 = (rel % ncb) * 32;
     T* wu = reinterpret_cast<T*>(d.wu);
-    for (int e = threadIdx.x; e < 32 * 16 * 32; e += blockDim.x) {
-        const int ci = ci0 + (e & 31), pair = (e >> 5) & 15, co = co0 + (e >> 9);
-        float v = 0.f;
-        if (co < d.cout && ci < d.cin) {
+    // one (co, ci) weight per thread and pass: its nine taps are loaded once and feed all sixteen (class, tap) sums (the first version looped over
+    // the 16384 outputs of the block with up to four dependent loads each: 40 us per step for three layers)
+    for (int e = threadIdx.x; e < 32 * 32; e += blockDim.x) {
+        const int ci = ci0 + (e & 31), co = co0 + (e >> 5);
+        float w[9];
+        const bool real = co < d.cout && ci < d.cin;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = real ? d.w[((int64_t)co * d.cin + ci) * 9 + t] : 0.f;
+#pragma unroll
+        for (int pair = 0; pair < 16; ++pair) {
             const int cls = pair >> 2, a = (pair >> 1) & 1, b = pair & 1, py = cls >> 1, px = cls & 1;
             // 3x3 taps that coincide on low-resolution neighbour a (rows) / b (columns) for output parity py / px
             const int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
             const int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
-            const float* w = d.w + ((int64_t)co * d.cin + ci) * 9;
-            for (int ky = ky0; ky <= ky1; ++ky)
-                for (int kx = kx0; kx <= kx1; ++kx) v += w[ky * 3 + kx];
+            float v = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    if (ky >= ky0 && ky <= ky1 && kx >= kx0 && kx <= kx1) v += w[ky * 3 + kx];
+            wu[((int64_t)co * 16 + pair) * d.cin_pad + ci] = from_f32<T>(v);
         }
-        wu[((int64_t)co * 16 + pair) * d.cin_pad + ci] = from_f32<T>(v);
     }
 }
 
@@ -3066,6 +3082,9 @@ extern "C" int falnet_conv3x3_c3(const float* x_nchw, const float* w_oihw, const
     p.out_cstride = Cout;
     p.bias = bias;
     p.act = act;
+#ifdef C3_STAMPS  // profiling build (tools/c3_stamps.py): where the kernel writes its phase stamps
+    if (const char* e = getenv("FALNET_C3_STAMP_PTR")) p.pool_actout = reinterpret_cast<const void*>(strtoull(e, nullptr, 10));
+#endif
     const int tiles_x = ((W + PT_TW - 1) / PT_TW + C3_TPW - 1) / C3_TPW /* groups of C3_TPW tiles */, tiles_y = (H + PT_TH - 1) / PT_TH;
     const dim3 grid((unsigned)(B * tiles_x * tiles_y));
     hipStream_t st = (hipStream_t)stream;
