@@ -106,9 +106,11 @@ typedef struct {
     const void* actout;        /* NHWC like out: multiply by d act / d pre computed from the activation output */
     int32_t actout_kind;       /* FALNET_ACT_ELU / RELU / NONE */
     int32_t dtype;
-    int32_t ksplit;            /* gather kernel only: > 1 splits the K loop over blockIdx.z (f32 atomics into
-                                  splitk_ws [B*TH*TW][w_rows], then an epilogue launch); for small-M layers */
-    float* splitk_ws;          /* must be ALL-ZERO on entry; the split-K epilogue leaves it all-zero again (no memset per launch) */
+    int32_t ksplit;            /* gather kernel: > 1 splits the K loop over blockIdx.z (f32 atomics into
+                                  splitk_ws [B*TH*TW][w_rows], then an epilogue launch); for small-M layers.
+                                  Variant 19: the number of 32- or 64-channel K slices (cin_total / 32 or / 64, a multiple of 4) */
+    float* splitk_ws;          /* must be ALL-ZERO on entry; the split-K epilogue leaves it all-zero again (no memset per launch).
+                                  Variant 19 keeps its tile counters in the last 16 KiB (zero on entry, zero again on exit) */
     int64_t splitk_ws_bytes;
     int32_t variant;           /* kernel choice: 0 heuristic, 1 gather, 2/3 halo-patch with 128-/64-B K chunks,
                                   4 halo-patch single-stage, 5 single-stage double-buffered,
