@@ -578,10 +578,12 @@ __device__ __forceinline__ void mma_steps(AOf a_of, BOf b_of, f32x16 (&acc)[MT][
 // The same walk on v_mfma_f32_16x16x32 (16-bit operands, exchanged operands only: positions on lanes): one step = one (chunk, tap) with
 // K = 32 (a whole 64-B chunk row), a 32x32 tile = 2 x 2 MFMAs (conv_epilogue.h: Acc16).  px_of(step, mt, pt) / w_of(step, nt, ct) return
 // this lane's 16-B fragment address: position 16 pt + (lane & 15) / weight row m16_row_channel(lane & 15) of half ct, K block lane >> 4.
-template <typename T, int MT, int NT, int NSTEP, typename PxOf, typename WOf, typename Hook = NoHook>
+// CTN = 1: only the first 16-channel half of every 32-channel tile is computed (the other half stays zero) -- launches with at most 16 real output
+// channels, e.g. the VGG data gradient into the 3-channel image, whose 32-wide tile is 29 channels of padding.
+template <typename T, int MT, int NT, int NSTEP, int CTN = 2, typename PxOf, typename WOf, typename Hook = NoHook>
 __device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[MT][NT], Hook hook = Hook()) {
     constexpr int SLOTS = 3;
-    uint4 fp[SLOTS][MT][2], fw[SLOTS][NT][2];
+    uint4 fp[SLOTS][MT][2], fw[SLOTS][NT][CTN];
     auto load = [&](int step, int slot) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -590,7 +592,7 @@ __device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[M
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) fw[slot][nt][ct] = *reinterpret_cast<const uint4*>(w_of(step, nt, ct));
+            for (int ct = 0; ct < CTN; ++ct) fw[slot][nt][ct] = *reinterpret_cast<const uint4*>(w_of(step, nt, ct));
     };
     load(0, 0);
     if (NSTEP > 1) load(1, 1);
@@ -603,7 +605,7 @@ __device__ __forceinline__ void mma_steps16(PxOf px_of, WOf w_of, Acc16 (&acc)[M
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
+                for (int ct = 0; ct < CTN; ++ct)
 #pragma unroll
                     for (int pt = 0; pt < 2; ++pt)
                         acc[mt][nt].t[ct][pt] = H16<T>::mma16(__builtin_bit_cast(s16x8_t, fw[sl][nt][ct]), __builtin_bit_cast(s16x8_t, fp[sl][mt][pt]),
@@ -1135,11 +1137,13 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const falnet_conv_t p, 
             const int lp = lane & 15, lg = lane >> 4;
             const char* pxb = Al + ((wm * MT) * PT_PW + lp) * PITCH + lg * 16;
             const char* wb16 = Wl + (wn * 32 + m16_row_channel(lp)) * PITCH + lg * 16;
-            mma_steps16<T, MT, NT, NCH * 9>(
-                [&](int st, int mt, int pt) { const int c = st / 9, t = st % 9;
-                                              return pxb + ((c * NPIX + mt * PT_PW + 16 * pt + (t / 3) * PT_PW + (t % 3)) * PITCH); },
-                [&](int st, int nt, int ct) { return wb16 + ((st * BN + nt * 32 + 16 * ct) * PITCH); },
-                a16);
+            auto px_of = [&](int st, int mt, int pt) { const int c = st / 9, t = st % 9;
+                                                       return pxb + ((c * NPIX + mt * PT_PW + 16 * pt + (t / 3) * PT_PW + (t % 3)) * PITCH); };
+            auto w_of = [&](int st, int nt, int ct) { return wb16 + ((st * BN + nt * 32 + 16 * ct) * PITCH); };
+            bool half_only = false;
+            if constexpr (BN == 32) half_only = p.Cout <= 16;  // (workgroup-uniform) the second 16-channel half is padding: half the MFMAs
+            if (half_only) mma_steps16<T, MT, NT, NCH * 9, 1>(px_of, w_of, a16);
+            else mma_steps16<T, MT, NT, NCH * 9>(px_of, w_of, a16);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -304,6 +304,35 @@ def test_conv_planar_output(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cout", [3, 16, 17])
+def test_conv_few_output_channels_planar(cout, dtype):
+    """Dense 3x3 over 64 channels into <= 17 planar f32 output channels (the VGG data gradient into the 3-channel image, loss_functions.py:
+    autograd of features[0]): every applicable kernel, incl. the weight-stationary kernel's half-tile path (v_mfma_f32_16x16x32, only the first
+    16-channel half of the 32-wide tile computed when Cout <= 16)."""
+    B, H, W = 2, 24, 64
+    case = (B, [64], cout, H, W, 1, 3, False, L.ACT_NONE, False)
+    xs, w, b = _conv_inputs(case, seed=5)
+    ref = _ref_conv(case, xs, w, b)
+    pc = packed(w, None, [64], 1, dtype)
+    src = to_nhwc(xs[0], dtype)
+    out = torch.empty(B, cout, H, W, device=DEV)
+    ops.AUTOTUNE = False
+    call = ops.conv_call(dtype, [ops.nhwc_src(src)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out,
+                         H, W, cout, 0, out_layout=L.OUT_PLANAR_F32)
+    ran = []
+    for variant in (1, 2, 4, 10, 16, 13):
+        call.desc.variant = variant
+        out.fill_(float("nan"))
+        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+        if rc == -2:
+            continue
+        assert rc == 0, (variant, L.lib().falnet_last_error())
+        assert rel(out, ref) < TOL[dtype], variant
+        ran.append(variant)
+    assert 1 in ran and ((10 in ran) == (dtype != torch.float32))  # (64 f32 channels are 256 B per pixel: beyond the weight-stationary kernel)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_fused_upsample(dtype):
     """deconv: nearest resize to an arbitrary size then conv (FAL_netB.py:57-60), incl. non-x2 ratio."""
     g = torch.Generator().manual_seed(3)
