@@ -481,18 +481,31 @@ class FalnetPlan:
                     self._dgrad(pcd, 0, g_dpre, tgt, hh, ww, actout=below, name=dname)
                 else:
                     tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)
-                    fused = False
+                    fused = None
                     if (2 * bh, 2 * bw) == (hh, ww) and L.ab("FALNET_FUSED_UPSUM", "1") == "1":
                         try:  # exact 2x: the 2x2 block sum and elu'(below) ride in the data-gradient epilogue (no full-res g_up)
+                            at = len(self.bwd_body)
                             self._dgrad(pcd, 0, g_dpre, None, hh, ww, name=dname, sum2x2_into=tgt, sum2x2_actout=below)
-                            fused = True
+                            fused, self.bwd_body = self.bwd_body[at:], self.bwd_body[:at]
                         except ValueError:
                             pass
-                    if not fused:
+                    # two launches (plain data gradient, then the adjoint of the upsampling): on the small deep maps the plain data
+                    # gradient has kernels the fused epilogue does not (variant 19 on 8 x 16 maps: deconv6 38 us fused on the halo-patch kernel)
+                    plain = None
+                    if fused is None or hh * ww <= 128:
+                        at = len(self.bwd_body)
                         g_up = self._act(f"g_up{lvl}", hh, ww, below_ch)
                         self._dgrad(pcd, 0, g_dpre, g_up, hh, ww, name=dname)
                         self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
                                                              ww, bh, bw, below_ch, code))
+                        plain, self.bwd_body = self.bwd_body[at:], self.bwd_body[:at]
+                    if fused is not None and plain is not None:
+                        seqs = [fused, plain]
+                        runs = [lambda q=q: [c() for c in q] for q in seqs]
+                        pick = ops.best_of(*runs, key=f"upsum|t{code}|B{B}|{hh}x{ww}|{pcd.cin_pad}>{pcd.cout_pad}")
+                        self.bwd_body.extend(seqs[runs.index(pick)])
+                    else:
+                        self.bwd_body.extend(fused if fused is not None else plain)
                 if lvl < 6:
                     g_ipre[lvl + 1] = tgt
             # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)
