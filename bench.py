@@ -88,12 +88,20 @@ def hbm_traffic_live(kernel_symbol, args):
         return None
     sums = {}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-             "--workload", args.workload, "--dtype", args.dtype, "--batch", str(args.batch)]
+             "--workload", args.workload, "--dtype", args.dtype, "--batch", str(args.batch),
+             "--height", str(args.height), "--width", str(args.width), "--levels", str(args.levels)]
+    # the child is a stand-alone single-GPU run: it must not inherit this process's rendezvous (under torchrun, or with
+    # FALNET_FORCE_DIST=1, it would call init_process_group as rank 0 of the PARENT's world and wait for peers that never come)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                        "GROUP_WORLD_SIZE", "FALNET_FORCE_DIST", "FALNET_DIST_BACKEND")
+           and not k.startswith(("MASTER_", "TORCHELASTIC_", "TORCH_NCCL_", "NCCL_ASYNC"))}
+    env["TMPDIR"] = "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="falnet_pmc_", dir="/tmp")
         try:
             r = subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp",
-                               env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=900)
+                               env=env, capture_output=True, text=True, timeout=600)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
@@ -125,9 +133,9 @@ def host_cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, height, width, levels, sample_batch=8, timed=2):
+def cpu_baseline(workload, height, width, levels, sample_batch=8, timed=3):
     """Reported CPU baseline: the oracle's step of the same workload (fp32, torch CPU) at the benchmark's own batch (B = 8,
-    BASELINE.md section 4) on a bounded sample: one warm-up step, then `timed` steps (about 30 s on the GPU box's host), plus the
+    BASELINE.md section 4: >= 3 timed steps) on a bounded sample: one warm-up step, then `timed` steps (about 40 s on the GPU box's host), plus the
     single-pair forward of BASELINE configs[0].  Threads are capped at 32: on the 256-thread GPU-box host torch's CPU convs get
     *slower* beyond that (measured: 235 s for B=2 with 256 threads), and `cores` must be the threads actually used."""
     from fal_net_amd import synthetic
@@ -402,16 +410,20 @@ def main():
         agg = timer.summary()
         ops.TIMER = None
         if args.launch_table:
-            per = {}
-            for tag, flops, nbytes, e0, e1, name in timer.records:
-                a = per.setdefault(name, [0.0, 0, flops, tag])
-                a[0] += e0.elapsed_time(e1)
-                a[1] += 1
+            # one row per LAUNCH of a step (position in the step's launch order), averaged over the three instrumented steps;
+            # FLOPs are that launch's own algorithmic FLOPs
+            n_per_step = len(timer.records) // 3
+            rows = []
+            for i in range(n_per_step):
+                tag, flops, nbytes, _, _, name = timer.records[i]
+                us = sum(timer.records[i + k * n_per_step][3].elapsed_time(timer.records[i + k * n_per_step][4]) for k in range(3)) * 1e3 / 3
+                same = all(timer.records[i + k * n_per_step][5] == name for k in range(3))
+                rows.append((us, i, flops, nbytes, name if same else name + " (order varies)", tag))
             with open(args.launch_table, "w") as f:
-                for name, (ms, cnt, flops, tag) in sorted(per.items(), key=lambda kv: -kv[1][0]):
-                    us = ms * 1e3 / cnt
-                    f.write(f"{ms * 1e3 / 3:8.1f} us/step {cnt // 3:3d} x {us:8.1f} us  "
-                            f"{flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  {name:44s} {tag}\n")
+                f.write(f"# {n_per_step} launches per step; us = mean of 3 instrumented steps (HIP events, side streams off); TF = the launch's own algorithmic FLOPs / us\n")
+                for us, i, flops, nbytes, name, tag in sorted(rows, key=lambda r: -r[0]):
+                    f.write(f"{us:8.1f} us  #{i:3d}  {flops / 1e9:8.2f} GFLOP {flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  "
+                            f"{nbytes / (us * 1e-6) / 1e9 if nbytes else 0:7.0f} GB/s  {name:44s} {tag}\n")
         total_ms = sum(a["ms"] for a in agg.values()) / 3
         dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
         d = agg[dom_tag]
@@ -421,7 +433,8 @@ def main():
         mfma_fl = sum(a["flops"] for a in agg.values()) / 3
         result["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": (None if args.no_live_traffic else hbm_traffic_live(dom_tag, args)) or hbm_traffic_from_profiles(dom_tag),
+            # live PMC child passes only from a single-process run (world > 1: the other ranks would sit in destroy_process_group)
+            "traffic": (None if (args.no_live_traffic or world > 1) else hbm_traffic_live(dom_tag, args)) or hbm_traffic_from_profiles(dom_tag),
             "kernel": dom_tag, "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "kernel_ms_per_step": d["ms"] / 3, "all_kernels_ms_per_step": total_ms,
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "falnet_med_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_head_bwd_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "falnet_med_head_kernel_name": [_I, _I, _I, _I, C.c_char_p, _I],
     "falnet_med_masks_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_maskr_acfalse_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_l1_fwd": [_P, _P, _P, _I, _I, _L, _F, _P, _I, _P],
@@ -151,6 +152,9 @@ SIGNATURES = {
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
 
 _lib = None
+# falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
+# FALNET_LIB build with the same symbols but another descriptor layout must not load
+EXPECTED_VERSION = 400
 
 
 def lib():
@@ -166,6 +170,10 @@ def lib():
             fn = getattr(l, name)  # AttributeError here = header/library drift: fail loudly
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
+        got = l.falnet_version()
+        if got != EXPECTED_VERSION:
+            raise RuntimeError(f"{_LIB_PATH} reports falnet_version() = {got}, this binding expects {EXPECTED_VERSION}: rebuild it "
+                               "(`python -m fal_net_amd._build`; experiment builds: `--ab <tag>`)")
         if DETERMINISTIC:
             l.falnet_set_deterministic(1)
         _lib = l
@@ -183,12 +191,15 @@ def check(rc, what=""):
 # Stream object per call: ~1.5 us x 300 launches), and `on_stream` redirects the launches of a `with` block to another stream (the
 # weight-gradient side stream) without torch.cuda.stream()'s context switch (~10 us per launch group).  Outside such scopes the current
 # torch stream is looked up per call, as before.
-_PINNED = None
+import threading
+
+_TLS = threading.local()  # the pin is per THREAD: autograd's backward thread pins its own stream without redirecting the main thread's launches
 
 
 def stream_ptr():
-    if _PINNED is not None:
-        return _PINNED
+    p = getattr(_TLS, "pinned", None)
+    if p is not None:
+        return p
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -199,15 +210,13 @@ class stream_scope:
         self._s = stream
 
     def __enter__(self):
-        global _PINNED
-        self._old = _PINNED
+        self._old = getattr(_TLS, "pinned", None)
         s = self._s if self._s is not None else torch.cuda.current_stream()
-        _PINNED = C.c_void_p(s.cuda_stream)
+        _TLS.pinned = C.c_void_p(s.cuda_stream)
         return self
 
     def __exit__(self, *exc):
-        global _PINNED
-        _PINNED = self._old
+        _TLS.pinned = self._old
         return False
 
 

@@ -690,8 +690,8 @@ static const bool g_head_v1 = [] { const char* e = falnet_ab_env("FALNET_HEAD_V1
 
 // wave-neighbour kernels (med_head2.hip)
 bool falnet_head_wave_applicable(int W);
-void falnet_head_fwd_wave_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
-                               float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream);
+bool falnet_head_fwd_lds2_applicable(int N, int W);
+bool falnet_head_bwd_lds2_applicable(int N, int W, int dtype);
 bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
                                  float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream);
 bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, const float* disp,
@@ -719,10 +719,6 @@ extern "C" int falnet_med_head_fwd(const float* dlog0, const float* left, const 
     if (!g_head_v1 && al16(dlog0) && al16(left) &&
         falnet_head_fwd_lds2_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, B, N, H, W, (hipStream_t)stream))
         FALNET_RETURN_LAUNCH();
-    if (!g_head_v1 && W > 1024 && falnet_head_wave_applicable(W) && al16(dlog0) && al16(left) && al16(disp) && al16(p_im0) && al16(stats)) {
-        falnet_head_fwd_wave_launch(dlog0, left, min_disp, max_disp, disp, p_im0, stats, B, N, H, W, (hipStream_t)stream);
-        FALNET_RETURN_LAUNCH();
-    }
     const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
     const size_t WP = (size_t)((W + 7) & ~3);
     const size_t lds2 = sizeof(PlaneTab) + (3 + CH) * WP * sizeof(float);
@@ -806,6 +802,31 @@ extern "C" int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, c
     FALNET_DISPATCH_DTYPE(dtype, BWD_V1_T);
 #undef BWD_V1_T
     FALNET_RETURN_LAUNCH();
+}
+
+// Which kernel the three entry points above dispatch to for a shape (16-byte aligned operands assumed: torch allocations are) -- the same
+// predicates in the same order.  pass: 0 = falnet_med_head_fwd, 1 = falnet_med_head_bwd (planar f32), 2 = falnet_med_head_bwd_nhwc.
+extern "C" int falnet_med_head_kernel_name(int pass, int dtype, int N, int W, char* buf, int len) {
+    if (int r = check_head(1, N, 1, W)) return r;
+    FALNET_CHECK_ARG(buf && len > 0 && pass >= 0 && pass <= 2, "med_head_kernel_name: bad argument");
+    const char* name;
+    if (pass == 0) {
+        const int ppt = (W + HEAD_THREADS - 1) / HEAD_THREADS;
+        const size_t lds2 = sizeof(PlaneTab) + (3 + CH) * (size_t)((W + 7) & ~3) * sizeof(float);
+        name = (!g_head_v1 && falnet_head_fwd_lds2_applicable(N, W)) ? (W > 1024 ? "med_head_fwd_lds2_kernel<512 threads>" : "med_head_fwd_lds2_kernel")
+               : (!g_head_v1 && ppt <= 8 && lds2 <= 64 * 1024)     ? "med_head_fwd_lds_kernel"
+                                                                    : "med_head_fwd_kernel";
+    } else if (pass == 1) {
+        name = "med_head_bwd_kernel<planar>";
+    } else {
+        static const bool v1 = [] { const char* e = falnet_ab_env("FALNET_HEAD_BWD_V1"); return e && e[0] == '1'; }();
+        name = (!v1 && falnet_head_bwd_lds2_applicable(N, W, dtype)) ? (W > 1024 ? "med_head_bwd_lds2_kernel<512 threads>" : "med_head_bwd_lds2_kernel")
+               : (!v1 && W > 1024 && falnet_head_wave_applicable(W)) ? "med_head_bwd_wave_kernel"
+               : (!v1 && W <= 4 * HEAD_THREADS)                      ? "med_head_bwd_lds_kernel"
+                                                                      : "med_head_bwd_kernel<nhwc>";
+    }
+    snprintf(buf, (size_t)len, "%s", name);
+    return 0;
 }
 
 extern "C" int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp,

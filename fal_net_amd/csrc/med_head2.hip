@@ -9,7 +9,8 @@
 //      pitch for W = 512; backward: the five per-source values interleaved ([s+1][5]: both sources of a pixel behind ONE address,
 //      conflict free), selects instead of divergent branches, 16-bit output in 32-B sectors.  46 / 61 VALU per (pixel, plane):
 //      forward 101 -> 86 us, backward 200 -> 160 us.
-//  (2) wave-neighbour form, 1024 < W <= 1984 (`*_wave_kernel`; used for the 16-bit backward of the 384x1280 high-resolution shape):
+//  (2) wave-neighbour form, 1024 < W <= 1984 (`med_head_bwd_wave_kernel`: the 16-bit backward of the 384x1280 high-resolution shape; its
+//      forward twin lost to (1)'s 512-thread form, 1097 vs 652 us at 8 x 384 x 1280, N = 96, and was removed in round 4):
 //      the plane shift k_n is the same for every pixel, so the second tap of pixel x is the FIRST tap of pixel x+1 -- one lane over.
 //      A wave owns 64 consecutive columns, every lane reads ONE tap from LDS and takes its neighbour's with a DPP wavefront shift; the
 //      last lane has no neighbour, so waves overlap by one column (63 outputs per wave forward).  Backward: the adjoint of the two-tap
@@ -96,136 +97,6 @@ struct RowFetch {
         }
     }
 };
-
-// ---------------------------------------------------------------------------------------- forward
-// LDS: left[3][WP] | plane rows [HW_CH][WP], WP = W + 8 (trailing zeros: out-of-range taps read 0 without a branch).
-// Wave unit u = outputs 63u .. 63u+62; unit u is handled by wave u % nw in round u / nw (nw waves, R rounds).
-template <int R>
-__global__ __launch_bounds__(HW_MAXT) void med_head_fwd_wave_kernel(
-    const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
-    const float* __restrict__ max_disp, float* __restrict__ disp, float* __restrict__ p_im0,
-    float* __restrict__ stats, int N, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int WP = W + 8;
-    float* lrow = reinterpret_cast<float*>(smem);  // [3][WP]
-    float* prow = lrow + 3 * WP;                   // [HW_CH][WP]
-    const int b = blockIdx.x / H, y = blockIdx.x % H;
-    const int64_t HW = (int64_t)H * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int w4 = W >> 2;
-    const WavePlanes tab = wave_build_planes(min_disp[b], max_disp[b], N, W);
-    const bool want_pan = p_im0 != nullptr;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = threadIdx.x; i < 3 * w4; i += blockDim.x) {
-        const int c = i / w4, q = i - c * w4;
-        *reinterpret_cast<float4*>(lrow + c * WP + 4 * q) =
-            want_pan ? reinterpret_cast<const float4*>(left + ((int64_t)b * 3 + c) * HW + (int64_t)y * W)[q] : zero4;
-    }
-    for (int i = threadIdx.x; i < 2 * (3 + HW_CH); i += blockDim.x)  // zero tails of every LDS row
-        *reinterpret_cast<float4*>(lrow + (i >> 1) * WP + W + 4 * (i & 1)) = zero4;
-    const float* Lrow = dlog0 + (int64_t)b * N * HW + (int64_t)y * W;
-
-    int xs[R];       // this lane's column per round (may lie beyond the row: addresses are clamped, stores skipped)
-    bool unit[R];    // wave-uniform: the round's unit exists
-    float m0[R], z0[R], dacc[R], mw[R], zw[R], p0[R], p1[R], p2[R];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const int X0 = 63 * (wave + nw * q);
-        unit[q] = X0 < W;
-        xs[q] = X0 + lane;
-        m0[q] = mw[q] = -INFINITY;
-        z0[q] = dacc[q] = zw[q] = p0[q] = p1[q] = p2[q] = 0.f;
-    }
-    constexpr int PF = 2 * R;  // >= HW_CH * (W / 4) / blockDim
-    RowFetch<PF> pf;
-    pf.load(Lrow, HW, 0, N, w4);
-    for (int n0 = 0; n0 < N; n0 += HW_CH) {
-        __syncthreads();  // previous chunk fully consumed (and the left row / tails written)
-        pf.store(prow, WP, 0, w4);
-        __syncthreads();
-        if (n0 + HW_CH < N) pf.load(Lrow, HW, n0 + HW_CH, N, w4);
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            if (!unit[q]) continue;  // wave-uniform: every DPP below runs with 64 active lanes
-            const int x = xs[q];
-            const int xc = min(x, W);
-            // No per-plane branches: planes >= N of the last chunk read the zero-filled rows, get logit -inf (weight exp(-inf) = 0)
-            // and contribute nothing -- so the chunk's 16 LDS reads issue back to back instead of one dependent round trip per plane.
-            float l0[HW_CH], lw[HW_CH], tp[HW_CH], pd[HW_CH], pa[HW_CH];
-            int pk[HW_CH];
-#pragma unroll
-            for (int j = 0; j < HW_CH; ++j) {
-                wave_plane(tab, n0 + j, pd[j], pa[j], pk[j]);  // n0 + j < 64 + HW_CH: inside the 128-entry table
-                const float* pr = prow + j * WP;
-                l0[j] = pr[xc];
-                tp[j] = pr[min(x + pk[j], W)];  // zero tail: an out-of-image logit is 0, not -inf
-            }
-            float cm0 = -INFINITY, cmw = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < HW_CH; ++j) {
-                const bool real = n0 + j < N;  // wave-uniform
-                lw[j] = real ? (1.f - pa[j]) * tp[j] + pa[j] * lane_next(tp[j]) : -INFINITY;
-                l0[j] = real ? l0[j] : -INFINITY;
-                cm0 = fmaxf(cm0, l0[j]);
-                cmw = fmaxf(cmw, lw[j]);
-            }
-            if (cm0 > m0[q]) {
-                const float s = __expf(m0[q] - cm0);
-                z0[q] *= s;
-                dacc[q] *= s;
-                m0[q] = cm0;
-            }
-            if (cmw > mw[q]) {
-                const float s = __expf(mw[q] - cmw);
-                zw[q] *= s;
-                p0[q] *= s;
-                p1[q] *= s;
-                p2[q] *= s;
-                mw[q] = cmw;
-            }
-            float ev[HW_CH];
-#pragma unroll
-            for (int j = 0; j < HW_CH; ++j) {
-                const float e = __expf(l0[j] - m0[q]);
-                z0[q] += e;
-                dacc[q] += pd[j] * e;
-                ev[j] = __expf(lw[j] - mw[q]);
-                zw[q] += ev[j];
-            }
-            if (want_pan) {  // uniform; the divergent rescale branches above have re-converged
-#pragma unroll
-                for (int j = 0; j < HW_CH; ++j) {
-                    const int i0 = min(x + pk[j], W);
-                    const float a = pa[j];
-                    const float t0 = lrow[i0], t1 = lrow[WP + i0], t2 = lrow[2 * WP + i0];
-                    p0[q] += ev[j] * ((1.f - a) * t0 + a * lane_next(t0));
-                    p1[q] += ev[j] * ((1.f - a) * t1 + a * lane_next(t1));
-                    p2[q] += ev[j] * ((1.f - a) * t2 + a * lane_next(t2));
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-        const int x = xs[q];
-        if (!unit[q] || lane == 63 || x >= W) continue;
-        const int64_t pix = (int64_t)y * W + x;
-        if (disp) disp[(int64_t)b * HW + pix] = dacc[q] / z0[q];
-        if (want_pan) {
-            const float r = 1.f / zw[q];
-            p_im0[((int64_t)b * 3 + 0) * HW + pix] = p0[q] * r;
-            p_im0[((int64_t)b * 3 + 1) * HW + pix] = p1[q] * r;
-            p_im0[((int64_t)b * 3 + 2) * HW + pix] = p2[q] * r;
-        }
-        if (stats) {
-            float* st = stats + (int64_t)b * 4 * HW + pix;
-            st[0] = m0[q];
-            st[HW] = z0[q];
-            st[2 * HW] = mw[q];
-            st[3 * HW] = zw[q];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------- backward (NHWC gradient)
 // Lane l of unit u sits on column x' = 62u - 1 + l: it holds L_n(x'), gets L_n(x'+1) from lane l+1, and computes T_n for the source
@@ -530,10 +401,14 @@ __global__ __launch_bounds__(NT) void med_head_fwd_lds2_kernel(
     }
 }
 
+bool falnet_head_fwd_lds2_applicable(int N, int W) {
+    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_FWD2"); return e && e[0] == '0'; }();
+    return !(off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128);  // (plane table: 128 entries, read up to N - 1 + HW_CH - 1)
+}
+
 bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
                                  float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream) {
-    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_FWD2"); return e && e[0] == '0'; }();
-    if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;  // (plane table: 128 entries, read up to N - 1 + HW_CH - 1)
+    if (!falnet_head_fwd_lds2_applicable(N, W)) return false;
     const int wp = (W + 7) & ~3;
     const size_t lds = (size_t)(3 + HW_CH) * wp * sizeof(float);
 #define HW_L(P, C, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(med_head_fwd_lds2_kernel<P, C, NT>), dim3(B * H), dim3(NT), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, N, H, W)
@@ -734,13 +609,18 @@ static void bwd_lds2_launch_t(const float* dlog0, const float* left, const float
 #undef HW_L
 }
 
+bool falnet_head_bwd_lds2_applicable(int N, int W, int dtype) {
+    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_BWD2"); return e && e[0] == '0'; }();
+    if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;
+    // 8 x 384 x 1280, N = 96: 16-bit gradient 991 us here vs 955 us on the wave-neighbour kernel (f32: 1277 vs 1357)
+    if (W > 1024 && dtype != FALNET_F32 && falnet_head_wave_applicable(W)) return false;
+    return true;
+}
+
 bool falnet_head_bwd_lds2_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, const float* disp,
                                  const float* p_im0, const float* stats, const float* gdisp, const float* gpan, void* gdlog0, int cpad,
                                  int dtype, int B, int N, int H, int W, hipStream_t stream) {
-    static const bool off = [] { const char* e = falnet_ab_env("FALNET_HEAD_BWD2"); return e && e[0] == '0'; }();
-    if (off || (W & 3) || W < 4 || W > 2048 || N + HW_CH > 128) return false;
-    // 8 x 384 x 1280, N = 96: 16-bit gradient 991 us here vs 955 us on the wave-neighbour kernel (f32: 1277 vs 1357; forward 652 vs 1097)
-    if (W > 1024 && dtype != FALNET_F32 && falnet_head_wave_applicable(W)) return false;
+    if (!falnet_head_bwd_lds2_applicable(N, W, dtype)) return false;
 #define HW_D(T) bwd_lds2_launch_t<T>(dlog0, left, min_disp, max_disp, disp, p_im0, stats, gdisp, gpan, (T*)gdlog0, cpad, B, N, H, W, stream)
     FALNET_DISPATCH_DTYPE(dtype, HW_D);
 #undef HW_D
@@ -757,16 +637,6 @@ static void wave_geometry(int W, int& rounds, int& threads) {
     const int units = (W + 61) / 62;  // 62 outputs per wave are enough for both kernels (63 / 62)
     rounds = (units + 15) / 16;
     threads = 64 * ((units + rounds - 1) / rounds);
-}
-
-void falnet_head_fwd_wave_launch(const float* dlog0, const float* left, const float* min_disp, const float* max_disp, float* disp,
-                                 float* p_im0, float* stats, int B, int N, int H, int W, hipStream_t stream) {
-    const size_t lds = (size_t)(3 + HW_CH) * (W + 8) * sizeof(float);
-    int r, nt;
-    wave_geometry(W, r, nt);
-#define HW_F(RR) hipLaunchKernelGGL(med_head_fwd_wave_kernel<RR>, dim3(B * H), dim3(nt), lds, stream, dlog0, left, min_disp, max_disp, disp, p_im0, stats, N, H, W)
-    if (r == 1) HW_F(1); else HW_F(2);
-#undef HW_F
 }
 
 template <typename T>

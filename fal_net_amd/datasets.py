@@ -31,7 +31,8 @@ def read_pair_list(list_file, root):
     if not os.path.isfile(list_file):
         raise FileNotFoundError(
             f"training list {list_file!r} not found: pass --train_list <file> with one 'left right' pair of paths (relative to --data/"
-            "<dataName0>) per line, e.g. the reference's Datasets/kitti_eigen_train.txt")
+            "<dataName0>) per line.  The Eigen training split the reference defaults to (22 600 pairs) ships with the reference repository as "
+            "Datasets/kitti_eigen_train.txt (github.com/JuanLuisGonzalez/FAL_net); it is not redistributed here: copy it next to the script or name it.")
     with open(list_file) as f:
         lines = [ln.split() for ln in f.read().splitlines() if ln.strip()]
     return [(ln[0], ln[1]) for ln in lines if len(ln) >= 2 and os.path.isfile(os.path.join(root, ln[0]))]
@@ -74,7 +75,9 @@ def eigen_test_triples(list_file, root):
     <drive>/proj_depth/groundtruth/image_02/<frame>.png, derived from the left path exactly as the reference slices it (the last 29
     characters are 'image_02/data/<10 digits>.png').  Lines whose image or ground truth is missing under `root` are skipped."""
     if not os.path.isfile(list_file):
-        raise FileNotFoundError(f"test list {list_file!r} not found (one 'left right [gt]' line per frame, paths relative to <data>/<tdataName>)")
+        raise FileNotFoundError(f"test list {list_file!r} not found (one 'left right [gt]' line per frame, paths relative to <data>/<tdataName>).  "
+                                "The improved Eigen test split (697 lines) ships with the reference repository as Datasets/kitti_eigen_test_improved.txt "
+                                "(github.com/JuanLuisGonzalez/FAL_net); it is not redistributed here: copy it or pass --test_list <file>.")
     out = []
     with open(list_file) as f:
         for ln in f.read().splitlines():

@@ -41,7 +41,7 @@ def flip_post_process(input_view, pan_model, disp, min_disp, max_pix):
 
 
 def evaluate(pan_model, loader, data_name="Kitti2015", max_disp=300.0, min_disp=2.0, rel_baseline=1.0, post="ms_pp", use_median=False,
-             print_freq=10, log=print):
+             print_freq=10, log=print, with_metrics=True):
     """The evaluation loop of Test_KITTI.py:163-208,255-280 over a loader of full-size frames (batch size 1: KITTI mixes image
     sizes, :113): forward (+ flip or multi-scale post-processing, :196-205), then per image the KITTI depth errors and -- for
     KITTI 2015 -- the end-point error (:257-271).  `loader` yields lists of (left_u8, right_u8, gt) from
@@ -70,7 +70,7 @@ def evaluate(pan_model, loader, data_name="Kitti2015", max_disp=300.0, min_disp=
                     disp = ms_pp(left, pan_model, disp, mn, mx)
                 torch.cuda.synchronize()
                 batch_time.update(time.time() - t0, 1)
-                if gt is not None:
+                if gt is not None and with_metrics:  # `-eval False`: forward and timing only (:255)
                     target = gt.to(dev).view(1, 1, *gt.shape)
                     t_np, p_np = target.squeeze(1).cpu().numpy(), disp.float().squeeze(1).cpu().numpy()
                     if data_name == "Kitti2015":  # :265-271

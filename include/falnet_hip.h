@@ -302,6 +302,9 @@ int falnet_med_head_bwd_nhwc(const float* dlog0, const float* left, const float*
                              const float* disp, const float* p_im0, const float* stats,
                              const float* grad_disp, const float* grad_p_im0, void* grad_dlog0_nhwc, int cpad, int dtype,
                              int B, int N, int H, int W, void* stream);
+/* Name of the kernel the three head entry points dispatch to for a shape (tests assert that every form is covered; same predicates as
+ * the launches, 16-byte aligned operands assumed).  pass: 0 = falnet_med_head_fwd, 1 = falnet_med_head_bwd, 2 = falnet_med_head_bwd_nhwc. */
+int falnet_med_head_kernel_name(int pass, int dtype, int N, int W, char* buf, int len);
 /* occlusion masks (FAL_netB.py:264-273,291-292), no grad: maskR = min(1, sum_n shift_{+s_n}(softmax(dlog0)_n)),
  * maskL = min(1, sum_n shift_{-s_n}(Dprob_n)).  Dprob is rebuilt from the logits and `stats`. */
 int falnet_med_masks_fwd(const float* dlog0, const float* min_disp, const float* max_disp, const float* stats,

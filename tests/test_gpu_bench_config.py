@@ -1,4 +1,5 @@
-"""GPU parity at the BENCHMARK's own configuration (BASELINE configs[1] / configs[3]: B = 8, 256 x 512, N = 49).
+"""GPU parity at the BENCHMARK's own configurations (BASELINE configs[1] / configs[3]: B = 8, 256 x 512, N = 49; configs[4]: 384 x 1280,
+N = 96, f16).
 
 `bench.py` picks its kernels from the B-keyed entries of the committed autotune cache (`...|B8|...`: the persistent LDS-DMA /
 weight-stationary variants on shapes no small test launches at that batch), so this module runs exactly those launches and holds
@@ -25,15 +26,16 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def _build(dtype, train_mode=True):
+def _build(dtype, train_mode=True, n=N):
     LF.set_compute_dtype(dtype)
-    m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(N)}, no_levels=N, compute_dtype=dtype).to(DEV)
+    m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(n)}, no_levels=n, compute_dtype=dtype).to(DEV)
     return m.train() if train_mode else m.eval()
 
 
-def _stage1(dtype):
-    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)  # bench.py's rank-0 batch
-    m = _build(dtype)
+def _stage1(dtype, shape=(B, H, W, N)):
+    b, h, w, n = shape
+    left, right, mn, mx = synthetic.synthetic_pair(b, h, w, seed=1234)  # bench.py's rank-0 batch
+    m = _build(dtype, n=n)
     out = train.stage1_step(m, train.FlatAdam(m), left.to(DEV), right.to(DEV), mx.to(DEV), optimize=False)
     inv = 1.0 / float(out["scaler"].state[0]) if out.get("scaler") is not None else 1.0  # f16: the raw gradients carry the loss scale
     res = {"loss": float(out["loss"]), "rec": float(out["rec"]), "sm": float(out["sm"]), "ldisp": out["ldisp"].clone().cpu(),
@@ -50,12 +52,10 @@ def _f32_stage1():
     return _F32["s1"]
 
 
-def test_stage1_b8_f32_vs_oracle():
-    """One Stage-1 step at B=8, 256x512, N=49 in f32 against the CPU oracle: loss scalars and disparity 1e-4, synthesised view
-    2e-4 (the reference's own fp32 grid noise, DESIGN section 2), every parameter's gradient norm 2e-3."""
-    hip = _f32_stage1()
-    left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=1234)
-    sd = synthetic.seeded_falnetb_state_dict(N)
+def _check_vs_oracle(hip, shape, what):
+    b, h, w, n = shape
+    left, right, mn, mx = synthetic.synthetic_pair(b, h, w, seed=1234)
+    sd = synthetic.seeded_falnetb_state_dict(n)
     params = O.leaf_params(sd)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     ref = O.stage1_step(params, O.OracleAdam(params), synthetic.seeded_vgg19_state_dict(), left, right, mn, mx)  # gradients in ref["grads"]
@@ -71,7 +71,43 @@ def test_stage1_b8_f32_vs_oracle():
         e = abs(gn - float(g.norm())) / float(g.norm())
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e < 2e-3, (k, gn, float(g.norm()))
-    print("B=8 f32 vs oracle: worst gradient-norm deviation", worst)
+    print(what, "f32 vs oracle: worst gradient-norm deviation", worst)
+
+
+def test_stage1_b8_f32_vs_oracle():
+    """One Stage-1 step at B=8, 256x512, N=49 in f32 against the CPU oracle: loss scalars and disparity 1e-4, synthesised view
+    2e-4 (the reference's own fp32 grid noise, DESIGN section 2), every parameter's gradient norm 2e-3."""
+    _check_vs_oracle(_f32_stage1(), (B, H, W, N), "B=8 256x512 N=49")
+
+
+HIGHRES = (384, 1280, 96)  # BASELINE configs[4]
+
+
+def test_highres_b1_f32_step_vs_oracle():
+    """BASELINE configs[4]'s shape, forward AND backward: one Stage-1 step at 384x1280, N=96 (B=1: the oracle's step is ~1.6 TFLOP per pair)
+    in f32 against the CPU oracle, same bounds as the configs[1] test.  The MED head runs on the 512-thread strided kernels here
+    (tests/test_gpu_ops.py::test_med_head_cases_cover_every_head_kernel names them).  Reference: FAL_netB.py:200-297, Train_Stage1_K.py:233-262."""
+    shape = (1,) + HIGHRES
+    _check_vs_oracle(_stage1(torch.float32, shape), shape, "B=1 384x1280 N=96")
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_highres_b8_16bit_vs_f32_hip(dt):
+    """configs[4] at the benchmark's own batch (the `...|B8|...` autotune entries of `bench.py --workload highres`, the wave-neighbour
+    16-bit head backward): f16 (its dtype) and bf16 against the f32 HIP step of the same inputs (itself held to the oracle at B=1 above)."""
+    shape = (8,) + HIGHRES
+    if "hr" not in _F32:
+        _F32["hr"] = _stage1(torch.float32, shape)
+    ref, got = _F32["hr"], _stage1(dt, shape)
+    lrel = abs(got["loss"] - ref["loss"]) / ref["loss"]
+    drel = rel(got["ldisp"], ref["ldisp"])
+    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
+    worst = max(((k, abs(v - ref["gnorm"][k]) / ref["gnorm"][k]) for k, v in got["gnorm"].items()), key=lambda t: t[1])
+    print(f"highres B=8 {dt} vs f32 HIP: loss rel {lrel:.2e}, disp max-rel {drel:.2e}, grad cosine {cos:.5f}, worst grad-norm rel {worst}")
+    assert torch.isfinite(got["flat_grad"]).all()
+    assert lrel < 2e-2 and cos > 0.98
+    assert drel < (1e-1 if dt == torch.bfloat16 else 2e-2)
+    assert worst[1] < 0.25, worst
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

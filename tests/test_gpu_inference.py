@@ -57,7 +57,7 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     ["Train_Stage1_Kslow.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage2_K.py", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
     # the other two model variants through the same scripts (FAL_netA: 3x1 / 1x3 residual convs + its align_corners=False right mask in Stage 2)
-    ["Test_KITTI.py", "-mm", "FAL_netA", "-no_levels", "33", "--height", "96", "--width", "320", "--iters", "2", "--dtype", "f32"],
+    ["Test_KITTI.py", "-m", "FAL_netA", "-no_levels", "33", "--height", "96", "--width", "320", "--iters", "2", "--dtype", "f32"],
     ["Train_Stage1_K.py", "-mm", "FAL_netC", "-no_levels", "33", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1"],
     ["Train_Stage2_K.py", "-mm", "FAL_netA", "--synthetic", "--epochs", "1", "--epoch_size", "2", "-b", "1", "-ch", "64", "-cw", "128", "-p", "1", "-no_levels", "7"],
 ])
@@ -111,6 +111,34 @@ def test_entry_scripts_train_and_validate_on_generated_pngs(script, extra, tmp_p
         assert bad.returncode != 0 and "--fix_model" in (bad.stderr + bad.stdout)
 
 
+def test_test_kitti_reference_command_line(tmp_path):
+    """A reference-style invocation (reference Test_KITTI.py:36-60,119-122): `-m` is the model NAME, the checkpoint is composed as
+    <-dt>/<-ts>/<-m><-dtl>, the model class comes from the checkpoint's m_model entry, and the results land in
+    Test_Results/<tdataName>/<model>/<time_stamp>mspp relative to the working directory."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_logic import _write_png_fixture
+    root, _ = _write_png_fixture(tmp_path, n_train=1, n_val=1)
+    ckdir = tmp_path / "Kitti_stage2" / "10-18-15_42" / "FAL_netB,e20es,b4,lr5e-05"
+    os.makedirs(ckdir)
+    sd = synthetic.seeded_state_dict("A", 33)  # the checkpoint says FAL_netA although -m says FAL_netB: m_model wins (:122)
+    torch.save({"epoch": 3, "m_model": "FAL_netA", "state_dict": sd, "best_rmse": 1.0}, ckdir / "checkpoint.pth.tar")
+    argv = ["-d", str(root), "-tn", "Kitti2015", "-relbase", "1", "-mdisp", "300", "-mindisp", "2", "-b", "4", "-eval", "True", "-save", "False",
+            "-save_pc", "False", "-save_pan", "False", "-save_input", "False", "-w", "1", "--sparse", "-p", "1", "-gpu_no", "0",
+            "-dt", str(tmp_path / "Kitti_stage2"), "-ts", "10-18-15_42", "-m", "FAL_netB", "-no_levels", "33",
+            "-dtl", ",e20es,b4,lr5e-05/checkpoint.pth.tar", "-fpp", "False", "-mspp", "True", "-median", "False"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "Test_KITTI.py")] + argv, capture_output=True, text=True, timeout=900, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "=> using pre-trained model for pan 'FAL_netA'" in r.stdout
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["frames"] == 1 and out["post"] == "ms_pp" and out["epe"] > 0
+    res = tmp_path / "Test_Results" / "Kitti2015" / "FAL_netB" / "10-18-15_42mspp"
+    assert os.path.isfile(res / "errors.txt") and os.path.isfile(res / "settings.txt")
+    # the dump switches parse, and are refused (out of scope) when true
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "Test_KITTI.py")] + argv + ["-save", "True"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert bad.returncode != 0 and "out of scope" in (bad.stderr + bad.stdout)
+
+
 @pytest.mark.parametrize("mode", ["Kitti2015", "Kitti_eigen_test_improved"])
 def test_test_kitti_evaluates_a_dataset(mode, tmp_path):
     """Test_KITTI.py as an evaluator (reference Test_KITTI.py:103-117,255-280): file-list dataset at B = 1 over a generated PNG
@@ -158,9 +186,9 @@ def test_test_kitti_evaluates_a_dataset(mode, tmp_path):
     assert "Number of parameters" in txt and "EPE" in txt and "abs_rel" in txt
     if mode == "Kitti2015":
         assert out["epe"] > 0
-    # without --model and without the explicit flag the evaluator refuses (the reference torch.loads the checkpoint)
+    # without a checkpoint and without the explicit flag the evaluator refuses (the reference torch.loads the checkpoint)
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "Test_KITTI.py"), "-d", str(root)] + args, capture_output=True, text=True, timeout=300, cwd=ROOT)
-    assert r2.returncode != 0 and "--model" in (r2.stderr + r2.stdout)
+    assert r2.returncode != 0 and "--checkpoint" in (r2.stderr + r2.stdout)
     # f32 evaluation loop vs the oracle's disparities through the same metric chain
     sd = synthetic.seeded_falnetb_state_dict(49)
     m = FAL_netB({"state_dict": sd}, 49, compute_dtype=torch.float32).to(DEV).eval()

@@ -674,7 +674,35 @@ def test_upsample_bwd_and_pool():
         assert rel(to_nchw(gx, 64), x.grad) < tol
 
 
-HEAD_CASES = [(2, 7, 6, 40, 30.0), (2, 49, 4, 128, 300.0), (1, 49, 3, 512, 300.0), (1, 96, 2, 320, 300.0), (2, 33, 5, 77, 120.0)]
+# The last three rows are the wide shapes: 1280 = BASELINE configs[4] (384 x 1280, N = 96: the 512-thread strided forms and, for a 16-bit
+# gradient, the wave-neighbour backward), 1242 = native KITTI width (W % 4 = 2: the first-generation kernels take it), 2100 = wider than any
+# staged form.  test_med_head_cases_cover_every_head_kernel checks that the list reaches every kernel the three entry points can dispatch to.
+HEAD_CASES = [(2, 7, 6, 40, 30.0), (2, 49, 4, 128, 300.0), (1, 49, 3, 512, 300.0), (1, 96, 2, 320, 300.0), (2, 33, 5, 77, 120.0),
+              (1, 96, 2, 1280, 300.0), (1, 49, 2, 1242, 300.0), (1, 7, 1, 2100, 300.0)]
+HEAD_KERNELS = {"med_head_fwd_lds2_kernel", "med_head_fwd_lds2_kernel<512 threads>", "med_head_fwd_lds_kernel", "med_head_fwd_kernel",
+                "med_head_bwd_kernel<planar>", "med_head_bwd_lds2_kernel", "med_head_bwd_lds2_kernel<512 threads>", "med_head_bwd_wave_kernel",
+                "med_head_bwd_lds_kernel", "med_head_bwd_kernel<nhwc>"}
+
+
+def head_kernel(pas, dt, N, W):
+    import ctypes
+    buf = ctypes.create_string_buffer(96)
+    L.check(L.lib().falnet_med_head_kernel_name(pas, L.dtype_code(dt), N, W, buf, 96))
+    return buf.value.decode()
+
+
+def test_med_head_cases_cover_every_head_kernel():
+    seen = set()
+    for B, N, H, W, maxd in HEAD_CASES:
+        seen.add(head_kernel(0, torch.float32, N, W))
+        seen.add(head_kernel(1, torch.float32, N, W))
+        seen |= {head_kernel(2, dt, N, W) for dt in (torch.float32, torch.bfloat16, torch.float16)}
+    assert seen == HEAD_KERNELS, (seen ^ HEAD_KERNELS)
+    # BASELINE configs[4]: 16-bit gradient on the wave-neighbour kernel, f32 and the forward on the 512-thread strided forms
+    assert head_kernel(2, torch.float16, 96, 1280) == "med_head_bwd_wave_kernel" == head_kernel(2, torch.bfloat16, 96, 1280)
+    assert head_kernel(2, torch.float32, 96, 1280) == "med_head_bwd_lds2_kernel<512 threads>"
+    assert head_kernel(0, torch.float32, 96, 1280) == "med_head_fwd_lds2_kernel<512 threads>"
+    assert head_kernel(0, torch.float32, 49, 1242) == "med_head_fwd_lds_kernel" and head_kernel(2, torch.float16, 49, 1242) == "med_head_bwd_kernel<nhwc>"
 
 
 @pytest.mark.parametrize("B,N,H,W,maxd", HEAD_CASES)

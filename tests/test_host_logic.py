@@ -158,3 +158,33 @@ def test_real_data_loader_on_generated_pngs(tmp_path):
     assert x.shape == (1, 3, 375, 1242) and abs(float(x[0, 1].mean()) - (float(left[..., 1].float().mean()) / 255 - 0.432)) < 1e-5
     with pytest.raises(FileNotFoundError):
         DS.read_pair_list(str(tmp_path / "nope.txt"), kroot)
+
+
+def test_test_kitti_accepts_the_reference_command_line():
+    """Every flag of the reference's parser (reference Test_KITTI.py:36-60) parses with its meaning: -m is the model name, the checkpoint
+    is <-dt>/<-ts>/<-m><-dtl> (:119-120), the booleans take a value, the dump switches are refused when true."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("Test_KITTI_entry", os.path.join(os.path.dirname(__file__), "..", "Test_KITTI.py"))
+    tk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tk)
+    d = tk.parser.parse_args([])  # the reference's defaults
+    assert (d.tdataName, d.max_disp, d.min_disp, d.batch_size, d.evaluate, d.save, d.save_pc, d.save_pan, d.save_input, d.workers, d.sparse,
+            d.print_freq, d.dataset, d.time_stamp, d.model, d.no_levels, d.details, d.f_post_process, d.ms_post_process, d.median, d.rel_baselne) == \
+        ("Kitti_eigen_test_improved", 300, 2, 1, True, False, False, False, False, 4, False, 10, "Kitti_stage2", "10-18-15_42", "FAL_netB", 49,
+         ",e20es,b4,lr5e-05/checkpoint.pth.tar", False, True, False, 1)
+    assert tk.checkpoint_path(d) == os.path.join("Kitti_stage2", "10-18-15_42", "FAL_netB,e20es,b4,lr5e-05/checkpoint.pth.tar")
+    a = tk.parser.parse_args(["-d", "/data", "-tn", "Kitti2015", "-relbase", "0.5", "-mdisp", "192", "-mindisp", "1", "-b", "2", "-eval", "False",
+                              "-save", "False", "-save_pc", "False", "-save_pan", "False", "-save_input", "False", "-w", "2", "--sparse", "-p", "5",
+                              "-gpu_no", "3", "-dt", "Kitti_stage1", "-ts", "01-02-03_04", "-m", "FAL_netC", "-no_levels", "33", "-dtl", "/model_best.pth.tar",
+                              "-fpp", "True", "-mspp", "False", "-median", "True"])
+    assert (a.max_disp, a.min_disp, a.rel_baselne, a.evaluate, a.f_post_process, a.ms_post_process, a.median, a.gpu_no, a.model) == \
+        (192.0, 1.0, 0.5, False, True, False, True, "3", "FAL_netC")
+    assert tk.checkpoint_path(a) == os.path.join("Kitti_stage1", "01-02-03_04", "FAL_netC/model_best.pth.tar")
+    tk.refuse_out_of_scope(a)
+    assert tk.checkpoint_path(tk.parser.parse_args(["--checkpoint", "x.pth.tar"])) == "x.pth.tar"
+    for flag in ("-save", "-save_pc", "-save_pan", "-save_input"):
+        with pytest.raises(SystemExit, match="out of scope"):
+            tk.refuse_out_of_scope(tk.parser.parse_args([flag, "True"]))
+    with pytest.raises(SystemExit):  # the round-3 spellings are gone: -m is no longer a path, -maxd never was a reference flag
+        tk.parser.parse_args(["-maxd", "300"])
