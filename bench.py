@@ -210,6 +210,23 @@ def parity_vs_oracle(height, width, levels, dev):
     return out
 
 
+def abs_rel_vs_ground_truth(args, steps=200):
+    """`abs_rel` where a ground truth exists: `steps` Stage-1 steps at the benchmark's own batch and size on STRUCTURED synthetic stereo
+    (fal_net_amd.synthetic.structured_stereo: right view = left view displaced by a smooth known disparity; pool of 4 batches), from the
+    seeded weights, per compute dtype; depth abs_rel (myUtils.py:225) of the trained model's disparity against the known one.  After the
+    timed region; tools/trajectory.py is the long form (profiles/r04_trajectory_*.json)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("trajectory", os.path.join(ROOT, "tools", "trajectory.py"))
+    traj = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(traj)
+    r = traj.run(steps=steps, height=args.height, width=args.width, batch=args.batch, pool=4, levels=args.levels, dtypes=("f32", "bf16", "f16"))
+    out = {k: {"abs_rel_vs_gt": r[k]["abs_rel_vs_gt"], "abs_rel_vs_gt_heldout": r[k]["abs_rel_vs_gt_heldout"], "loss_last": r[k]["loss_last"]} for k in ("f32", "bf16", "f16")}
+    out["at_seeded_weights"] = r["f32"]["abs_rel_vs_gt_start"]
+    out["sample"] = (f"{steps} Stage-1 steps, B={args.batch}, {args.height}x{args.width}, N={args.levels}, pool of 4 structured synthetic batches with known "
+                     "disparity, Adam lr 1e-4; depth abs_rel of the trained model vs ground truth (training pool / 2 held-out batches of 2)")
+    return out
+
+
 def allreduce_report(model, step, args, world, rank, dev, ms_per_step):
     """The step's single collective, measured after the timed region (every rank takes part; rank 0 reports):
       * `param_checksum_equal`: the flat parameter buffers of all ranks are still bit-identical after the timed steps (a racing
@@ -295,6 +312,7 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-trajectory", action="store_true", help="skip the abs_rel_vs_gt leg (200 training steps per dtype on structured stereo, ~15 s)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed profiles/ file instead of two live rocprofv3 --pmc child passes (~25 s each)")
     ap.add_argument("--graph", action="store_true",
@@ -450,6 +468,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.workload, args.height, args.width, args.levels)
         result["abs_rel_vs_ref"] = parity_vs_oracle(args.height, args.width, args.levels, dev)
+    if rank == 0 and world == 1 and args.workload == "stage1" and not args.no_trajectory and not args.no_cpu_baseline:
+        result["abs_rel_vs_gt"] = abs_rel_vs_ground_truth(args)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

@@ -132,6 +132,13 @@ class FalnetPlan:
         self._side = self._side_stream = None
         self._side_pending, self._side_events, self._side_ev_next = [], [], 0
         self._side_batch = max(1, int(L.ab("FALNET_SIDE_BATCH", "2")))
+        # third stream of backward: the weight gradients of the small deep maps (levels 4-6: 12-30 us launches that fill a fraction of
+        # the chip and are latency-, not throughput-bound).  Queued behind the big decoder weight gradients on the side stream they
+        # lengthen the LONGER chain of backward by ~0.3 ms while the chip idles; on a stream of their own they run beside both chains.
+        self._deep = self._deep_stream = None
+        self._deep_pending, self._deep_events, self._deep_ev_next, self._deep_dirty = [], [], 0, False
+        self._deep_batch = max(1, int(L.ab("FALNET_DEEP_BATCH", "3")))
+        self._deep_max_px = int(L.ab("FALNET_DEEP_STREAM_PX", "512"))  # maps of at most this many positions (16 x 32 = level 4); 0 = off
         self.buf = {}
         self.fwd, self.bwd_head, self.bwd_body, self.pack = [], [], [], []
         self._build()
@@ -262,8 +269,52 @@ class FalnetPlan:
         if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
             self._main_tail = getattr(self, "_main_tail", [])
             self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)
+        elif OH * OW <= self._deep_max_px:
+            self._deep_call(call)
         else:
             self._side_call(call)
+
+    def _deep_call(self, call):
+        """A small weight gradient for the third stream (see __init__); handed over in groups like the side stream's launches."""
+        def run(c=call):
+            if self._deep_stream is None:
+                c()
+                return
+            self._deep_pending.append(c)
+            if len(self._deep_pending) >= self._deep_batch:
+                self._flush_deep()
+        self.bwd_body.append(run)
+
+    def _event(self, pool, index):
+        if index == len(pool):
+            pool.append(torch.cuda.Event())
+        return pool[index]
+
+    def _flush_deep(self):
+        pend, deep = self._deep_pending, self._deep_stream
+        if not pend:
+            return
+        ev = self._event(self._deep_events, self._deep_ev_next)
+        self._deep_ev_next += 1
+        ev.record()  # main stream: behind the producer of the group's last gradient
+        deep.wait_event(ev)
+        with L.on_stream(deep):
+            for c in pend:
+                c()
+        pend.clear()
+        self._deep_dirty = True
+
+    def _join_deep(self, stream):
+        """`stream` waits for everything the third stream has been given so far (a bucket's slab reduce reads those slabs)."""
+        if self._deep_stream is None:
+            return
+        self._flush_deep()
+        if self._deep_dirty:
+            ev = self._event(self._deep_events, self._deep_ev_next)
+            self._deep_ev_next += 1
+            ev.record(self._deep_stream)
+            stream.wait_event(ev)
+            self._deep_dirty = False
 
     def _side_call(self, call):
         """Weight gradients are off the data-gradient critical path: run them on a side HIP stream so they fill the
@@ -554,17 +605,25 @@ class FalnetPlan:
                         # last bucket: the bias gradients only need the data gradients -> main stream (idle by now), beside the
                         # side stream's last weight gradients and slab reduce; run_backward fires the bucket hook after the join
                         self.bwd_body.append(bias)
-                        self._side_call(red)
+
+                        def last_reduce(red=red):
+                            self._join_deep(torch.cuda.current_stream())
+                            red()
+                        last_reduce.needs_torch_stream = True
+                        self.bwd_body.append(lambda: self._deep_stream is not None and self._flush_deep())  # (from the main stream's context)
+                        self._side_call(last_reduce)
                         self._deferred_ready = bucket
                         continue
 
                     def finish(red=red, bias=bias, bucket=bucket):
+                        self._join_deep(torch.cuda.current_stream())  # (the side stream: needs_torch_stream below)
                         red()
                         bias()
                         if bucket == 0 and getattr(self.model, "_compose_logits", False):
                             self._split_logits_grad()
                         self.model._bucket_ready(bucket)
                     finish.needs_torch_stream = True
+                    self.bwd_body.append(lambda: self._deep_stream is not None and self._flush_deep())  # (from the main stream's context)
                     self._side_call(finish)
             self.bwd_body.extend(body[pos:])
 
@@ -639,14 +698,21 @@ class FalnetPlan:
                 self._side = torch.cuda.Stream(device=self.device)
             self._side_stream = self._side
             self._side_stream.wait_stream(main)  # the previous step's Adam / repack must not be overtaken
+            if self._deep_max_px > 0:
+                if self._deep is None:
+                    self._deep = torch.cuda.Stream(device=self.device)
+                self._deep_stream = self._deep
+                self._deep_stream.wait_stream(main)
         else:
-            self._side_stream = None
-        self._side_ev_next = 0
+            self._side_stream = self._deep_stream = None
+        self._side_ev_next = self._deep_ev_next = 0
+        self._deep_dirty = False
         with L.stream_scope():  # one stream lookup for the whole replay; side calls redirect their launches with L.on_stream
             self.head_bwd[(g_disp is not None, g_pan is not None)]()
             for call in self.bwd_body:
                 call()
             self._flush_side()
+            self._join_deep(main)
         if self._side_stream is not None:
             main.wait_stream(self._side_stream)
         if getattr(self, "_deferred_ready", None) is not None:

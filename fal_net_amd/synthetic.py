@@ -109,3 +109,40 @@ def synthetic_pair(batch, height, width, seed=1234, max_disp=300.0, distinct=Fal
         md = md * (1.0 - 0.1 * torch.arange(batch, dtype=torch.float32).view(batch, 1, 1) / max(batch, 1))
     min_disp = md * 2.0 / 300.0  # Train_Stage1_K.py:237 with the default --min_disp 2 --max_disp 300
     return left, right, min_disp, md
+
+
+def structured_stereo(batch, height, width, seed=77, d_lo=3.0, d_hi=24.0, max_disp=300.0):
+    """A stereo pair with a KNOWN disparity field (seeded, no dataset): a band-limited textured left image and a smooth right-view
+    disparity d_r in [d_lo, d_hi] pixels (larger towards the bottom, as on a road scene, plus two low-frequency bumps per sample);
+    the right image is the left one sampled at x + d_r(x, y) (the geometry the network's plane sweep synthesises:
+    models/FAL_netB.py:255-262).  The Stage-1 loss then has a defined minimum and the trained disparity can be scored against ground
+    truth (tools/trajectory.py).  Returns left, right, min_disp, max_disp as synthetic_pair does, plus the ground-truth LEFT-view
+    disparity (B, 1, H, W): d_l(x + d_r(x)) = d_r(x), solved by fixed-point iteration (|d d_r / dx| << 1: no occlusions)."""
+    g = torch.Generator().manual_seed(seed)
+    F = torch.nn.functional
+
+    def band(ch, cells, amp):  # smooth random field: coarse noise, bicubic up (CPU data synthesis, not on the hot path)
+        z = torch.rand(batch, ch, max(2, height // cells), max(2, width // cells), generator=g)
+        return amp * F.interpolate(z, size=(height, width), mode="bicubic", align_corners=True)
+    left = (band(3, 32, 0.45) + band(3, 8, 0.35) + band(3, 3, 0.25) + 0.1 * torch.rand(batch, 3, height, width, generator=g)).clamp(0, 1.2) / 1.2
+    yy = torch.linspace(0, 1, height).view(1, 1, height, 1)
+    xx = torch.linspace(0, 1, width).view(1, 1, 1, width)
+    cx, cy = torch.rand(batch, 2, 1, 1, generator=g), torch.rand(batch, 2, 1, 1, generator=g)
+    bumps = sum(torch.exp(-(((xx - cx[:, i:i + 1]) / 0.25) ** 2 + ((yy - cy[:, i:i + 1]) / 0.3) ** 2)) for i in range(2))
+    rel = (0.15 + 0.55 * yy ** 1.5 + 0.3 * bumps / 2).clamp(0, 1)
+    d_r = d_lo + (d_hi - d_lo) * rel  # (B, 1, H, W)
+    xs = torch.arange(width, dtype=torch.float32).view(1, 1, 1, width)
+
+    def sample_x(img, pos):  # img (B, C, H, W) at fractional columns pos (B, 1, H, W), zero outside
+        x0 = pos.floor()
+        a = pos - x0
+        i0, i1 = x0.long(), x0.long() + 1
+        v0 = torch.gather(img, 3, i0.clamp(0, width - 1).expand_as(img)) * ((i0 >= 0) & (i0 < width))
+        v1 = torch.gather(img, 3, i1.clamp(0, width - 1).expand_as(img)) * ((i1 >= 0) & (i1 < width))
+        return v0 * (1 - a) + v1 * a
+    right = sample_x(left, xs + d_r)
+    d_l = d_r.clone()
+    for _ in range(8):  # d_l(x) = d_r(x - d_l(x))
+        d_l = sample_x(d_r, (xs - d_l).clamp(0, width - 1))
+    md = torch.full((batch, 1, 1), float(max_disp))
+    return left - 0.43, right - 0.43, md * 2.0 / 300.0, md, d_l

@@ -328,24 +328,37 @@ def test_pack_after_optimizer_tracks_weight_changes(monkeypatch):
 
 
 def test_reduced_precision_trains_like_f32():
-    """60 Stage-1 steps on a cycled pool of seeded batches from the same weights, in f32, bf16 and f16 (tools/trajectory.py;
-    the 200-step 128x256 run is quoted in DESIGN.md): the 16-bit paths must reach the f32 path's loss within a few per cent and
-    their trained models must predict the f32-trained model's depth to a few per cent."""
+    """300 Stage-1 steps on STRUCTURED synthetic stereo (synthetic.structured_stereo: the right view is the left one displaced by a smooth
+    known disparity, so the self-supervised loss has a defined minimum and ground truth exists), from the same seeded weights, in f32, bf16
+    and f16 (tools/trajectory.py; the 600-step run and the deterministic control are in profiles/r04_trajectory_*.json).  The f32 path must
+    LEARN the disparity (depth abs_rel against ground truth 0.70 at the seeded weights -> < 0.12), and each 16-bit path must reach
+    <= 1.5 x the f32 value: a broken 16-bit kernel does not train to ground truth (round 3's bounds on noise images could not tell)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("trajectory", os.path.join(os.path.dirname(__file__), "..", "tools", "trajectory.py"))
     traj = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(traj)
-    r = traj.run(steps=60, height=64, width=128, batch=2, pool=4, levels=49)
+    r = traj.run(steps=300, height=128, width=256, batch=4, pool=8, levels=49, dtypes=("f32", "bf16", "f16"))
     print(r)
-    assert r["f32"]["finite"] and r["f32"]["loss_last"] < r["f32"]["loss_first"]
-    ctrl = r["f32_again"]["depth_abs_rel_vs_f32_model"]  # run-to-run distance of two f32 trainings (atomics reorder sums)
-    # Ten repetitions of this run on one box (round 3): control 0.09-0.14, bf16 0.12-0.28, f16 0.11-0.27 in depth, |loss difference| <= 1.4 %
-    # in every column (the synthetic noise images leave the disparity field weakly determined, so trajectories separate): the bounds
-    # catch a path that stops training or drifts away, not a ranking of the three
+    f32 = r["f32"]
+    assert f32["finite"] and f32["loss_last"] < 0.6 * f32["loss_first"]
+    assert f32["abs_rel_vs_gt_start"] > 0.4 and f32["abs_rel_vs_gt"] < 0.12, f32
     for k in ("bf16", "f16"):
-        assert r[k]["finite"] and r[k]["loss_last"] < r[k]["loss_first"]
-        assert abs(r[k]["loss_last_rel_to_f32"]) < 0.04, (k, r[k])
-        assert r[k]["depth_abs_rel_vs_f32_model"] < max(0.5, 4 * ctrl), (k, r[k], ctrl)
+        assert r[k]["finite"] and r[k]["loss_last"] < 0.6 * r[k]["loss_first"], (k, r[k])
+        assert r[k]["abs_rel_vs_gt"] <= 1.5 * f32["abs_rel_vs_gt"] + 0.005, (k, r[k]["abs_rel_vs_gt"], f32["abs_rel_vs_gt"])
+        assert r[k]["abs_rel_vs_gt_heldout"] <= 1.5 * f32["abs_rel_vs_gt_heldout"] + 0.01, (k, r[k], f32)
+
+
+def test_deterministic_f32_trajectories_are_identical():
+    """The control of the trajectory evidence: two fresh processes with FALNET_DETERMINISTIC=1 train bit-identical models (distance 0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "trajectory.py"), "--control", "--steps", "40", "--height", "64", "--width", "128",
+                        "--batch", "2", "--pool", "4"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["bit_identical"] and out["disp_max_abs_diff"] == 0.0, out
 
 
 def test_stage2_step_256x512_vs_oracle():
