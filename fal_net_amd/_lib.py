@@ -112,6 +112,7 @@ SIGNATURES = {
     "falnet_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "falnet_upsample_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "falnet_wgrad_const_plane": [_P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "falnet_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_act_bwd": [_P, _P, _P, _L, _I, _I, _P],

@@ -252,6 +252,107 @@ extern "C" int falnet_upsample_bwd(const void* gup, void* gsrc, const void* acto
     FALNET_RETURN_LAUNCH();
 }
 
+// ---- weight gradient of a 3x3 conv (pad 1, stride 1 or 2) with respect to a PER-SAMPLE CONSTANT input plane ---------------------------
+// The `flow` input of conv1 (FAL_netB.py:208-209,101: max_disp / 100 broadcast over the image) is one value f_b per sample, so
+//   dW[co][ky][kx] = sum_b f_b * sum_{(i,j): tap (ky,kx) in bounds} g[b][i][j][co]
+// and the inner sum is the whole-image sum S minus the first / last row and column sums the tap's zero padding cuts off (inclusion-
+// exclusion with the four corners).  Nine sums per (sample, channel) replace a 32-channel padded K tile of the stride-2 weight-gradient
+// kernel (half of conv1's launch: 31 zero channels beside the one real one).
+//   stats kernel:   ws[b][k][c] += partial sums, k = S, top row, bottom row, left col, right col, tl, tr, bl, br
+//   combine kernel: one block; adds into the f32 OIHW gradient and leaves ws ZERO again (it is zero on entry by contract).
+template <typename T>
+__global__ __launch_bounds__(256) void const_plane_stats_kernel(const T* __restrict__ g, float* __restrict__ ws, int TH, int TW, int gC, int rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int b = blockIdx.y, segs = gC >> 3, npl = 256 / segs;
+    const int seg = threadIdx.x % segs, pl = threadIdx.x / segs;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, TH);
+    float st[9][8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[k][i] = 0.f;
+    if (pl < npl) {
+        for (int y = r0; y < r1; ++y) {
+            const bool top = y == 0, bot = y == TH - 1;
+            const T* row = g + (((int64_t)b * TH + y) * TW) * gC + seg * 8;
+            for (int x = pl; x < TW; x += npl) {
+                float v[8];
+                load8_as(row + (int64_t)x * gC, v);
+                const bool lf = x == 0, rt = x == TW - 1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    st[0][i] += v[i];
+                    if (top) st[1][i] += v[i];
+                    if (bot) st[2][i] += v[i];
+                    if (lf) st[3][i] += v[i];
+                    if (rt) st[4][i] += v[i];
+                    if (top && lf) st[5][i] += v[i];
+                    if (top && rt) st[6][i] += v[i];
+                    if (bot && lf) st[7][i] += v[i];
+                    if (bot && rt) st[8][i] += v[i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = st[k][i];
+        __syncthreads();
+        if ((int)threadIdx.x < gC) {
+            const int c = threadIdx.x, sg = c >> 3, i = c & 7;
+            float t = 0.f;
+            for (int q = 0; q < npl; ++q) t += red[(q * segs + sg) * 8 + i];
+            if (t != 0.f) atomicAdd(ws + ((int64_t)b * 9 + k) * gC + c, t);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void const_plane_combine_kernel(float* __restrict__ ws, const T* __restrict__ plane, int64_t plane_stride, float* __restrict__ grad,
+                                                                   int64_t co_stride, int B, int gC, int cout, int ex_bot, int ex_rt) {
+    for (int e = threadIdx.x; e < cout * 9; e += blockDim.x) {
+        const int co = e / 9, tap = e - co * 9, ky = tap / 3, kx = tap - ky * 3;
+        const float et = ky == 0 ? 1.f : 0.f, eb = ((ex_bot >> ky) & 1) ? 1.f : 0.f, el = kx == 0 ? 1.f : 0.f, er = ((ex_rt >> kx) & 1) ? 1.f : 0.f;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* w = ws + (int64_t)b * 9 * gC + co;
+            const float s = w[0] - et * w[gC] - eb * w[2 * gC] - el * w[3 * gC] - er * w[4 * gC] + et * el * w[5 * gC] + et * er * w[6 * gC] +
+                            eb * el * w[7 * gC] + eb * er * w[8 * gC];
+            acc += to_f32(plane[b * plane_stride]) * s;
+        }
+        atomicAdd(grad + co * co_stride + tap, acc);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * 9 * gC; e += blockDim.x) ws[e] = 0.f;
+}
+
+extern "C" int falnet_wgrad_const_plane(const void* gout, const void* plane, int64_t plane_stride, float* grad, int64_t grad_co_stride, float* ws, int B,
+                                        int TH, int TW, int gC, int cout, int IH, int IW, int stride, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(gout && plane && grad && ws && B > 0 && TH >= 2 && TW >= 2 && gC % 8 == 0 && gC <= 256 && cout > 0 && cout <= gC,
+                     "wgrad_const_plane: bad argument (B=%d TH=%d TW=%d gC=%d cout=%d)", B, TH, TW, gC, cout);
+    FALNET_CHECK_ARG((stride == 1 || stride == 2) && TH == (IH + stride - 1) / stride && TW == (IW + stride - 1) / stride,
+                     "wgrad_const_plane: a 3x3 pad-1 conv of stride %d maps %dx%d to %dx%d, not %dx%d", stride, IH, IW, (IH + stride - 1) / stride,
+                     (IW + stride - 1) / stride, TH, TW);
+    FALNET_CHECK_ARG(!falnet_deterministic(), "wgrad_const_plane adds with f32 atomics: not available in deterministic mode");
+    int ex_bot = 0, ex_rt = 0;  // bit k: tap row / column k reads beyond the last input row / column from the last output row / column
+    for (int k = 0; k < 3; ++k) {
+        if ((TH - 1) * stride + k - 1 >= IH) ex_bot |= 1 << k;
+        if ((TW - 1) * stride + k - 1 >= IW) ex_rt |= 1 << k;
+    }
+    const int rows_per_block = TH >= 64 ? 4 : 1;
+    const dim3 grid((unsigned)((TH + rows_per_block - 1) / rows_per_block), (unsigned)B);
+#define EW_L(T)                                                                                                                                         \
+    hipLaunchKernelGGL(const_plane_stats_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)gout, ws, TH, TW, gC, rows_per_block);           \
+    hipLaunchKernelGGL(const_plane_combine_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, ws, (const T*)plane, plane_stride, grad, grad_co_stride, \
+                       B, gC, cout, ex_bot, ex_rt)
+    FALNET_DISPATCH_DTYPE(dtype, EW_L);
+#undef EW_L
+    FALNET_RETURN_LAUNCH();
+}
+
 extern "C" int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(x && y && B > 0 && H >= 2 && W >= 2 && C > 0, "maxpool2_fwd: bad argument");

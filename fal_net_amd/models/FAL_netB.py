@@ -263,9 +263,30 @@ class FalnetPlan:
             for c in calls:
                 self._side_call(c)
             return
-        call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
-                               pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
-                               bucket=self._bucket)
+        if (len(srcs) == 2 and srcs[1].sy == 0 and srcs[1].sx == 0 and pc.groups_real[1] == 1 and pc.taps == 9 and self.dtype in ops.H16
+                and not ops.DETERMINISTIC and OH >= 2 and OW >= 2 and L.ab("FALNET_FLOW_WGRAD", "1") == "1"):
+            # conv1 over concat(conv0_1 output, `flow`): the second source is ONE real channel, constant per sample, padded to 32 -- half of the
+            # stride-2 launch's K tiles multiply zeros.  The image source alone goes through the MFMA kernel; the flow channel's nine weights
+            # per output channel come from nine masked sums of the gradient (falnet_wgrad_const_plane), added straight into its column of dW.
+            c_real, c_pad = pc.groups_real[0], pc.groups_pad[0]
+            main_call = self.wbatch.add([srcs[0]], IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
+                                        _WgradPart(pc, c_real, c_pad), gw, gb, name="wgrad " + name,
+                                        flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps, bucket=self._bucket)
+            flow_t, gC = self.buf["flow"], gout.shape[3]
+            ws = torch.zeros(self.B * 9 * gC, dtype=torch.float32, device=self.device)  # zero on entry, left zero by the kernel
+            self.buf["flow_wgrad_ws"] = ws
+            plane_call = ops.simple_call("falnet_wgrad_const_plane", L.ptr(gout), L.ptr(flow_t), flow_t.stride(0), L.ptr(gw[:, c_real:]),
+                                         pc.cin * 9, L.ptr(ws), self.B, OH, OW, gC, pc.cout, IH, IW, pc.stride, L.dtype_code(self.dtype),
+                                         name="wgrad " + name + "[flow plane]")
+
+            def call(main_call=main_call, plane_call=plane_call):
+                main_call()
+                plane_call()
+            call.tag, call.flops, call.name = main_call.tag, main_call.flops, main_call.name
+        else:
+            call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
+                                   pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
+                                   bucket=self._bucket)
         if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
             self._main_tail = getattr(self, "_main_tail", [])
             self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)

@@ -272,6 +272,12 @@ int falnet_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W,
  * gsrc[b, sy, sx, c] = (sum over virtual pixels mapping to (sy,sx) of gup[b, vy, vx, c]) * elu'(actout) */
 int falnet_upsample_bwd(const void* gup, void* gsrc, const void* actout, int B, int IH, int IW,
                         int H, int W, int C, int dtype, void* stream);
+/* Weight gradient of a 3x3 pad-1 conv (stride 1 or 2) with respect to an input plane that is CONSTANT per sample -- the `flow` input of
+ * conv1 (FAL_netB.py:208-209, :101): dW[co][ky][kx] += sum_b plane[b * plane_stride] * sum over the output pixels whose tap (ky,kx) is in
+ * bounds of gout[b][i][j][co].  gout NHWC `dtype` [B][TH][TW][gC]; grad = &dW_oihw[0][ci][0][0] of the f32 gradient, grad_co_stride = Cin * 9;
+ * ws: B * 9 * gC floats, ZERO on entry and left zero.  Adds with f32 atomics (refused in deterministic mode). */
+int falnet_wgrad_const_plane(const void* gout, const void* plane, int64_t plane_stride, float* grad, int64_t grad_co_stride, float* ws,
+                             int B, int TH, int TW, int gC, int cout, int IH, int IW, int stride, int dtype, void* stream);
 /* 2x2/2 max pool on NHWC (torchvision VGG19 features[4,9,18]; loss_functions.py:21-29) and its adjoint */
 int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy, void* gx, int B, int H, int W, int C,

@@ -677,6 +677,33 @@ def test_upsample_bwd_and_pool():
 # The last three rows are the wide shapes: 1280 = BASELINE configs[4] (384 x 1280, N = 96: the 512-thread strided forms and, for a 16-bit
 # gradient, the wave-neighbour backward), 1242 = native KITTI width (W % 4 = 2: the first-generation kernels take it), 2100 = wider than any
 # staged form.  test_med_head_cases_cover_every_head_kernel checks that the list reaches every kernel the three entry points can dispatch to.
+@pytest.mark.parametrize("B,IH,IW,stride,gC,cout", [(2, 64, 128, 2, 64, 64), (3, 75, 250, 2, 64, 49), (2, 20, 36, 1, 32, 32), (1, 9, 11, 2, 32, 17)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_const_plane(B, IH, IW, stride, gC, cout, dtype):
+    """Weight gradient with respect to a per-sample constant input plane (conv1's `flow` channel, FAL_netB.py:101,208-209) from nine masked
+    sums of the output gradient, against autograd of F.conv2d over the broadcast plane (zero padding 1; even and odd sizes, both strides)."""
+    g = torch.Generator().manual_seed(B * 1000 + IW)
+    TH, TW = (IH + stride - 1) // stride, (IW + stride - 1) // stride
+    f = (torch.rand(B, generator=g) * 3 + 0.5).to(dtype).float()
+    gout = torch.randn(B, TH, TW, gC, generator=g).to(dtype)
+    w = torch.zeros(cout, 1, 3, 3, requires_grad=True)
+    y = F.conv2d(f.view(B, 1, 1, 1).expand(B, 1, IH, IW), w, stride=stride, padding=1)
+    (y * gout.float()[..., :cout].permute(0, 3, 1, 2)).sum().backward()
+    cin = 5  # the plane is input channel 3 of a 5-channel OIHW gradient: only that column may change
+    grad = torch.full((cout, cin, 3, 3), 7.0, device=DEV)
+    plane = torch.zeros(B, 32, dtype=dtype, device=DEV)
+    plane[:, 0] = f.to(DEV).to(dtype)
+    ws = torch.zeros(B * 9 * gC, device=DEV)
+    gd = gout.to(DEV)
+    for rep in range(2):  # twice: the kernel must leave its workspace zero, and it ADDS
+        L.check(L.lib().falnet_wgrad_const_plane(L.ptr(gd), L.ptr(plane), plane.stride(0), L.ptr(grad[:, 3:]), cin * 9, L.ptr(ws), B, TH, TW, gC, cout,
+                                                 IH, IW, stride, L.dtype_code(dtype), L.stream_ptr()))
+    assert float(ws.abs().max()) == 0.0
+    got = (grad[:, 3] - 7.0) / 2
+    assert rel(got, w.grad[:, 0]) < 2e-5
+    assert float((grad[:, [0, 1, 2, 4]] - 7.0).abs().max()) == 0.0
+
+
 HEAD_CASES = [(2, 7, 6, 40, 30.0), (2, 49, 4, 128, 300.0), (1, 49, 3, 512, 300.0), (1, 96, 2, 320, 300.0), (2, 33, 5, 77, 120.0),
               (1, 96, 2, 1280, 300.0), (1, 49, 2, 1242, 300.0), (1, 7, 1, 2100, 300.0)]
 HEAD_KERNELS = {"med_head_fwd_lds2_kernel", "med_head_fwd_lds2_kernel<512 threads>", "med_head_fwd_lds_kernel", "med_head_fwd_kernel",
