@@ -132,13 +132,18 @@ class FalnetPlan:
         self._side = self._side_stream = None
         self._side_pending, self._side_events, self._side_ev_next = [], [], 0
         self._side_batch = max(1, int(L.ab("FALNET_SIDE_BATCH", "2")))
-        # third stream of backward: the weight gradients of the small deep maps (levels 4-6: 12-30 us launches that fill a fraction of
-        # the chip and are latency-, not throughput-bound).  Queued behind the big decoder weight gradients on the side stream they
-        # lengthen the LONGER chain of backward by ~0.3 ms while the chip idles; on a stream of their own they run beside both chains.
+        # third stream of backward: every weight gradient below full resolution (levels 1-6).  The deep ones (levels 4-6) are 12-30 us
+        # launches that fill a fraction of the chip and are latency-, not throughput-bound; queued behind the big full-resolution weight
+        # gradients on the side stream they lengthen the LONGER chain of backward by ~0.3 ms while the chip idles.  With the side stream
+        # keeping only the full-resolution layers (logits, deconv1, level 0) and this stream everything else, two weight-gradient chains
+        # of 128 workgroups each run beside the data gradients: same-box A/B -1.7 % on the step (profiles/r04_ab_wgrad_streams.txt:
+        # levels 4-6 only -0.7 %, levels 3-6 -1.0 %, levels 1-6 -1.7 %, everything on this stream or alternating launches: worse).
         self._deep = self._deep_stream = None
         self._deep_pending, self._deep_events, self._deep_ev_next, self._deep_dirty = [], [], 0, False
         self._deep_batch = max(1, int(L.ab("FALNET_DEEP_BATCH", "3")))
-        self._deep_max_px = int(L.ab("FALNET_DEEP_STREAM_PX", "512"))  # maps of at most this many positions (16 x 32 = level 4); 0 = off
+        self._deep_alt = L.ab("FALNET_DEEP_ALT", "0") == "1"  # experiment: every second larger weight gradient on the third stream as well
+        self._alt_n = 0
+        self._deep_max_px = int(L.ab("FALNET_DEEP_STREAM_PX", str(H * W // 4)))  # maps of at most this many positions (level 1 and below); 0 = off
         self.buf = {}
         self.fwd, self.bwd_head, self.bwd_body, self.pack = [], [], [], []
         self._build()
@@ -290,10 +295,14 @@ class FalnetPlan:
         if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
             self._main_tail = getattr(self, "_main_tail", [])
             self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)
-        elif OH * OW <= self._deep_max_px:
+        elif OH * OW <= self._deep_max_px or (self._deep_alt and self._alt_toggle()):
             self._deep_call(call)
         else:
             self._side_call(call)
+
+    def _alt_toggle(self):
+        self._alt_n += 1
+        return self._alt_n % 2 == 0
 
     def _deep_call(self, call):
         """A small weight gradient for the third stream (see __init__); handed over in groups like the side stream's launches."""
