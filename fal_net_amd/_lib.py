@@ -103,6 +103,9 @@ SIGNATURES = {
     "falnet_wgrad_reduce": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P],
     "falnet_bias_grad": [_P, _L, _I, _I, _P, _I, _I, _P],
     "falnet_pack_weights_batched": [_P, _I, _I, _I, _P],
+    "falnet_adam_pack_batched": [_P, _I, _I, _I, _L, _L, _L, _P, _F, _F, _F, _F, _P, _P],
+    "falnet_adam_ranges": [_P, _L, _L, _L, _P, _I, _P, _F, _F, _F, _F, _P, _P],
+    "falnet_adam_tick": [_P, _P, _P],
     "falnet_pack_up2_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_batched": [_P, _I, _I, _I, _P],
     "falnet_wgrad_reduce_blocks": [_I, _I, _I],

@@ -2587,8 +2587,15 @@ __global__ __launch_bounds__(256) void bias_grad_batched_kernel(const falnet_bia
 // One block = one 32(cout) x 32(packed cin) tile of one layer, all taps, staged through LDS: the OIHW reads are
 // runs of taps*32 contiguous floats, the wf rows ([co][tap][32 cin]) and wd rows ([cin][tap][32 cout]) are written as
 // 32 contiguous elements.  (The element-per-thread version gathered with stride `taps` and scattered 2-byte writes.)
-template <typename T, int TAPS>
-__device__ __forceinline__ void pack_tile(const falnet_pack_t& d, int rel, float (&tile)[32][32 * 9 + 1]) {
+// ADAM: the tile's master weights are UPDATED while they are loaded (torch.optim.Adam, Train_Stage1_K.py:177-180: the same arithmetic as
+// losses.hip: adam_dev_kernel) -- every real (co, ci, tap) element of a layer belongs to exactly one tile, so the optimiser step of all
+// packed layers and their re-pack are ONE pass over the masters (the stand-alone re-pack read the 68 MB Adam had just written again).
+struct PackAdam {
+    int64_t g_off, m_off, v_off;  // element offsets from a master weight to its gradient / first / second moment (the flat buffers share one layout)
+    float b1, b2, eps, grad_scale, step_size, rsqrt_bc2;
+};
+template <typename T, int TAPS, bool ADAM = false>
+__device__ __forceinline__ void pack_tile(const falnet_pack_t& d, int rel, float (&tile)[32][32 * 9 + 1], const PackAdam* ad = nullptr) {
     const int ctiles = d.cin_pad / 32;
     const int co0 = (rel / ctiles) * 32, cp0 = (rel % ctiles) * 32;
     constexpr int rowlen = 32 * TAPS;
@@ -2598,7 +2605,21 @@ __device__ __forceinline__ void pack_tile(const falnet_pack_t& d, int rel, float
     for (int e = threadIdx.x; e < 32 * rowlen; e += 256) {
         const int r = e / rowlen, k = e % rowlen;            // r: cout row of the tile, k = cil*TAPS + t
         const int co = co0 + r, ci = ci0 + k / TAPS;
-        tile[r][k] = (co < d.cout && ci < ci_end) ? d.w[((int64_t)co * d.cin + ci0) * TAPS + k] : 0.f;
+        float val = 0.f;
+        if (co < d.cout && ci < ci_end) {
+            float* wp = const_cast<float*>(d.w) + ((int64_t)co * d.cin + ci0) * TAPS + k;
+            val = *wp;
+            if constexpr (ADAM) {
+                const float gr = wp[ad->g_off] * ad->grad_scale;
+                const float m = ad->b1 * wp[ad->m_off] + (1.f - ad->b1) * gr;
+                const float v = ad->b2 * wp[ad->v_off] + (1.f - ad->b2) * gr * gr;
+                val -= ad->step_size * m / (sqrtf(v) * ad->rsqrt_bc2 + ad->eps);
+                *wp = val;
+                wp[ad->m_off] = m;
+                wp[ad->v_off] = v;
+            }
+        }
+        tile[r][k] = val;
     }
     __syncthreads();
     T* wf = reinterpret_cast<T*>(d.wf);
@@ -2652,6 +2673,30 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const falnet_
     else pack_tile<T, 1>(d, rel, tile);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void adam_pack_batched_kernel(const falnet_pack_t* __restrict__ descs, int n, int64_t g_off, int64_t m_off, int64_t v_off,
+                                                                const float* __restrict__ state, float b1, float b2, float eps, float grad_scale,
+                                                                const float* __restrict__ scaler) {
+    __shared__ float tile[32][32 * 9 + 1];
+    __shared__ int entry_begin[64];
+    if (scaler != nullptr) {
+        if (scaler[2] != 0.f) return;  // non-finite gradient somewhere: the whole update is skipped, the packed copies stay valid (grid-uniform)
+        grad_scale /= scaler[0];
+    }
+    const float t = state[1] + 1.0f;
+    PackAdam ad;
+    ad.g_off = g_off, ad.m_off = m_off, ad.v_off = v_off;
+    ad.b1 = b1, ad.b2 = b2, ad.eps = eps, ad.grad_scale = grad_scale;
+    ad.step_size = state[0] / (1.0f - powf(b1, t));
+    ad.rsqrt_bc2 = rsqrtf(1.0f - powf(b2, t));
+    const int li = find_entry(descs, n, entry_begin);
+    const falnet_pack_t d = descs[li];
+    const int rel = blockIdx.x - d.block_begin;
+    if (d.taps == 9) pack_tile<T, 9, true>(d, rel, tile, &ad);
+    else if (d.taps == 3) pack_tile<T, 3, true>(d, rel, tile, &ad);
+    else pack_tile<T, 1, true>(d, rel, tile, &ad);
+}
+
 // Sub-pixel weights of the deconv layers (conv_dma.hip: conv3x3_up2_dma_kernel): wu[co][pair][ci], pair = 4 (2 py + px) + 2 a + b
 template <typename T>
 __global__ __launch_bounds__(256) void pack_up2_batched_kernel(const falnet_pack_up2_t* __restrict__ descs, int n) {
@@ -2703,6 +2748,19 @@ extern "C" int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n
 #define PACK_B(T) hipLaunchKernelGGL(pack_weights_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n)
     FALNET_DISPATCH_DTYPE(dtype, PACK_B);
 #undef PACK_B
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_adam_pack_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, int64_t g_off, int64_t m_off, int64_t v_off,
+                                        const float* state, float b1, float b2, float eps, float grad_scale, const float* scaler, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(descs_dev && n > 0 && n <= 64 && total_blocks > 0 && state, "adam_pack_batched: bad argument (n <= 64)");
+    FALNET_CHECK_ARG(g_off != 0 && m_off != 0 && v_off != 0 && g_off != m_off && g_off != v_off && m_off != v_off,
+                     "adam_pack_batched: gradient / moment buffers must be distinct from the weights and from each other");
+#define APACK_B(T) hipLaunchKernelGGL(adam_pack_batched_kernel<T>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n, g_off, m_off, v_off, \
+                                      state, b1, b2, eps, grad_scale, scaler)
+    FALNET_DISPATCH_DTYPE(dtype, APACK_B);
+#undef APACK_B
     FALNET_RETURN_LAUNCH();
 }
 

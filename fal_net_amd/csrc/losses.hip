@@ -414,6 +414,29 @@ __global__ __launch_bounds__(RED_THREADS) void adam_dev_kernel(float* __restrict
         reinterpret_cast<float4*>(v)[i] = vv;
     }
 }
+// The same update over a list of element ranges of the flat buffer (the parameters falnet_adam_pack_batched does not own: biases, the two
+// factors of the composed logits weights): ranges[2 r] = first element, ranges[2 r + 1] = count; blockIdx.y = range.
+__global__ __launch_bounds__(RED_THREADS) void adam_ranges_kernel(float* __restrict__ p, int64_t g_off, int64_t m_off, int64_t v_off,
+                                                                  const int64_t* __restrict__ ranges, const float* __restrict__ state, float b1, float b2,
+                                                                  float eps, float grad_scale, const float* __restrict__ scaler) {
+    if (scaler != nullptr) {
+        if (scaler[2] != 0.f) return;
+        grad_scale /= scaler[0];
+    }
+    const float t = state[1] + 1.0f;
+    const float step_size = state[0] / (1.0f - powf(b1, t));
+    const float rsqrt_bc2 = rsqrtf(1.0f - powf(b2, t));
+    const int64_t beg = ranges[2 * blockIdx.y], cnt = ranges[2 * blockIdx.y + 1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+        float* wp = p + beg + i;
+        const float gr = wp[g_off] * grad_scale;
+        const float m = b1 * wp[m_off] + (1.f - b1) * gr;
+        const float v = b2 * wp[v_off] + (1.f - b2) * gr * gr;
+        *wp -= step_size * m / (sqrtf(v) * rsqrt_bc2 + eps);
+        wp[m_off] = m;
+        wp[v_off] = v;
+    }
+}
 __global__ void adam_tick_kernel(float* state, const float* __restrict__ scaler) {
     if (scaler == nullptr || scaler[2] == 0.f) state[1] += 1.0f;  // a skipped (overflowed) step does not count
 }
@@ -612,6 +635,20 @@ static int adam_dev_launch(float* p, const float* g, float* m, float* v, int64_t
     FALNET_CHECK_ARG(p && g && m && v && state && n > 0 && (n & 3) == 0, "adam_step_dev: bad argument (n must be a multiple of 4)");
     FALNET_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_dev: buffers must be 16-B aligned");
     hipLaunchKernelGGL(adam_dev_kernel, dim3(2048), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g, m, v, n, state, b1, b2, eps, grad_scale, scaler);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, scaler);
+    FALNET_RETURN_LAUNCH();
+}
+extern "C" int falnet_adam_ranges(float* p, int64_t g_off, int64_t m_off, int64_t v_off, const int64_t* ranges_dev, int n_ranges, const float* state,
+                                  float b1, float b2, float eps, float grad_scale, const float* scaler, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(p && ranges_dev && n_ranges > 0 && state && g_off != 0 && m_off != 0 && v_off != 0, "adam_ranges: bad argument");
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3(8, n_ranges), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g_off, m_off, v_off, ranges_dev, state, b1, b2, eps,
+                       grad_scale, scaler);
+    FALNET_RETURN_LAUNCH();
+}
+extern "C" int falnet_adam_tick(float* state, const float* scaler, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(state, "adam_tick: bad argument");
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, scaler);
     FALNET_RETURN_LAUNCH();
 }

@@ -408,6 +408,25 @@ class FalnetPlan:
         up2 = ops.pack_up2_call(packed_now, dt, dev)
         if up2 is not None:
             self.pack.append(up2)
+        # Optimiser step fused with the re-pack (train.FlatAdam.step -> model.adam_and_repack): the layers whose f32 masters live in the flat
+        # parameter buffer are updated by the launch that packs them; everything else in the buffer (biases, the two factors of the composed
+        # logits weights) by a range list; derived weights (the composed logits conv, the sub-pixel deconv weights) are rebuilt behind them.
+        flat = m._flat
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        owned = [pc for pc in packed_now if lo <= pc.weight.data_ptr() < hi]
+        derived = [pc for pc in packed_now if not (lo <= pc.weight.data_ptr() < hi)]
+        spans = sorted(((pc.weight.data_ptr() - lo) // 4, pc.weight.numel()) for pc in owned)
+        rest, pos = [], 0
+        for a, cnt in spans:
+            if a > pos:
+                rest += [pos, a - pos]
+            pos = a + cnt
+        if pos < flat.numel():
+            rest += [pos, flat.numel() - pos]
+        self.adam_pack = dict(
+            owned=ops.adam_pack_call(owned, dt, dev) if owned else None,
+            rest=torch.tensor(rest, dtype=torch.int64, device=dev) if rest else None, n_rest=len(rest) // 2,
+            after=([compose_call] if compose else []) + ([ops.pack_all_call(derived, dt, dev)] if derived else []) + ([up2] if up2 is not None else []))
         self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)
@@ -864,6 +883,28 @@ class FAL_net(nn.Module):
         for call in plan.pack:
             call()
         self._packed_version = self._weights_version()
+
+    def adam_and_repack(self, grad, m, v, state, b1, b2, eps, grad_scale, scaler_state):
+        """torch.optim.Adam's update of the whole flat buffer AND the re-pack of the compute-dtype weight copies: one pass over the masters
+        of the packed layers (falnet_adam_pack_batched), a range list for the rest, then the derived weights.  Returns False when no plan
+        exists yet (the caller runs the stand-alone update)."""
+        plan = next(iter(self._plans.values()), None)
+        ap = getattr(plan, "adam_pack", None)
+        if ap is None or torch.cuda.is_current_stream_capturing():
+            return False
+        flat = self._flat
+        g_off, m_off, v_off = ((t.data_ptr() - flat.data_ptr()) // 4 for t in (grad, m, v))
+        lib, st = L.lib(), L.stream_ptr()
+        if ap["rest"] is not None:
+            L.check(lib.falnet_adam_ranges(L.ptr(flat), g_off, m_off, v_off, L.ptr(ap["rest"]), ap["n_rest"], L.ptr(state), b1, b2, eps, float(grad_scale),
+                                           L.ptr(scaler_state), st), "adam_ranges")
+        if ap["owned"] is not None:
+            ap["owned"](g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler_state)
+        L.check(lib.falnet_adam_tick(L.ptr(state), L.ptr(scaler_state), st), "adam_tick")
+        for call in ap["after"]:
+            call()
+        self._packed_version = self._weights_version()
+        return True
 
     def gradient_buckets(self):
         """Contiguous element ranges of the flat gradient buffer, in the order backward finalises them."""

@@ -270,6 +270,28 @@ def pack_all_call(pcs, dtype, device):
     return _timed("pack_weights_batched", 0, 0, launch, "pack_weights_batched")
 
 
+def adam_pack_call(pcs, dtype, device):
+    """ONE launch = the Adam update of every layer in `pcs` (f32 masters inside the model's flat buffer) + its re-pack into wf / wd
+    (falnet_adam_pack_batched).  Returns launch(g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler_ptr_or_None)."""
+    lib = L.lib()
+    descs = (L.PackDesc * len(pcs))()
+    blk = 0
+    for i, pc in enumerate(pcs):
+        c0_real, c0_pad = pc.group_channels()
+        d = descs[i]
+        d.w, d.wf, d.wd = pc.weight.data_ptr(), pc.wf.data_ptr(), pc.wd.data_ptr()
+        d.cout, d.cin, d.taps, d.c0_real, d.c0_pad, d.cin_pad, d.cout_pad, d.block_begin = (
+            pc.cout, pc.cin, pc.taps, c0_real, c0_pad, pc.cin_pad, pc.cout_pad, blk)
+        blk += (pc.cout_pad // 32) * (pc.cin_pad // 32)
+    dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
+    n, total, code = len(pcs), blk, L.dtype_code(dtype)
+
+    def launch(g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler, _keep=(dev, pcs)):
+        L.check(lib.falnet_adam_pack_batched(L.ptr(dev), n, total, code, g_off, m_off, v_off, L.ptr(state), b1, b2, eps, float(grad_scale),
+                                             L.ptr(scaler), L.stream_ptr()), "adam_pack_batched")
+    return launch
+
+
 def pack_up2_call(pcs, dtype, device):
     """ONE launch that rebuilds the sub-pixel weights (PackedConv.wu) of every `deconv` layer from its f32 OIHW master weight."""
     lib = L.lib()

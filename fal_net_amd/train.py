@@ -49,6 +49,20 @@ class FlatAdam:
             self.state[0] = self._lr_dev
         self.t += 1
         b1, b2 = self.betas
+        if _ADAM_PACK and hasattr(self.model, "adam_and_repack"):
+            # the update of the packed layers rides in the launch that re-packs them (one pass over the f32 masters instead of two)
+            if scaler is not None:
+                L.check(L.lib().falnet_grad_guard(L.ptr(grad), grad.numel(), L.ptr(scaler.state), L.stream_ptr()), "grad_guard")
+            if self.model.adam_and_repack(grad, self.m, self.v, self.state, b1, b2, self.eps, grad_scale, None if scaler is None else scaler.state):
+                if scaler is not None:
+                    scaler.update()
+                return
+            if scaler is not None:  # (no plan yet: fall through to the stand-alone update; the guard has run)
+                L.check(L.lib().falnet_adam_step_guarded(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
+                                                         b1, b2, self.eps, float(grad_scale), L.ptr(scaler.state), L.stream_ptr()), "adam_step_guarded")
+                scaler.update()
+                self.model.mark_weights_changed()
+                return
         if scaler is None:
             L.check(L.lib().falnet_adam_step_dev(L.ptr(flat), L.ptr(grad), L.ptr(self.m), L.ptr(self.v), flat.numel(), L.ptr(self.state),
                                                  b1, b2, self.eps, float(grad_scale), L.stream_ptr()), "adam_step_dev")
@@ -229,6 +243,7 @@ def vgg_label_async(label, borrow=True):
 
 
 _FUSED_STEP = _os.environ.get("FALNET_FUSED_STEP", "1") == "1"
+_ADAM_PACK = L.ab("FALNET_ADAM_PACK", "1") == "1"  # FlatAdam.step: optimiser update fused with the weight re-pack (falnet_adam_pack_batched)
 _SEEDS = {}
 
 

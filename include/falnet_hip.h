@@ -234,6 +234,18 @@ typedef struct {
     int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps 9, 3 or 1 */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
+/* The optimiser step of every packed layer AND its re-pack in one pass over the f32 masters (Train_Stage1_K.py:177-180 torch.optim.Adam; the
+ * arithmetic of falnet_adam_step_dev): a block updates the 32 x 32 x taps master tile it is about to pack.  g_off / m_off / v_off: element
+ * offsets from a master weight to its gradient and moments (the four flat buffers share one layout).  state = {lr, t} on the device (t is NOT
+ * advanced: falnet_adam_tick); scaler: NULL, or the f16 loss-scale state {scale, ., overflow flag, .} -- the update divides by the scale and
+ * is skipped as a whole when the flag is set.  Parameters outside the packed layers (biases, factors of composed weights): falnet_adam_ranges. */
+int falnet_adam_pack_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, int64_t g_off, int64_t m_off, int64_t v_off,
+                             const float* state, float b1, float b2, float eps, float grad_scale, const float* scaler, void* stream);
+/* the same update over n_ranges element ranges (ranges_dev[2 r] = first element, [2 r + 1] = count) of the flat parameter buffer p */
+int falnet_adam_ranges(float* p, int64_t g_off, int64_t m_off, int64_t v_off, const int64_t* ranges_dev, int n_ranges, const float* state,
+                       float b1, float b2, float eps, float grad_scale, const float* scaler, void* stream);
+/* t += 1 unless the scaler's overflow flag is set (a skipped step does not count) */
+int falnet_adam_tick(float* state, const float* scaler, void* stream);
 /* Sub-pixel weights of the `deconv` layers (falnet_conv_t::weight_up2; FAL_netB.py:52-58), all layers in one launch: entry i sums the f32 OIHW
  * 3x3 master weights w into wu [cout_pad][16][cin_pad] (`dtype`; pair index 4 (2 py + px) + 2 a + b, rows / columns: py = 0 -> (W[0], W[1] + W[2]),
  * py = 1 -> (W[0] + W[1], W[2])); an entry uses (cout_pad / 32) * (cin_pad / 32) blocks from block_begin. */

@@ -571,3 +571,42 @@ def test_bench_two_ranks_reports_allreduce():
     assert sum(a["buckets_bytes"]) == a["bytes"]
     assert a["isolated_ms"]["whole_buffer"] > 0 and a["ms_per_step_without_collective"] > 0 and np.isfinite(a["exposed_ms"])
     assert abs(d["value"] - 2 * 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # whole-job pairs/s = world * batch / step time
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_adam_fused_with_repack_equals_standalone_update(dt):
+    """FlatAdam.step's default path -- the optimiser update of every packed layer inside the launch that re-packs it
+    (falnet_adam_pack_batched) + a range list for the rest (falnet_adam_ranges) -- against the stand-alone flat update followed by the
+    re-pack: same gradients, two steps each (bias-corrected moments), then weights, moments and every packed operand compared.
+    Reference: Train_Stage1_K.py:177-180 (torch.optim.Adam, lr 1e-4, betas (0.5, 0.999)); the stand-alone kernel is pinned to it by G2."""
+    LF.set_compute_dtype(dt)
+    left, right, mn, mx = synthetic.synthetic_pair(1, 64, 128, seed=9)
+    results = []
+    for fused in (True, False):
+        m = FAL_netB({"state_dict": synthetic.seeded_falnetb_state_dict(7)}, no_levels=7, compute_dtype=dt).to(DEV).train()
+        opt = train.FlatAdam(m)
+        old = train._ADAM_PACK
+        train._ADAM_PACK = fused
+        try:
+            for _ in range(2):
+                train.stage1_step(m, opt, left.to(DEV), right.to(DEV), mx.to(DEV), optimize=False)
+                g = m.flat_gradients()
+                g.copy_(torch.sin(torch.arange(g.numel(), device=DEV) * 0.37) * 1e-3)  # the same gradient for both variants
+                opt.step(0.5, scaler=train.loss_scaler(m))
+            disp = m(left.to(DEV), mn.to(DEV), mx.to(DEV)).detach().clone()  # uses the packed copies the update left behind
+        finally:
+            train._ADAM_PACK = old
+        packed = {k: (pc.wf.float().clone(), pc.wd.float().clone(), None if pc.wu is None else pc.wu.float().clone()) for k, pc in m._packed.items() if pc.wf is not None}
+        results.append((m.flat_parameters().clone(), opt.m.clone(), opt.v.clone(), packed, disp, float(opt.state[1])))
+        del m, opt
+    LF.set_compute_dtype(torch.float32)
+    (fa, ma, va, pa, da, ta), (fb, mb, vb, pb, db, tb) = results
+    assert ta == tb == 2.0
+    assert float((fa - fb).abs().max()) <= 1e-7 * float(fb.abs().max()) and rel(ma, mb) < 1e-6 and rel(va, vb) < 1e-6
+    assert pa.keys() == pb.keys()
+    for k in pa:
+        for x, y in zip(pa[k], pb[k]):
+            assert (x is None) == (y is None)
+            if x is not None:  # a master that differs in its last f32 bit may round to the neighbouring 16-bit value: one 16-bit ulp
+                assert float((x - y).abs().max()) <= (2.0 ** -7 if dt != torch.float32 else 1e-6) * float(y.abs().max()), k
+    assert rel(da, db) < (1e-5 if dt == torch.float32 else 2e-2)
