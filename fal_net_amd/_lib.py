@@ -71,7 +71,7 @@ class ReduceDesc(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32),
                 ("taps", C.c_int32), ("c0_real", C.c_int32), ("c0_pad", C.c_int32), ("cin_pad", C.c_int32),
-                ("cout_pad", C.c_int32), ("block_begin", C.c_int32)]
+                ("cout_pad", C.c_int32), ("block_begin", C.c_int32), ("no_update", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PackUp2Desc(C.Structure):
@@ -158,7 +158,7 @@ _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.
 _lib = None
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 400
+EXPECTED_VERSION = 401
 
 
 def lib():

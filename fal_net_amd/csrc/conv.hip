@@ -2692,7 +2692,11 @@ __global__ __launch_bounds__(256) void adam_pack_batched_kernel(const falnet_pac
     const int li = find_entry(descs, n, entry_begin);
     const falnet_pack_t d = descs[li];
     const int rel = blockIdx.x - d.block_begin;
-    if (d.taps == 9) pack_tile<T, 9, true>(d, rel, tile, &ad);
+    if (d.no_update) {  // derived weights (their factors were updated by falnet_adam_ranges and re-composed before this launch)
+        if (d.taps == 9) pack_tile<T, 9>(d, rel, tile);
+        else if (d.taps == 3) pack_tile<T, 3>(d, rel, tile);
+        else pack_tile<T, 1>(d, rel, tile);
+    } else if (d.taps == 9) pack_tile<T, 9, true>(d, rel, tile, &ad);
     else if (d.taps == 3) pack_tile<T, 3, true>(d, rel, tile, &ad);
     else pack_tile<T, 1, true>(d, rel, tile, &ad);
 }
@@ -3258,9 +3262,11 @@ extern "C" int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p) {
 }
 
 // kernel selection of falnet_wgrad -- ONE place, also behind falnet_wgrad_fuses_bias (the host must not re-derive it)
-enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_S2, WGK_C3, WGK_ROWS };
+enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_S2, WGK_C3, WGK_ROWS, WGK_ROWS_S2 };
 bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p);           // wgrad_rows.hip
 int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st);
+bool falnet_wgrad_rows_s2_applicable(const falnet_wgrad_t& p);        // wgrad_rows.hip: row-streaming form of the stride-2 weight gradient (variant 8)
+int falnet_wgrad_rows_s2_launch(const falnet_wgrad_t& p, hipStream_t st);
 
 static bool canonical_taps9(const falnet_wgrad_t& p) {
     if (p.ntaps != 9) return false;
@@ -3284,6 +3290,10 @@ static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
         for (int s = 0; s < p.nsrc && ok; ++s) ok = p.src[s].C % 32 == 0 && ((p.src[s].H == p.IH && p.src[s].W == p.IW) || (p.src[s].sy == 0 && p.src[s].sx == 0));
         if (!ok) { falnet_set_error("wgrad: variant 5 needs a 16-bit 3x3 stride-2 pad-1 launch with sources at the input size"); return WGK_BAD; }
         return WGK_S2;
+    }
+    if (p.variant == 8) {
+        if (!falnet_wgrad_rows_s2_applicable(p)) { falnet_set_error("wgrad: variant 8 needs a 16-bit 3x3 stride-2 pad-1 launch with ONE source at the input size"); return WGK_BAD; }
+        return WGK_ROWS_S2;
     }
     if (p.variant == 7) {
         if (!falnet_wgrad_rows_applicable(p)) { falnet_set_error("wgrad: variant 7 needs a 16-bit dense 3x3 stride-1 launch with sources at the launch size or half of it"); return WGK_BAD; }
@@ -3323,7 +3333,7 @@ static int check_wgrad_desc(const falnet_wgrad_t& p) {
 
 static bool wgrad_kernel_fuses_bias(WgradKernel k) {
     if (falnet_deterministic()) return false;  // the fused form adds with f32 atomics from every workgroup
-    return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS;
+    return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS || k == WGK_ROWS_S2;
 }
 
 extern "C" int falnet_wgrad_fuses_bias(const falnet_wgrad_t* pp) {
@@ -3352,6 +3362,8 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     switch (k) {
     case WGK_ROWS:
         return falnet_wgrad_rows_launch(p, st);
+    case WGK_ROWS_S2:
+        return falnet_wgrad_rows_s2_launch(p, st);
     case WGK_C3:
 #define WG_C3(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_c3_kernel<T>), dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
         FALNET_DISPATCH_16(p.dtype, WG_C3);

@@ -642,7 +642,7 @@ extern "C" int falnet_adam_ranges(float* p, int64_t g_off, int64_t m_off, int64_
                                   float b1, float b2, float eps, float grad_scale, const float* scaler, void* stream) {
     FALNET_ENTER(stream);
     FALNET_CHECK_ARG(p && ranges_dev && n_ranges > 0 && state && g_off != 0 && m_off != 0 && v_off != 0, "adam_ranges: bad argument");
-    hipLaunchKernelGGL(adam_ranges_kernel, dim3(8, n_ranges), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g_off, m_off, v_off, ranges_dev, state, b1, b2, eps,
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3(48, n_ranges), dim3(RED_THREADS), 0, (hipStream_t)stream, p, g_off, m_off, v_off, ranges_dev, state, b1, b2, eps,
                        grad_scale, scaler);
     FALNET_RETURN_LAUNCH();
 }

@@ -77,7 +77,9 @@ __device__ __forceinline__ void wr_vmcnt() {
     else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (K == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (K == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (K == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else static_assert(K == 0, "unsupported vmcnt");
@@ -687,6 +689,353 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
             o[7] = st_prev - ct0;                            // shader cycles over the loop
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 form of the eight-wave kernel (encoder convs conv2..conv4, FAL_netB.py:103-107: 3x3, stride 2, pad 1):
+//   dW[co][ky][kx][ci] = sum over output pixels (i, j) of gout[i][j][co] * in[2 i + ky - 1][2 j + kx - 1][ci]
+// Same roles (16-pixel half x 32-channel sub-tiles, one workgroup per CU, accumulators summed through LDS), same ring of row slots
+// filled by LDS-DMA, but a step moves TWO gout rows (i0, i1 = i0 + 1) and the FOUR input rows R0..R3 = 2 i0 - 1 .. 2 i0 + 2:
+//   gout i0 meets R0 (ky 0), R1 (ky 1), R2 (ky 2);  gout i1 meets R2 (ky 0), R3 (ky 1) and -- one step later -- the next R0 (ky 2),
+// so one gout fragment stays in a register window (w_b) and an item of n rows takes n / 2 + 1 steps: 18 MFMAs per wave and step,
+// as in the stride-1 kernel.  The DMA DE-INTERLEAVES every input row by column parity while fetching (each lane names its own source
+// pixel): E[s] = in[2 (x0 + s)] (32 pixels), O[s] = in[2 (x0 + s) - 1] (33 pixels), so the sixteen pixels a fragment needs for tap
+// kx are consecutive LDS rows -- kx 0: O[s], kx 1: E[s], kx 2: O[s + 1] -- and the transposed reads / XOR swizzle are unchanged.
+// (The parity-plane halo kernel it replaces, wgrad3x3_s2_kernel, stages a 9 x 65-pixel region per 4 x 32 outputs through registers with
+// two barriers per block: 96-171 TFLOP/s on these layers.)
+#define WS2R_XROW (WR_GROW + WR_XROW)                 // one input row: E half 4 KiB + O half 5 KiB (33 pixels used)
+#define WS2R_SLOT (2 * WR_GROW + 4 * WS2R_XROW)       // 44 KiB: gout rows i0, i1, input rows R0..R3
+
+struct Ws2Item { int u, n, T, t, b, x0, y0; };
+
+template <typename T, int D>
+__global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8s2_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
+    constexpr int NS = D + 1;
+    static_assert(D >= 1 && D <= 2, "prefetch distance");
+    constexpr int LDS_BYTES = NS * WS2R_SLOT > WR8_RED ? NS * WS2R_SLOT : WR8_RED;
+    static_assert(LDS_BYTES <= 160 * 1024, "ring + reduction space must fit in LDS");
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(wr_lptr_t)lds;
+    const int nsplit = p.nsplit;
+    int tile, split;
+    {
+        const int wg = blockIdx.x;
+        if ((nsplit & 7) == 0) {
+            const int idx = wg >> 3;
+            split = (idx / ntiles) * 8 + (wg & 7);
+            tile = idx % ntiles;
+        } else {
+            tile = wg % ntiles;
+            split = wg / ntiles;
+        }
+    }
+    const int ci0 = (tile % ntci) * 64, co0 = (tile / ntci) * 64;
+    const int hf = wave >> 2, a_t = (wave >> 1) & 1, c_t = wave & 1;
+    const int rsel = wave >> 2, pw = wave & 3;  // DMA role: gout row / input rows rsel and rsel + 2 of the step, 8-pixel piece
+    const int H = p.TH, TW = p.TW, gC = p.gC, IH = p.IH, IW = p.IW;
+    const int R = p.B * nstrips * H;
+    const int u0 = (int)((int64_t)R * split / nsplit), u1 = (int)((int64_t)R * (split + 1) / nsplit);
+
+    const int pl = lane >> 3, cpos = lane & 7;
+    const int gch = cpos ^ (((pl >> 1) & 1) << 2);
+    const char* const zero_page = reinterpret_cast<const char*>(g_wr_zero);
+    const bool g_chok = co0 + 8 * gch < gC;
+    const int ch = ci0 + 8 * gch;
+    const bool x_chok = ch < p.cin_total;
+    const falnet_src_t& S = p.src[0];
+    const int64_t l_sy = S.sy, l_sx = S.sx, l_sb = S.sb;
+    const T* const l_ptr = reinterpret_cast<const T*>(S.ptr) + ch;
+
+    auto load_item = [&](Ws2Item& c, int u) {
+        c.u = u;
+        const int bs = u / H;
+        c.y0 = u - bs * H;
+        c.n = min((bs + 1) * H, u1) - u;
+        c.T = (c.n >> 1) + 1;
+        c.b = bs / nstrips;
+        c.x0 = (bs - c.b * nstrips) * WR_TW;
+        c.t = 0;
+    };
+    int nst = 0;
+    for (int u = u0; u < u1;) {
+        const int e = min((u / H + 1) * H, u1);
+        nst += ((e - u) >> 1) + 1;
+        u = e;
+    }
+
+    // running per-lane source pointers: gout row y0 + rsel + 2 t; input row 2 y0 - 1 + rsel + 4 t (the piece of row rsel + 2 sits two
+    // image rows further: a constant byte offset); column pieces E (pw), O (pw) and the 33rd O pixel (pw == 0, lane pixel 0)
+    const char* gptr = zero_page;
+    const char* eptr = zero_page;
+    const char* optr = zero_page;
+    const char* hptr = zero_page;
+    bool e_ok = false, o_ok = false, h_ok = false;
+    unsigned g_inc = 0;
+    const unsigned x_inc = (unsigned)(4 * l_sy * (int)sizeof(T));
+    const int64_t x_row2 = 2 * l_sy * (int64_t)sizeof(T);
+    auto item_pointers = [&](const Ws2Item& c) {
+        const int gx = c.x0 + 8 * pw + pl;
+        const bool g_ok = g_chok && gx < TW;
+        gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H + c.y0 + rsel) * TW + gx) * gC + co0 + 8 * gch) : zero_page;
+        g_inc = g_ok ? (unsigned)(2 * TW * gC * (int)sizeof(T)) : 0u;
+        const int64_t rowoff = (int64_t)c.b * l_sb + (int64_t)(2 * c.y0 - 1 + rsel) * l_sy;  // (may point in front of the image: only dereferenced for valid rows)
+        const int ce = 2 * gx, co = 2 * gx - 1, chh = 2 * (c.x0 + 32 + pl) - 1;
+        e_ok = x_chok && ce < IW;
+        o_ok = x_chok && co >= 0 && co < IW;
+        h_ok = x_chok && pl == 0 && chh < IW;
+        eptr = reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)ce * l_sx);
+        optr = reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)co * l_sx);
+        hptr = reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)chh * l_sx);
+    };
+    // piece k of a step: 0 gout; 1 / 2: E of rows rsel / rsel + 2; 3 / 4: O of those rows; 5 / 6: their 33rd O pixel (pw == 0 only)
+    auto issue_piece = [&](const Ws2Item& c, int slot, int k) {
+        const unsigned base = lds_base + slot * WS2R_SLOT;
+        if (k == 0) {
+            const bool gv = 2 * c.t + rsel < c.n;
+            wr_glds16(gv ? gptr : zero_page, base + rsel * WR_GROW + pw * 1024);
+            gptr += g_inc;
+            return;
+        }
+        const int far = (k - 1) & 1;                       // 0: row rsel, 1: row rsel + 2
+        const int row = rsel + 2 * far;
+        const int i = 2 * (c.y0 + 2 * c.t) - 1 + row;
+        const bool xv = i >= 0 && i < IH;
+        const unsigned xb = base + 2 * WR_GROW + row * WS2R_XROW;
+        const int64_t off = far ? x_row2 : 0;
+        if (k <= 2) wr_glds16((xv && e_ok) ? eptr + off : zero_page, xb + pw * 1024);
+        else if (k <= 4) wr_glds16((xv && o_ok) ? optr + off : zero_page, xb + WR_GROW + pw * 1024);
+        else if (pw == 0) wr_glds16((xv && h_ok) ? hptr + off : zero_page, xb + WR_GROW + 4 * 1024);
+    };
+    auto advance_pointers = [&]() {  // after the last piece of a step
+        eptr += x_inc;
+        optr += x_inc;
+        hptr += x_inc;
+    };
+    auto issue = [&](const Ws2Item& c, int slot) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) issue_piece(c, slot, k);
+        advance_pointers();
+    };
+
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int kh = g16 >> 1, cb = g16 & 1, q = i16 >> 2, pc = i16 & 3;
+    auto frag_off = [&](int tile32, int pshift) {
+        const int gc = tile32 * 4 + cb * 2 + (pc >> 1);
+        const int sw = ((pshift + q) >> 1) & 1;
+        return (q + 8 * kh) * 128 + ((gc ^ (sw << 2)) * 16) + (pc & 1) * 8;
+    };
+    const int offA = frag_off(c_t, 0) + hf * 16 * 128;
+    const int offE = 2 * WR_GROW + frag_off(a_t, 0) + hf * 16 * 128;
+    const int offO0 = 2 * WR_GROW + WR_GROW + frag_off(a_t, 0) + hf * 16 * 128;
+    const int offO1 = 2 * WR_GROW + WR_GROW + frag_off(a_t, 1) + 128 + hf * 16 * 128;
+    auto frag = [&](const char* base) -> s16x8 {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base + 4 * 128));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[dy][dx][j] = 0.f;
+    s16x8 w_b;  // gout fragment of the previous step's second row
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w_b[j] = 0;
+    bool w_valid = false;
+    const bool a_live = ci0 + 32 * a_t < p.cin_total && co0 + 32 * c_t < gC;
+    const bool do_bias = p.bias_grad != nullptr && (tile % ntci) == 0 && a_t == 0;
+    float bsum = 0.f;
+
+    Ws2Item ci_, cc_;
+    if (nst > 0) {
+        load_item(ci_, u0);
+        cc_ = ci_;
+        item_pointers(ci_);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < nst) {
+                issue(ci_, d);
+                if (d + 1 < nst && ++ci_.t == ci_.T) {
+                    load_item(ci_, ci_.u + ci_.n);
+                    item_pointers(ci_);
+                }
+            }
+        }
+    }
+    int slot = 0, islot = D;
+    // stagger as in the stride-1 kernel: waves 4-7 multiply the step they read before the last barrier while waves 0-3 issue / read first
+    const bool lag = hf == 1;
+    s16x8 n_a, n_b, xr[4][3];
+    int m_t2 = 0, m_n = 0, m_i0 = 0;
+    bool m_have = false, m_first = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n_a[j] = n_b[j] = 0;
+    auto advance_issue = [&](int g) {
+        advance_pointers();
+        if (g + D + 1 < nst && ++ci_.t == ci_.T) {
+            load_item(ci_, ci_.u + ci_.n);
+            item_pointers(ci_);
+        }
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    };
+    auto read_frags = [&](int g) {
+        const char* sb = lds + slot * WS2R_SLOT;
+        m_t2 = 2 * cc_.t;
+        m_n = cc_.n;
+        m_i0 = 2 * (cc_.y0 + m_t2) - 1;  // image row of R0
+        m_first = cc_.t == 0;            // first step of an item: no previous gout row
+        m_have = true;
+        n_a = frag(sb + offA);
+        n_b = frag(sb + WR_GROW + offA);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xr[r][0] = frag(sb + r * WS2R_XROW + offO0);
+            xr[r][1] = frag(sb + r * WS2R_XROW + offE);
+            xr[r][2] = frag(sb + r * WS2R_XROW + offO1);
+        }
+        if (g + 1 < nst && ++cc_.t == cc_.T) load_item(cc_, cc_.u + cc_.n);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    };
+    for (int g = 0; g <= nst; ++g) {
+        const bool do_issue = g + D < nst;
+        if (g < nst) {
+            const int k = max(0, min(D - 1, nst - g - 1));  // younger steps whose pieces may still be in flight
+            if (pw == 0) {
+                if (k >= 1) wr_vmcnt<7>();
+                else wr_vmcnt<0>();
+            } else {
+                if (k >= 1) wr_vmcnt<5>();
+                else wr_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!lag) read_frags(g);
+        }
+        auto piece = [&](int kk) {
+            if (do_issue) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(ci_, islot, kk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            const int t2 = m_t2;
+            auto vr = [&](int r) { return (unsigned)r < (unsigned)m_n; };       // gout row r of the item exists
+            auto vx = [&](int k) { return (unsigned)(m_i0 + k) < (unsigned)IH; };  // input row R_k inside the image
+            const bool live = a_live && m_have;
+            if (live && vx(0) && !m_first && w_valid) {  // previous step's second gout row, ky = 2
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(w_b, xr[0][dx], acc[2][dx]);
+            }
+            piece(0);
+            if (live && vx(0) && vr(t2)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_a, xr[0][dx], acc[0][dx]);
+            }
+            piece(1);
+            piece(2);
+            if (live && vx(1) && vr(t2)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(n_a, xr[1][dx], acc[1][dx]);
+            }
+            piece(3);
+            if (live && vx(2) && vr(t2)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[2][dx] = Mma16<T>::mma(n_a, xr[2][dx], acc[2][dx]);
+            }
+            piece(4);
+            if (live && vx(2) && vr(t2 + 1)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[0][dx] = Mma16<T>::mma(n_b, xr[2][dx], acc[0][dx]);
+            }
+            piece(5);
+            piece(6);
+            if (live && vx(3) && vr(t2 + 1)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc[1][dx] = Mma16<T>::mma(n_b, xr[3][dx], acc[1][dx]);
+            }
+            if (do_issue) advance_issue(g);
+            if (m_have) {
+                if (do_bias) {  // rows outside the item arrive as zeros
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += Mma16<T>::f32(n_a[j]) + Mma16<T>::f32(n_b[j]);
+                }
+                w_b = n_b;
+                w_valid = vr(t2 + 1);
+                m_have = false;
+            }
+        }
+        if (lag && g < nst) read_frags(g);
+    }
+
+    // ---- the two halves' accumulators are summed through LDS: waves 4-7 deposit, waves 0-3 add and write the slab ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = reinterpret_cast<float*>(lds) + (wave & 3) * (9 * 4 * 256) + lane * 4;
+    if (hf == 1) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    *reinterpret_cast<float4*>(red + ((dy * 3 + dx) * 4 + j4) * 256) =
+                        make_float4(acc[dy][dx][4 * j4], acc[dy][dx][4 * j4 + 1], acc[dy][dx][4 * j4 + 2], acc[dy][dx][4 * j4 + 3]);
+    }
+    __syncthreads();
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        const int co = co0 + 32 * c_t + (lane & 31);
+        if ((lane >> 5) == 0 && co < p.cout) atomicAdd(p.bias_grad + co, bsum);
+    }
+    if (hf == 1) return;
+    const int r = lane & 31, h = lane >> 5;
+    const int ci = ci0 + 32 * a_t + r;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float* dst = p.partial + (((int64_t)split * 9 + dy * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const float4 o = *reinterpret_cast<const float4*>(red + ((dy * 3 + dx) * 4 + j4) * 256);
+                const float v[4] = {acc[dy][dx][4 * j4] + o.x, acc[dy][dx][4 * j4 + 1] + o.y, acc[dy][dx][4 * j4 + 2] + o.z, acc[dy][dx][4 * j4 + 3] + o.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * j4 + e;
+                    const int co = co0 + 32 * c_t + (j & 3) + 8 * (j >> 2) + 4 * h;
+                    if (ci < p.cin_total && co < w_rows) dst[(int64_t)co * p.cin_total + ci] = v[e];
+                }
+            }
+        }
+}
+
+bool falnet_wgrad_rows_s2_applicable(const falnet_wgrad_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.ntaps != 9 || p.isy != 2 || p.isx != 2 || p.TH != (p.IH + 1) / 2 || p.TW != (p.IW + 1) / 2) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.tap_dy[t] != t / 3 - 1 || p.tap_dx[t] != t % 3 - 1) return false;
+    if (p.gC % 32 || p.cin_total % 32 || p.nsrc != 1) return false;
+    const falnet_src_t& S = p.src[0];
+    if (S.C != p.cin_total || S.H != p.IH || S.W != p.IW || S.sx == 0 || S.sy == 0) return false;
+    if ((int64_t)p.B * ((p.TW + WR_TW - 1) / WR_TW) * p.TH >= (1ll << 30)) return false;
+    return true;
+}
+
+int falnet_wgrad_rows_s2_launch(const falnet_wgrad_t& p, hipStream_t st) {
+    const int w_rows = (p.gC + 31) / 32 * 32;
+    const int ntci = (p.cin_total + 63) / 64, ntco = (w_rows + 63) / 64;
+    const int ntiles = ntci * ntco;
+    const int nstrips = (p.TW + WR_TW - 1) / WR_TW;
+    const dim3 grid((unsigned)(ntiles * p.nsplit));
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8s2_kernel<f16_t, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8s2_kernel<bf16_t, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    FALNET_RETURN_LAUNCH();
 }
 
 // does this launch fit the row-streaming kernel?  (16-bit operands, canonical dense 3x3 stride 1, sources at the launch

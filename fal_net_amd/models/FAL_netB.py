@@ -424,9 +424,10 @@ class FalnetPlan:
         if pos < flat.numel():
             rest += [pos, flat.numel() - pos]
         self.adam_pack = dict(
-            owned=ops.adam_pack_call(owned, dt, dev) if owned else None,
             rest=torch.tensor(rest, dtype=torch.int64, device=dev) if rest else None, n_rest=len(rest) // 2,
-            after=([compose_call] if compose else []) + ([ops.pack_all_call(derived, dt, dev)] if derived else []) + ([up2] if up2 is not None else []))
+            before=[compose_call] if compose else [],  # (needs the factors the range update has just written)
+            owned=ops.adam_pack_call(owned, dt, dev, derived) if owned else None,
+            after=[up2] if up2 is not None else [])
         self.wbatch = ops.WgradBatch(dt, dev)
 
         # boundary tensors (planar f32)
@@ -898,6 +899,8 @@ class FAL_net(nn.Module):
         if ap["rest"] is not None:
             L.check(lib.falnet_adam_ranges(L.ptr(flat), g_off, m_off, v_off, L.ptr(ap["rest"]), ap["n_rest"], L.ptr(state), b1, b2, eps, float(grad_scale),
                                            L.ptr(scaler_state), st), "adam_ranges")
+        for call in ap["before"]:
+            call()
         if ap["owned"] is not None:
             ap["owned"](g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler_state)
         L.check(lib.falnet_adam_tick(L.ptr(state), L.ptr(scaler_state), st), "adam_tick")

@@ -270,13 +270,17 @@ def pack_all_call(pcs, dtype, device):
     return _timed("pack_weights_batched", 0, 0, launch, "pack_weights_batched")
 
 
-def adam_pack_call(pcs, dtype, device):
+def adam_pack_call(pcs, dtype, device, derived=()):
     """ONE launch = the Adam update of every layer in `pcs` (f32 masters inside the model's flat buffer) + its re-pack into wf / wd
-    (falnet_adam_pack_batched).  Returns launch(g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler_ptr_or_None)."""
+    (falnet_adam_pack_batched); the layers in `derived` (masters outside the flat buffer, rebuilt from updated factors before this launch)
+    are only packed.  Returns launch(g_off, m_off, v_off, state, b1, b2, eps, grad_scale, scaler_ptr_or_None)."""
     lib = L.lib()
+    n_own = len(pcs)
+    pcs = list(pcs) + list(derived)
     descs = (L.PackDesc * len(pcs))()
     blk = 0
     for i, pc in enumerate(pcs):
+        descs[i].no_update = int(i >= n_own)
         c0_real, c0_pad = pc.group_channels()
         d = descs[i]
         d.w, d.wf, d.wd = pc.weight.data_ptr(), pc.wf.data_ptr(), pc.wd.data_ptr()
@@ -578,6 +582,13 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
     if c3:
         assert h16 and dense and cout_pad == 32 and cin_pad == 32, "variant 6: 16-bit first layer, Cout 32"
         variant, nsplit, sym = 6, max(1, min(_WGRAD_WGS, npatch)), f"_Z18wgrad3x3_c3_kernelI{tn}Ev14falnet_wgrad_tiiii"
+    elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs) and _wgrad_rows_s2(srcs, IH, IW, TW, cin_pad, cout_pad):
+        tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
+        units = B * ((TW + 31) // 32) * TH
+        nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
+        if nsplit >= 8:
+            nsplit -= nsplit % 8
+        variant, sym = 8, f"_Z23wgrad3x3_rows8s2_kernelI{tn}Li2EEv14falnet_wgrad_tiiii"
     elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):
         tiles = (cin_pad // 32) * (cout_pad // (64 if cout_pad % 64 == 0 else 32))
         variant, nsplit = 5, max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
@@ -694,6 +705,13 @@ def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
     if str(cin_pad) in L.ab("FALNET_WGRAD_ROWS_SKIP_CIN", "").split(","):  # A/B: leave layers of this input width on the patch kernel
         return False
     return L.ab("FALNET_WGRAD_ROWS", "1") == "1"
+
+
+def _wgrad_rows_s2(srcs, IH, IW, TW, cin_pad, cout_pad):
+    """Row-streaming stride-2 weight gradient (falnet_wgrad variant 8, csrc/wgrad_rows.hip): one NHWC source at the input size with at
+    least 64 input channels (64 x 64 blocks per workgroup: a 32-channel source would idle half of its waves), 32-pixel strips."""
+    return (len(srcs) == 1 and srcs[0].H == IH and srcs[0].W == IW and srcs[0].sx != 0 and cin_pad >= int(L.ab("FALNET_WGRAD_ROWS_S2_MINCIN", "64")) and cout_pad >= 64 and TW >= 32
+            and L.ab("FALNET_WGRAD_ROWS_S2", "1") == "1")
 
 
 def _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs):

@@ -232,6 +232,7 @@ typedef struct {
 typedef struct {
     const float* w; void* wf; void* wd;
     int32_t cout, cin, taps, c0_real, c0_pad, cin_pad, cout_pad, block_begin;  /* entry uses (cout_pad/32)*(cin_pad/32) blocks, taps 9, 3 or 1 */
+    int32_t no_update, reserved;  /* falnet_adam_pack_batched: != 0 -> this entry is only packed (a derived weight, e.g. composed logits weights) */
 } falnet_pack_t;
 int falnet_pack_weights_batched(const falnet_pack_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 /* The optimiser step of every packed layer AND its re-pack in one pass over the f32 masters (Train_Stage1_K.py:177-180 torch.optim.Adam; the
