@@ -7,6 +7,7 @@ shared between torch's caching allocator and these kernels.
 """
 import ctypes as C
 import os
+import threading
 
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
@@ -77,6 +78,14 @@ class PackDesc(C.Structure):
 class PackUp2Desc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wu", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
                 ("block_begin", C.c_int32)]
+
+
+class Cmd(C.Structure):  # falnet_cmd_t
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("event", C.c_int32), ("nint", C.c_int32), ("nflt", C.c_int32), ("reserved", C.c_int32),
+                ("iarg", C.c_uint64 * 18), ("farg", C.c_double * 6)]
+
+
+CMD_RECORD, CMD_WAIT = -1, -2
 
 
 class BiasGradDesc(C.Structure):
@@ -152,10 +161,16 @@ SIGNATURES = {
     "falnet_disp_prologue": [_P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P],
     "falnet_occlusion_mask": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_mirror_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "falnet_replay_op_index": [C.c_char_p],
+    "falnet_replay_op_args": [_I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "falnet_replay": [_P, _I, _P, _I, _P, _I, C.POINTER(C.c_int)],
+    "falnet_fill_f32": [_P, _L, _F, _P],
+    "falnet_copy_bytes": [_P, _P, _L, _P],
 }
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
 
 _lib = None
+_TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
 EXPECTED_VERSION = 401
@@ -180,8 +195,176 @@ def lib():
                                "(`python -m fal_net_amd._build`; experiment builds: `--ab <tag>`)")
         if DETERMINISTIC:
             l.falnet_set_deterministic(1)
-        _lib = l
+        _lib = _LibProxy(l)
     return _lib
+
+
+# ---- host launch path in C (csrc/replay.cpp) -------------------------------------------------------------------------------------------
+# Every launch entry point (a function of the header that ends in `void* stream`) is reached through _LibProxy: normally a plain call; while
+# a Recorder is active on this thread the call is NOT made but appended to the recorder's command list, with its stream replaced by an
+# index.  Event records / stream waits go through ev_record / ev_wait for the same reason.  Recorder.finalize() -> Segment, whose run()
+# issues the whole list from one falnet_replay call.
+_MASK64 = (1 << 64) - 1
+
+
+def _int_arg(a):
+    if a is None:
+        return 0
+    if isinstance(a, int):
+        return a & _MASK64
+    if isinstance(a, C.c_void_p):
+        return a.value or 0
+    if isinstance(a, (C.Structure, C.Array)):
+        return C.addressof(a)
+    obj = getattr(a, "_obj", None)  # C.byref(x)
+    if obj is not None:
+        return C.addressof(obj)
+    if isinstance(a, C._SimpleCData):
+        return int(a.value or 0) & _MASK64
+    raise TypeError(f"cannot record argument {a!r}")
+
+
+class Segment:
+    """A recorded launch sequence: run(main_stream_pointer) issues it through falnet_replay (stream index 0 = the caller's stream)."""
+
+    def __init__(self, cmds, streams, events, keep):
+        self.n = len(cmds)
+        self.cmds = (Cmd * max(self.n, 1))(*cmds)
+        self.streams = (C.c_void_p * len(streams))(*streams)
+        self.events = (C.c_void_p * max(len(events), 1))(*events)
+        self.ns, self.ne = len(streams), len(events)
+        self.failed = C.c_int(-1)
+        self._keep = keep
+        self._fn = _lib._cdll.falnet_replay
+
+    def run(self, main_ptr):
+        self.streams[0] = main_ptr
+        rc = self._fn(self.cmds, self.n, self.streams, self.ns, self.events, self.ne, C.byref(self.failed))
+        if rc != 0:
+            msg = _lib._cdll.falnet_last_error().decode(errors="replace")
+            raise RuntimeError(f"libfalnet_hip replay failed at command {self.failed.value} (rc={rc}): {msg}")
+
+
+class Recorder:
+    """`with Recorder(main_stream_ptr) as r: <launches>` -> r.finalize() is the Segment of everything the block would have launched."""
+
+    def __init__(self, main_ptr):
+        self.streams = [int(main_ptr or 0)]
+        self.events, self.cmds, self.keep = [], [], []
+        self._ops = {}
+
+    def __enter__(self):
+        assert getattr(_TLS, "rec", None) is None, "recorders do not nest"
+        _TLS.rec = self
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.rec = None
+        return False
+
+    def _stream(self, ptr):
+        v = int((ptr.value if isinstance(ptr, C.c_void_p) else ptr) or 0)
+        if v not in self.streams:
+            self.streams.append(v)
+        return self.streams.index(v)
+
+    def _event(self, ev):
+        h = int(ev.cuda_event)
+        if not h:
+            raise RuntimeError("recording an event that was never recorded eagerly (no handle yet)")
+        if h not in self.events:
+            self.events.append(h)
+            self.keep.append(ev)
+        return self.events.index(h)
+
+    def add(self, name, argtypes, args):
+        op = self._ops.get(name)
+        if op is None:
+            op = self._ops[name] = _lib._cdll.falnet_replay_op_index(name.encode())
+            if op < 0:
+                raise RuntimeError(f"{name} is not a replayable entry point")
+        c = Cmd()
+        c.op, c.stream = op, self._stream(args[-1])
+        ni = nf = 0
+        for t, a in zip(argtypes[:-1], args[:-1]):
+            if t is _F or t is _D:
+                c.farg[nf] = float(a)
+                nf += 1
+            else:
+                c.iarg[ni] = _int_arg(a)
+                ni += 1
+        c.nint, c.nflt = ni, nf
+        self.cmds.append(c)
+        self.keep.append(args)
+        return 0
+
+    def record(self, ev, stream_ptr):
+        c = Cmd()
+        c.op, c.stream, c.event = CMD_RECORD, self._stream(stream_ptr), self._event(ev)
+        self.cmds.append(c)
+
+    def wait(self, stream_ptr, ev):
+        c = Cmd()
+        c.op, c.stream, c.event = CMD_WAIT, self._stream(stream_ptr), self._event(ev)
+        self.cmds.append(c)
+
+    def finalize(self):
+        return Segment(self.cmds, self.streams, self.events, self.keep)
+
+
+class _LibProxy:
+    """The loaded library; launch entry points become recordable wrappers (cached as instance attributes on first use)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        raw = getattr(self._cdll, name)
+        argtypes = SIGNATURES.get(name)
+        if not argtypes or argtypes[-1] is not _P or name in ("falnet_replay", "falnet_conv2d_kernel_name", "falnet_med_head_kernel_name"):
+            fn = raw
+        else:
+            def fn(*args, _raw=raw, _name=name, _at=argtypes):
+                rec = getattr(_TLS, "rec", None)
+                if rec is None:
+                    return _raw(*args)
+                return rec.add(_name, _at, args)
+        object.__setattr__(self, name, fn)
+        return fn
+
+
+def recording():
+    return getattr(_TLS, "rec", None) is not None
+
+
+def ev_record(ev, stream):
+    """ev.record(stream) -- or its recorded form; `stream`: a torch.cuda.Stream."""
+    rec = getattr(_TLS, "rec", None)
+    if rec is None:
+        ev.record(stream)
+    else:
+        rec.record(ev, stream.cuda_stream)
+
+
+def ev_wait(stream, ev):
+    """stream.wait_event(ev) -- or its recorded form."""
+    rec = getattr(_TLS, "rec", None)
+    if rec is None:
+        stream.wait_event(ev)
+    else:
+        rec.wait(stream.cuda_stream, ev)
+
+
+def record_calls(calls, main_ptr=None):
+    """Segment of the launches `calls` (zero-argument callables) would issue on the current launch stream."""
+    mp = stream_ptr().value if main_ptr is None else main_ptr
+    with Recorder(mp) as r:
+        for c in calls:
+            c()
+    return r.finalize()
+
+
+REPLAY = os.environ.get("FALNET_REPLAY", "1") == "1"  # plans replay their recorded launch sequences through falnet_replay (0: every launch from Python)
 
 
 def check(rc, what=""):
@@ -195,9 +378,7 @@ def check(rc, what=""):
 # Stream object per call: ~1.5 us x 300 launches), and `on_stream` redirects the launches of a `with` block to another stream (the
 # weight-gradient side stream) without torch.cuda.stream()'s context switch (~10 us per launch group).  Outside such scopes the current
 # torch stream is looked up per call, as before.
-import threading
-
-_TLS = threading.local()  # the pin is per THREAD: autograd's backward thread pins its own stream without redirecting the main thread's launches
+# (the pin is per THREAD: autograd's backward thread pins its own stream without redirecting the main thread's launches)
 
 
 def stream_ptr():

@@ -86,6 +86,8 @@ class _VggPlan:
             acts.append(("pool", cur, pooled, h, w))
             self.outs.append(pooled)
             cur, h, w = pooled, h // 2, w // 2
+        self.run_fwd = ops.ReplayList(self.fwd, eager_head=1)  # (the first conv reads the caller's image: set_input per call)
+        self.run_bwd = None
         if not need_grad:
             return
         # ---- backward: gradients of the three pooled outputs -> gradient of the planar f32 input ----
@@ -128,14 +130,14 @@ class _VggPlan:
                                                   flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.keep.append(gin)
                     g_next = gin
+        self.run_bwd = ops.ReplayList(self.bwd)
 
 
 class _VggFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, plan, x):
         plan.c3_call.set_input(x)  # the first conv reads the caller's image in place (it is only read during this forward)
-        for c in plan.fwd:
-            c()
+        plan.run_fwd()
         ctx.plan, ctx.owner, ctx.gen = plan, owner, plan.gen
         # no clone: the plan (and its output buffers) stays reserved for this call until its backward has run -- or until the graph
         # is dropped without one (validation under grad mode, an exception): the finalizer frees it then
@@ -153,8 +155,7 @@ class _VggFunction(torch.autograd.Function):
                 buf.zero_()
             elif g.data_ptr() != buf.data_ptr():  # _PerceptualMse writes its gradient straight into this buffer
                 buf.copy_(g.permute(0, 2, 3, 1))
-        for c in plan.bwd:
-            c()
+        plan.run_bwd()
         out = plan.g_in.clone()
         plan.busy = False
         return None, None, out
@@ -228,8 +229,7 @@ class Vgg19_pc(nn.Module):
             return _VggFunction.apply(self, plan, xs)
         with torch.no_grad():
             plan.c3_call.set_input(xs)
-            for c in plan.fwd:
-                c()
+            plan.run_fwd()
             return tuple((o if borrow else o.clone()).permute(0, 3, 1, 2) for o in plan.outs)
 
 

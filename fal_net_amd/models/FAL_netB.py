@@ -140,6 +140,10 @@ class FalnetPlan:
         # levels 4-6 only -0.7 %, levels 3-6 -1.0 %, levels 1-6 -1.7 %, everything on this stream or alternating launches: worse).
         self._deep = self._deep_stream = None
         self._deep_pending, self._deep_events, self._deep_ev_next, self._deep_dirty = [], [], 0, False
+        self._sync_events, self._sync_ev_next = [], 0
+        self._bwd_segments, self._bwd_eager_runs = {}, {}
+        self._fwd_segments, self._fwd_eager_runs = {}, {}
+        self._main_stream = None
         self._deep_batch = max(1, int(L.ab("FALNET_DEEP_BATCH", "3")))
         self._deep_alt = L.ab("FALNET_DEEP_ALT", "0") == "1"  # experiment: every second larger weight gradient on the third stream as well
         self._alt_n = 0
@@ -326,8 +330,8 @@ class FalnetPlan:
             return
         ev = self._event(self._deep_events, self._deep_ev_next)
         self._deep_ev_next += 1
-        ev.record()  # main stream: behind the producer of the group's last gradient
-        deep.wait_event(ev)
+        L.ev_record(ev, self._main_stream)  # main stream: behind the producer of the group's last gradient
+        L.ev_wait(deep, ev)
         with L.on_stream(deep):
             for c in pend:
                 c()
@@ -342,8 +346,8 @@ class FalnetPlan:
         if self._deep_dirty:
             ev = self._event(self._deep_events, self._deep_ev_next)
             self._deep_ev_next += 1
-            ev.record(self._deep_stream)
-            stream.wait_event(ev)
+            L.ev_record(ev, self._deep_stream)
+            L.ev_wait(stream, ev)
             self._deep_dirty = False
 
     def _side_call(self, call):
@@ -369,8 +373,8 @@ class FalnetPlan:
             self._side_events.append(torch.cuda.Event())
         ev = self._side_events[self._side_ev_next]
         self._side_ev_next += 1
-        ev.record()
-        side.wait_event(ev)
+        L.ev_record(ev, self._main_stream)
+        L.ev_wait(side, ev)
         for c in pend:
             if getattr(c, "needs_torch_stream", False):  # the bucket hook (torch.distributed collectives run on torch's current stream)
                 with torch.cuda.stream(side), L.on_stream(side):
@@ -547,7 +551,7 @@ class FalnetPlan:
             def x0_convert_and_mark():
                 if not self._c3_wgrad:
                     self._x0_convert()
-                self._x0_event.record()  # on the stream the conversion was launched on
+                L.ev_record(self._x0_event, torch.cuda.current_stream())  # on the stream the conversion was launched on
             x0_convert_and_mark.needs_torch_stream = True  # (the event is recorded on torch's current stream: make that the side stream)
             self._side_call(x0_convert_and_mark)
             if compose:
@@ -634,7 +638,7 @@ class FalnetPlan:
                 srcs, ih, iw = self._enc_srcs[i]
                 if tail:
                     self._main_tail = getattr(self, "_main_tail", [])
-                    self._main_tail.append(lambda: torch.cuda.current_stream().wait_event(self._x0_event))
+                    self._main_tail.append(lambda: L.ev_wait(torch.cuda.current_stream(), self._x0_event))
                 self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail or cname in extra)
                 if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                     self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
@@ -714,6 +718,25 @@ class FalnetPlan:
                 call()
         hook, mid = getattr(self.model, "_mid_forward_hook", None), getattr(self, "_mid_index", -1)
         with L.stream_scope():  # one stream lookup for the whole replay
+            if ops.replay_ok():
+                # host launch path in C: the launches in front of the mid-forward hook and those behind it (with the MED head) as two
+                # recorded segments (csrc/replay.cpp) -- after two eager passes of this output combination
+                fk = (bool(ret_pan or ret_subocc), bool(ret_subocc))
+                segs = self._fwd_segments.get(fk)
+                fire = hook is not None and 0 <= mid < len(self.fwd)
+                if segs is None and self._fwd_eager_runs.get(fk, 0) >= 2:
+                    m = mid if 0 <= mid < len(self.fwd) else 0
+                    tail = list(self.fwd[m:]) + [self.head_full if fk[0] else self.head_disp_only] + ([self.head_masks] if fk[1] else [])
+                    segs = self._fwd_segments[fk] = (L.record_calls(self.fwd[:m]), L.record_calls(tail))
+                if segs is not None:
+                    ptr = L.stream_ptr().value
+                    segs[0].run(ptr)
+                    if fire:
+                        self.model._mid_forward_hook = None  # one shot
+                        hook()
+                    segs[1].run(ptr)
+                    return self.generation
+                self._fwd_eager_runs[fk] = self._fwd_eager_runs.get(fk, 0) + 1
             for i, call in enumerate(self.fwd):
                 if hook is not None and i == mid:
                     self.model._mid_forward_hook = None  # one shot
@@ -738,36 +761,70 @@ class FalnetPlan:
         self._accumulate = self.model._begin_grad_accumulation()
         self.wbatch.accumulate = 1 if self._accumulate else 0
         self.model._accumulating = bool(self._accumulate)
-        if not self._accumulate:
-            self.model._flat_grad.zero_()  # the batched reduce / bias kernels ADD into the flat gradient buffer
-        if getattr(self.model, "_compose_logits", False):
-            self.model._gwc.zero_()  # per-backward scratch: its content is split into the two real gradients
         main = torch.cuda.current_stream()
-        if self.use_side_stream and ops.TIMER is None:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            self._side_stream = self._side
-            self._side_stream.wait_stream(main)  # the previous step's Adam / repack must not be overtaken
-            if self._deep_max_px > 0:
-                if self._deep is None:
-                    self._deep = torch.cuda.Stream(device=self.device)
-                self._deep_stream = self._deep
-                self._deep_stream.wait_stream(main)
+        use_side = self.use_side_stream and ops.TIMER is None
+        # Host launch path in C (csrc/replay.cpp): the body below is a static sequence of C-ABI launches, event records and stream waits per
+        # (which upstream gradients exist, accumulating or not); after two eager passes it is recorded once and every later backward is ONE
+        # falnet_replay call -- the same launches on the same three streams.  Not with a gradient-bucket hook installed (torch.distributed
+        # collectives are issued from Python between the buckets) and not inside bench.py's instrumented pass.
+        key = (g_disp is not None, g_pan is not None, bool(self._accumulate))
+        can = use_side and ops.replay_ok() and getattr(self.model, "bucket_hook", None) is None
+        seg = self._bwd_segments.get(key) if can else None
+        if seg is None and can and self._bwd_eager_runs.get(key, 0) >= 2:
+            with L.Recorder(main.cuda_stream) as rec:
+                self._backward_body(main, use_side, key)
+            seg = self._bwd_segments[key] = rec.finalize()
+        if seg is not None:
+            seg.run(main.cuda_stream)
         else:
-            self._side_stream = self._deep_stream = None
-        self._side_ev_next = self._deep_ev_next = 0
-        self._deep_dirty = False
-        with L.stream_scope():  # one stream lookup for the whole replay; side calls redirect their launches with L.on_stream
-            self.head_bwd[(g_disp is not None, g_pan is not None)]()
+            self._backward_body(main, use_side, key)
+            if can:
+                self._bwd_eager_runs[key] = self._bwd_eager_runs.get(key, 0) + 1
+        if getattr(self, "_deferred_ready", None) is not None:
+            self.model._bucket_ready(self._deferred_ready)
+        self.model._end_grad_accumulation()
+
+    def _backward_body(self, main, use_side, key):
+        lib = L.lib()
+        self._main_stream = main
+        with L.stream_scope(main):  # one stream lookup for the whole replay; side calls redirect their launches with L.on_stream
+            st = L.stream_ptr()
+            if not self._accumulate:  # the batched reduce / bias kernels ADD into the flat gradient buffer
+                fg = self.model._flat_grad
+                L.check(lib.falnet_fill_f32(L.ptr(fg), fg.numel(), 0.0, st), "fill flat gradient")
+            if getattr(self.model, "_compose_logits", False):  # per-backward scratch: its content is split into the two real gradients
+                gw = self.model._gwc
+                L.check(lib.falnet_fill_f32(L.ptr(gw), gw.numel(), 0.0, st), "fill composed-logits gradient")
+            self._side_ev_next = self._deep_ev_next = self._sync_ev_next = 0
+            self._deep_dirty = False
+            if use_side:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side_stream = self._side
+                self._stream_wait(self._side_stream, main)  # the previous step's Adam / repack must not be overtaken
+                if self._deep_max_px > 0:
+                    if self._deep is None:
+                        self._deep = torch.cuda.Stream(device=self.device)
+                    self._deep_stream = self._deep
+                    self._stream_wait(self._deep_stream, main)
+                else:
+                    self._deep_stream = None
+            else:
+                self._side_stream = self._deep_stream = None
+            self.head_bwd[(key[0], key[1])]()
             for call in self.bwd_body:
                 call()
             self._flush_side()
             self._join_deep(main)
-        if self._side_stream is not None:
-            main.wait_stream(self._side_stream)
-        if getattr(self, "_deferred_ready", None) is not None:
-            self.model._bucket_ready(self._deferred_ready)
-        self.model._end_grad_accumulation()
+            if self._side_stream is not None:
+                self._stream_wait(main, self._side_stream)
+
+    def _stream_wait(self, waiter, waited):
+        """waiter.wait_stream(waited) as an explicit event pair (recordable)."""
+        ev = self._event(self._sync_events, self._sync_ev_next)
+        self._sync_ev_next += 1
+        L.ev_record(ev, waited)
+        L.ev_wait(waiter, ev)
 
 
 class _FalnetFunction(torch.autograd.Function):

@@ -851,6 +851,37 @@ class WgradBatch:
         return out
 
 
+def replay_ok():
+    """May a plan issue its recorded launch sequence through falnet_replay right now?  Not inside bench.py's instrumented pass (per-launch
+    events), not while another sequence is being recorded, not under hipGraph capture."""
+    return L.REPLAY and TIMER is None and not L.recording() and not torch.cuda.is_current_stream_capturing()
+
+
+class ReplayList:
+    """A fixed list of launches on ONE stream (a VGG plan's forward / backward, a stretch of the backbone's forward).  Called like the
+    loop over the list it replaces; after two eager passes (autotuning done, every launch has run once) the list is recorded and later
+    calls are one falnet_replay.  `eager_head`: leading launches with per-call inputs (conv_c3_call.set_input) stay eager."""
+
+    def __init__(self, calls, eager_head=0):
+        self.calls, self.head, self.seg, self.runs = list(calls), eager_head, None, 0
+
+    def __call__(self):
+        if not replay_ok():
+            for c in self.calls:
+                c()
+            return
+        for c in self.calls[:self.head]:
+            c()
+        if self.seg is None:
+            if self.runs < 2:
+                self.runs += 1
+                for c in self.calls[self.head:]:
+                    c()
+                return
+            self.seg = L.record_calls(self.calls[self.head:])
+        self.seg.run(L.stream_ptr().value)
+
+
 def simple_call(fn_name, *args, name=None, nbytes=0):
     lib = L.lib()
     fn = getattr(lib, fn_name)

@@ -310,8 +310,7 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
         vm._prepare(dev, vdt)
         vplan = vm._plan(B, H, W, vdt, dev, hold=True)
         vplan.c3_call.set_input(rpan)
-        for c in vplan.fwd:
-            c()
+        vplan.run_fwd()
         labels = joins[0]()
         code = L.dtype_code(vdt)
         feats = []
@@ -330,8 +329,7 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
                                           L.ptr(g_disp), st), "smooth_fwd_bwd")
     # ---- the VGG adjoint (every node is linear in its upstream scalar: s = loss scale) joins the L1 gradient ----
     if vplan is not None:
-        for c in vplan.bwd:
-            c()
+        vplan.run_bwd()
         # L1 term (loss_functions.py:53) and its gradient, with the VGG gradient of the synthesised view added in the same pass
         L.check(lib.falnet_l1_fwd_bwd_add(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(vplan.g_in), L.ptr(g_pan), st),
                 "l1_fwd_bwd_add")

@@ -437,6 +437,27 @@ int falnet_augment_normalize(const uint8_t* src, int H, int W, int x1, int y1, i
                              double bright, double cb0, double cb1, double cb2, float mean0, float mean1, float mean2,
                              float* dst, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Host launch path in C (csrc/replay.cpp).  A command = one call of a launch entry point of this header (every function that ends in
+ * `void* stream`), an event record or a stream wait.  `op`: index from falnet_replay_op_index("falnet_conv2d") ..., or FALNET_CMD_RECORD /
+ * FALNET_CMD_WAIT; `stream` / `event`: indices into the tables passed to falnet_replay; iarg: the pointer / integer arguments in
+ * declaration order (nint of them), farg: the float / double ones (nflt), the trailing stream argument is supplied by the replay.
+ * falnet_replay issues commands 0..n-1 in order and stops at the first failure (its index in *failed_at, -1 when all were issued); the
+ * launches are ordinary launches -- same kernels, same streams, same dependencies as the eager sequence they were recorded from. */
+#define FALNET_CMD_RECORD (-1)
+#define FALNET_CMD_WAIT (-2)
+typedef struct {
+    int32_t op, stream, event, nint, nflt, reserved;
+    uint64_t iarg[18];
+    double farg[6];
+} falnet_cmd_t;
+int falnet_replay_op_index(const char* name);
+int falnet_replay_op_args(int op, int* nint, int* nflt);
+int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* streams, int nstreams, void* const* events, int nevents, int* failed_at);
+/* p[0..n) = value (hipMemsetAsync / hipMemsetD32Async) and a device-to-device copy: the two aten launches of a static step, replayable */
+int falnet_fill_f32(float* p, int64_t n, float value, void* stream);
+int falnet_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

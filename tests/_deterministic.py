@@ -21,7 +21,8 @@ def digest(t):
     return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
 
 
-def run(dtype, stage2=False):
+def run(dtype, stage2=False, steps=2, replay=True):
+    L.REPLAY = replay  # host launch path: recorded sequences through falnet_replay (after two eager passes) vs every launch from Python
     LF.set_compute_dtype(dtype)
     sd = synthetic.seeded_falnetb_state_dict(49)
     m = FAL_netB({"state_dict": sd}, no_levels=49, compute_dtype=dtype).to("cuda").train()
@@ -29,7 +30,7 @@ def run(dtype, stage2=False):
     opt = train.FlatAdam(m)
     left, right, mn, mx = synthetic.synthetic_pair(2, 128, 256, seed=23, distinct=True)
     out = []
-    for _ in range(2):
+    for _ in range(steps):
         if stage2:
             o = train.stage2_step(m, fix, opt, left.cuda(), right.cuda(), mx.cuda())
         else:
@@ -44,6 +45,11 @@ def main():
     res = {}
     for name, dt, s2 in (("f32", torch.float32, False), ("bf16", torch.bfloat16, False), ("f32_stage2", torch.float32, True)):
         a, b = run(dt, s2), run(dt, s2)
+        res[name] = {"a": a, "b": b, "identical": a == b}
+    # the C replay of the recorded launch sequences against the eager launch path: six steps each (recording happens after the second
+    # one), every step's loss, gradients, weights and disparities bit-identical
+    for name, dt, s2 in (("replay_bf16", torch.bfloat16, False), ("replay_f32_stage2", torch.float32, True)):
+        a, b = run(dt, s2, steps=6, replay=True), run(dt, s2, steps=6, replay=False)
         res[name] = {"a": a, "b": b, "identical": a == b}
     print(json.dumps(res), flush=True)
 
