@@ -400,6 +400,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(out["loss"])
+    # host time to ISSUE a step, measured where the queues cannot push back: three steps from an idle device (inside the timed loop a
+    # host that runs ahead blocks on the hardware queues, and `issued` then measures the GPU, not the host)
+    torch.cuda.synchronize()
+    ti = time.perf_counter()
+    for _ in range(3):
+        step()
+    issue_idle = (time.perf_counter() - ti) / 3
+    torch.cuda.synchronize()
     ms = elapsed * 1e3 / args.steps
     pairs_per_s = world * args.batch * args.steps / elapsed
 
@@ -413,7 +421,9 @@ def main():
         "config": {"workload": f"{stage} training step ({cfg_name}), batch {args.batch}/GPU, "
                                f"{args.height}x{args.width}, N={args.levels}, seeded weights, seeded VGG19",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": loss,
-                   "launch": "hipGraph replay" if graphed else "eager", "host_issue_ms_per_step": issued * 1e3 / args.steps},
+                   "launch": "hipGraph replay" if graphed else ("eager launches, recorded sequences issued by falnet_replay (C)" if os.environ.get("FALNET_REPLAY", "1") == "1"
+                                                                       else "eager launches from Python"),
+                   "host_issue_ms_per_step": issue_idle * 1e3, "host_issue_ms_per_step_in_timed_loop": issued * 1e3 / args.steps},
     }
 
     if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
