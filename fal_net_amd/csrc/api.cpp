@@ -22,6 +22,10 @@ extern "C" const char* falnet_last_error(void) { return g_err; }
 // Deterministic mode (process-wide): see include/falnet_hip.h.  Read by the launchers of conv.hip / losses.hip.
 static int g_deterministic = 0;
 int falnet_deterministic() { return g_deterministic; }
+int* falnet_replay_depth() {
+    static thread_local int depth = 0;
+    return &depth;
+}
 extern "C" int falnet_set_deterministic(int on) {
     g_deterministic = on ? 1 : 0;
     return 0;

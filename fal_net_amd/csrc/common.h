@@ -30,8 +30,9 @@ static inline const char* falnet_ab_env(const char*) { return nullptr; }
 // runs on autograd's worker thread, whose current device need not be the forward thread's; a launch on a stream of another
 // device fails with hipErrorInvalidResourceHandle).  The device comes from the stream itself, so no entry point needs a
 // device argument; the NULL stream keeps the thread's current device (falnet_set_device sets it explicitly).
+int* falnet_replay_depth();  // api.cpp: > 0 while falnet_replay (which has selected the device once) issues commands on this thread
 static inline void falnet_enter_stream(void* stream) {
-    if (!stream) return;
+    if (!stream || *falnet_replay_depth() > 0) return;
     hipDevice_t dev;
     int cur = -1;
     if (hipStreamGetDevice((hipStream_t)stream, &dev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)dev) (void)hipSetDevice((int)dev);

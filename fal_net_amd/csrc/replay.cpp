@@ -97,6 +97,13 @@ extern "C" int falnet_replay_op_args(int op, int* nint, int* nflt) {
 
 extern "C" int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* streams, int nstreams, void* const* events, int nevents, int* failed_at) {
     FALNET_CHECK_ARG(cmds && n >= 0 && streams && nstreams > 0, "replay: bad argument");
+    // every stream of a replay belongs to one device: select it once instead of per launch (falnet_enter_stream is skipped while depth > 0)
+    falnet_enter_stream(streams[0] ? streams[0] : (nstreams > 1 ? streams[1] : nullptr));
+    struct Depth {
+        int* d;
+        Depth() : d(falnet_replay_depth()) { ++*d; }
+        ~Depth() { --*d; }
+    } depth_guard;
     for (int i = 0; i < n; ++i) {
         const falnet_cmd_t& c = cmds[i];
         int rc = 0;
