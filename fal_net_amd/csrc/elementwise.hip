@@ -271,31 +271,48 @@ __global__ __launch_bounds__(256) void const_plane_stats_kernel(const T* __restr
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[k][i] = 0.f;
+    const bool has_top = r0 == 0, has_bot = r1 == TH;
     if (pl < npl) {
         for (int y = r0; y < r1; ++y) {
             const bool top = y == 0, bot = y == TH - 1;
             const T* row = g + (((int64_t)b * TH + y) * TW) * gC + seg * 8;
+            float rs[8];  // this thread's share of the row
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rs[i] = 0.f;
             for (int x = pl; x < TW; x += npl) {
                 float v[8];
                 load8_as(row + (int64_t)x * gC, v);
-                const bool lf = x == 0, rt = x == TW - 1;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    st[0][i] += v[i];
-                    if (top) st[1][i] += v[i];
-                    if (bot) st[2][i] += v[i];
-                    if (lf) st[3][i] += v[i];
-                    if (rt) st[4][i] += v[i];
-                    if (top && lf) st[5][i] += v[i];
-                    if (top && rt) st[6][i] += v[i];
-                    if (bot && lf) st[7][i] += v[i];
-                    if (bot && rt) st[8][i] += v[i];
+                for (int i = 0; i < 8; ++i) rs[i] += v[i];
+                if (x == 0) {  // two pixels per row: the column sums and the corners (compile-time indices: no scratch)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        st[3][i] += v[i];
+                        if (top) st[5][i] += v[i];
+                        if (bot) st[7][i] += v[i];
+                    }
                 }
+                if (x == TW - 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        st[4][i] += v[i];
+                        if (top) st[6][i] += v[i];
+                        if (bot) st[8][i] += v[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                st[0][i] += rs[i];
+                if (top) st[1][i] += rs[i];
+                if (bot) st[2][i] += rs[i];
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
+        if ((k == 1 || k == 5 || k == 6) && !has_top) continue;  // (block-uniform) sums this block cannot have
+        if ((k == 2 || k == 7 || k == 8) && !has_bot) continue;
 #pragma unroll
         for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = st[k][i];
         __syncthreads();

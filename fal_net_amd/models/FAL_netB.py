@@ -288,10 +288,8 @@ class FalnetPlan:
                                          pc.cin * 9, L.ptr(ws), self.B, OH, OW, gC, pc.cout, IH, IW, pc.stride, L.dtype_code(self.dtype),
                                          name="wgrad " + name + "[flow plane]")
 
-            def call(main_call=main_call, plane_call=plane_call):
-                main_call()
-                plane_call()
-            call.tag, call.flops, call.name = main_call.tag, main_call.flops, main_call.name
+            self._side_call(plane_call)  # (independent of the MFMA launch: it goes to the side stream, which idles at the end of backward)
+            call = main_call
         else:
             call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
                                    pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
@@ -642,6 +640,9 @@ class FalnetPlan:
                 self._wgrad(pcc, srcs, ih, iw, g_a, name=cname, on_main=tail or cname in extra)
                 if i > 0:  # data gradient into the previous level's output (already holds the skip contribution)
                     self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
+            # hand the side / third streams their pending weight gradients BEFORE the main stream's own tail launches: the hand-over event is
+            # recorded behind whatever the main stream was given last, and behind the tail it would hold them back by ~130 us (traced step)
+            self.bwd_body.append(lambda: (self._flush_side(), self._deep_stream is not None and self._flush_deep()))
             self.bwd_body.extend(getattr(self, "_main_tail", []))
             self._finish.append((3, len(self.bwd_body)))
             # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
