@@ -642,7 +642,8 @@ class FalnetPlan:
                     self._dgrad(pcc, 0, g_a, gc[i - 1], ih, iw, addend=gc[i - 1], actout=c[i - 1], name=cname)
             # hand the side / third streams their pending weight gradients BEFORE the main stream's own tail launches: the hand-over event is
             # recorded behind whatever the main stream was given last, and behind the tail it would hold them back by ~130 us (traced step)
-            self.bwd_body.append(lambda: (self._flush_side(), self._deep_stream is not None and self._flush_deep()))
+            if L.ab("FALNET_TAIL_FLUSH", "1") == "1":
+                self.bwd_body.append(lambda: (self._flush_side(), self._deep_stream is not None and self._flush_deep()))
             self.bwd_body.extend(getattr(self, "_main_tail", []))
             self._finish.append((3, len(self.bwd_body)))
             # per bucket: one batched slab reduce + one batched bias-gradient launch after the bucket's last wgrad, then the
