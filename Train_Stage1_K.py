@@ -101,6 +101,8 @@ def main(step='stage1_step'):
     if stage2 and network_data is None:  # --synthetic: seeded stand-in for the Stage-1 model
         network_data = {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
     m_model = models.__dict__[args.m_model](network_data, no_levels=args.no_levels, compute_dtype=dtype).to(dev)
+    if isinstance(network_data, dict) and 'loss_scaler' in network_data and train.loss_scaler(m_model) is not None:
+        train.loss_scaler(m_model).load_state_dict(network_data['loss_scaler'])  # resumed f16 run: continue at the scale it had reached
     fix_model = None
     if stage2:  # frozen Stage-1 teacher (Train_Stage2_K.py:190-198)
         fix_data = torch.load(args.fix_model, map_location='cpu') if args.fix_model else {'state_dict': synthetic.seeded_state_dict(args.m_model[-1], args.no_levels)}
@@ -217,8 +219,11 @@ def main(step='stage1_step'):
             # inside the next epoch's first gradient all-reduce, whose RCCL timeout that time would count against
             dist.barrier()
         if rank == 0:
-            utils.save_checkpoint({'epoch': epoch + 1, 'm_model': args.m_model, 'state_dict': m_model.state_dict(), 'best_rmse': best},
-                                  is_best, save_path)
+            ckpt = {'epoch': epoch + 1, 'm_model': args.m_model, 'state_dict': m_model.state_dict(), 'best_rmse': best}
+            sc = train.loss_scaler(m_model)
+            if sc is not None:
+                ckpt['loss_scaler'] = sc.state_dict()  # (an extra key: the reference's loader reads only the four above)
+            utils.save_checkpoint(ckpt, is_best, save_path)
     if world > 1:
         dist.destroy_process_group()
 

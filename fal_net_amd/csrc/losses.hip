@@ -460,11 +460,14 @@ __global__ void loss_seeds_kernel(const float* __restrict__ scaler, const float*
 }
 __global__ void loss_scale_update_kernel(float* scaler, float growth, float backoff, float interval, float min_scale, float max_scale) {
     if (scaler[2] != 0.f) {
+        // scaler[1] < 0 marks an overflow at a scale that was ALREADY at its floor (LossScaler.check: the run is diverging); a back-off that
+        // merely arrives at the floor is not one -- no step has been tried there yet
+        const bool at_floor = scaler[0] <= min_scale;
         scaler[0] = fmaxf(scaler[0] * backoff, min_scale);
-        scaler[1] = 0.f;
+        scaler[1] = at_floor ? -1.f : 0.f;
         scaler[3] += 1.f;
     } else {
-        scaler[1] += 1.f;
+        scaler[1] = fmaxf(scaler[1], 0.f) + 1.f;
         if (scaler[1] >= interval) {
             scaler[0] = fminf(scaler[0] * growth, max_scale);
             scaler[1] = 0.f;

@@ -111,15 +111,18 @@ def synthetic_pair(batch, height, width, seed=1234, max_disp=300.0, distinct=Fal
     return left, right, min_disp, md
 
 
-def structured_stereo(batch, height, width, seed=77, d_lo=3.0, d_hi=24.0, max_disp=300.0):
+def structured_stereo(batch, height, width, seed=77, d_lo=None, d_hi=None, max_disp=300.0):
     """A stereo pair with a KNOWN disparity field (seeded, no dataset): a band-limited textured left image and a smooth right-view
-    disparity d_r in [d_lo, d_hi] pixels (larger towards the bottom, as on a road scene, plus two low-frequency bumps per sample);
+    disparity d_r in [d_lo, d_hi] pixels (default 3 .. 24 px per 256 px of width; larger towards the bottom, as on a road scene, plus two low-frequency bumps per sample);
     the right image is the left one sampled at x + d_r(x, y) (the geometry the network's plane sweep synthesises:
     models/FAL_netB.py:255-262).  The Stage-1 loss then has a defined minimum and the trained disparity can be scored against ground
     truth (tools/trajectory.py).  Returns left, right, min_disp, max_disp as synthetic_pair does, plus the ground-truth LEFT-view
     disparity (B, 1, H, W): d_l(x + d_r(x)) = d_r(x), solved by fixed-point iteration (|d d_r / dx| << 1: no occlusions)."""
     g = torch.Generator().manual_seed(seed)
     F = torch.nn.functional
+    # disparity range as a fraction of the width (3 .. 24 px at W = 256): the same geometry at every size
+    d_lo = 3.0 * width / 256 if d_lo is None else d_lo
+    d_hi = 24.0 * width / 256 if d_hi is None else d_hi
 
     def band(ch, cells, amp):  # smooth random field: coarse noise, bicubic up (CPU data synthesis, not on the hot path)
         z = torch.rand(batch, ch, max(2, height // cells), max(2, width // cells), generator=g)

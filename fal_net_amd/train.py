@@ -112,6 +112,13 @@ class LossScaler:
     def scale_tensor(self):
         return self.state[0]
 
+    def state_dict(self):
+        """For checkpoints: a resumed f16 run continues at the scale it had reached instead of re-discovering it from the initial 8192."""
+        return {"state": [float(x) for x in self.state.tolist()]}
+
+    def load_state_dict(self, sd):
+        self.state.copy_(torch.tensor([float(x) for x in sd["state"]], device=self.state.device))
+
     def update(self):
         L.check(L.lib().falnet_loss_scale_update(L.ptr(self.state), self.growth, self.backoff, self.interval, self.min_scale, self.max_scale,
                                                  L.stream_ptr()), "loss_scale_update")
@@ -120,7 +127,7 @@ class LossScaler:
         """Host-side health check (synchronises: call it at logging frequency, not per step).  Returns (scale, skipped steps);
         raises when the scale has backed off to its floor and the last step still overflowed -- the run is diverging."""
         scale, clean, flag, skipped = (float(x) for x in self.state.tolist())
-        if scale <= self.min_scale and clean == 0 and skipped > 0:
+        if clean < 0:  # (set by falnet_loss_scale_update when a step overflowed at a scale that was already at its floor)
             raise FloatingPointError(f"f16 step: gradients are non-finite even at loss scale {scale} ({int(skipped)} steps skipped): "
                                      "the run diverged (use --dtype bf16 / f32 or a lower learning rate)")
         return scale, int(skipped)
@@ -262,7 +269,16 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
     launches of 4-5 us on `l1 + a_p * perc`, `rec + a_sm * sm`, output clones, gradient sums and seed fills).  `rpan` /
     `ldisp` in the result alias the plan's output buffers: valid until the model's next forward of this shape."""
     with L.stream_scope():  # one stream lookup for the ~330 launches of the step
-        return _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize)
+        try:
+            return _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize)
+        except BaseException:
+            # the loss accumulators are zero on entry by contract (falnet_step_scalars re-zeroes them at the END of a step): a step that
+            # fails in between must not leave its partial sums for the next one
+            for plan in getattr(model, "_plans", {}).values():
+                S = plan.buf.get("step_scalars")
+                if S is not None:
+                    S.zero_()
+            raise
 
 
 def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize):

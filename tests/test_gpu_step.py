@@ -483,6 +483,11 @@ def test_f16_overflow_skips_the_step_and_backs_the_scale_off(fused):
         assert sc.check()[0] == 8192.0 * 2 or sc.check()[0] == 8192.0  # (one or two clean steps since the last change)
         train.stage1_step(m, opt, left, right, mx)
         assert sc.check()[0] >= 8192.0 * 2
+        # a back-off that merely ARRIVES at the floor is not a diverged run: no step has been tried at that scale yet
+        sc.state[0], sc.min_scale, sc.max_scale = 2.0 ** 41, 2.0 ** 40, 2.0 ** 42
+        train.stage1_step(m, opt, left, right, mx)
+        assert sc.check()[0] == 2.0 ** 40
+        assert train.LossScaler(DEV).state_dict()["state"][0] == 8192.0  # (checkpointable: Train_Stage1_K.py saves / restores it)
         # a scale at its floor that still overflows is a diverged run: check() raises
         sc.state[0], sc.min_scale, sc.max_scale = 2.0 ** 40, 2.0 ** 40, 2.0 ** 41
         train.stage1_step(m, opt, left, right, mx)
