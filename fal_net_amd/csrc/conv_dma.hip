@@ -341,9 +341,11 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int
 // ELU', store) runs once per class on the interleaved output positions.
 #define SD_PW 33  // patch columns: 32 + the +1 halo
 
-template <typename T>
+// MT = rows per wave: 2 -> 16 x 32 gout positions per tile; 1 -> 8 x 32 (round 4): conv3 / conv4 have 32 / 8 sixteen-row tiles per
+// channel block at B = 8 -- 128 / 64 workgroups for 256 CUs -- and twice as many eight-row ones.
+template <typename T, int MT = 2>
 __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles, int GH, int GW) {
-    constexpr int TH = 16, NWAVES = 8, BN = 32, MT = 2;
+    constexpr int NWAVES = 8, BN = 32, TH = NWAVES * MT;
     constexpr int KCV = 32;
     constexpr int NPIX = (TH + 1) * SD_PW;
     constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
@@ -554,17 +556,25 @@ bool falnet_conv_s2d_dma_applicable(const falnet_conv_t* d, int n) {
 int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
     const falnet_conv_t& p = d[3];
     const int GH = p.IH, GW = p.IW;  // the upstream-gradient grid
-    const int tiles_x = (GW + 31) / 32, tiles_y = (GH + 15) / 16;
-    const int ntiles = p.B * tiles_x * tiles_y;
     const int ny = (p.Cout + 31) / 32;
+    const int tiles_x = (GW + 31) / 32;
+    static const int force_mt = [] { const char* e = falnet_ab_env("FALNET_S2D_MT"); return e ? atoi(e) : 0; }();
+    // eight-row tiles when sixteen-row ones leave CUs idle (fewer workgroups than CUs)
+    const bool small = force_mt ? force_mt == 1 : p.B * tiles_x * ((GH + 15) / 16) * ny < 256;
+    const int th = small ? 8 : 16;
+    const int tiles_y = (GH + th - 1) / th;
+    const int ntiles = p.B * tiles_x * tiles_y;
     int gx = 256 / ny;
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-    if (p.dtype == FALNET_F16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+#define S2D_L(T)                                                                                                                                     \
+    do {                                                                                                                                             \
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<T, 1>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<T, 2>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);        \
+    } while (0)
+    FALNET_DISPATCH_16(p.dtype, S2D_L);
+#undef S2D_L
     FALNET_RETURN_LAUNCH();
 }
 

@@ -436,7 +436,7 @@ bool falnet_head_fwd_lds2_launch(const float* dlog0, const float* left, const fl
 // (Measured and dropped: one pixel per thread with the pixel's whole 128-B output line held in registers and written at the end --
 // no faster than the paired 32-B stores, 167 vs 169 us.)
 template <typename OUT, int PPT, int NT>
-__global__ __launch_bounds__(NT) void med_head_bwd_lds2_kernel(
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void med_head_bwd_lds2_kernel(
     const float* __restrict__ dlog0, const float* __restrict__ left, const float* __restrict__ min_disp,
     const float* __restrict__ max_disp, const float* __restrict__ disp, const float* __restrict__ p_im0,
     const float* __restrict__ stats, const float* __restrict__ gdisp, const float* __restrict__ gpan,

@@ -328,7 +328,7 @@ def test_pack_after_optimizer_tracks_weight_changes(monkeypatch):
 
 
 def test_reduced_precision_trains_like_f32():
-    """300 Stage-1 steps on STRUCTURED synthetic stereo (synthetic.structured_stereo: the right view is the left one displaced by a smooth
+    """400 Stage-1 steps on STRUCTURED synthetic stereo (synthetic.structured_stereo: the right view is the left one displaced by a smooth
     known disparity, so the self-supervised loss has a defined minimum and ground truth exists), from the same seeded weights, in f32, bf16
     and f16 (tools/trajectory.py; the 600-step run and the deterministic control are in profiles/r04_trajectory_*.json).  The f32 path must
     LEARN the disparity (depth abs_rel against ground truth 0.70 at the seeded weights -> < 0.12), and each 16-bit path must reach
@@ -337,14 +337,15 @@ def test_reduced_precision_trains_like_f32():
     spec = importlib.util.spec_from_file_location("trajectory", os.path.join(os.path.dirname(__file__), "..", "tools", "trajectory.py"))
     traj = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(traj)
-    r = traj.run(steps=300, height=128, width=256, batch=4, pool=8, levels=49, dtypes=("f32", "bf16", "f16"))
+    r = traj.run(steps=400, height=128, width=256, batch=4, pool=8, levels=49, dtypes=("f32", "bf16", "f16"))
     print(r)
     f32 = r["f32"]
     assert f32["finite"] and f32["loss_last"] < 0.6 * f32["loss_first"]
     assert f32["abs_rel_vs_gt_start"] > 0.4 and f32["abs_rel_vs_gt"] < 0.12, f32
     for k in ("bf16", "f16"):
         assert r[k]["finite"] and r[k]["loss_last"] < 0.6 * r[k]["loss_first"], (k, r[k])
-        assert r[k]["abs_rel_vs_gt"] <= 1.5 * f32["abs_rel_vs_gt"] + 0.005, (k, r[k]["abs_rel_vs_gt"], f32["abs_rel_vs_gt"])
+        # (ten runs of this configuration, round 4: every dtype 0.024-0.035 at 400 steps; a path that does not train stays above 0.1)
+        assert r[k]["abs_rel_vs_gt"] <= 1.5 * f32["abs_rel_vs_gt"] + 0.01, (k, r[k]["abs_rel_vs_gt"], f32["abs_rel_vs_gt"])
         assert r[k]["abs_rel_vs_gt_heldout"] <= 1.5 * f32["abs_rel_vs_gt_heldout"] + 0.01, (k, r[k], f32)
 
 
