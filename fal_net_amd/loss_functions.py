@@ -87,6 +87,7 @@ class _VggPlan:
             self.outs.append(pooled)
             cur, h, w = pooled, h // 2, w // 2
         self.run_fwd = ops.ReplayList(self.fwd, eager_head=1)  # (the first conv reads the caller's image: set_input per call)
+        self.run_bwd = None
         if not need_grad:
             return
         # ---- backward: gradients of the three pooled outputs -> gradient of the planar f32 input ----
@@ -122,8 +123,6 @@ class _VggPlan:
                     from_pool = any(x is o for o in self.outs)
                     gin = torch.empty_like(x)
                     own = next((g for o, g in zip(self.outs, self.gouts) if x is o), None)  # perceptual gradient of that slice
-                    if own is not None and getattr(self, "bwd_split", None) is None:
-                        self.bwd_split = len(self.bwd)  # first launch that reads the feature gradient of slice 1 / 2 (slice 3's feeds bwd[0])
                     self.bwd.append(_conv(dtype, [ops.nhwc_src(g_next)], h, w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9,
                                                   pc.cin_pad, 1, B, h, w, gin, h, w, pc.cin_pad, pc.cin_pad, addend=own,
                                                   actout=None if from_pool else x,
@@ -131,16 +130,7 @@ class _VggPlan:
                                                   flops=2 * B * h * w * pc.cout * pc.cin * 9))
                     self.keep.append(gin)
                     g_next = gin
-        k = getattr(self, "bwd_split", None) or 0
-        self._run_bwd_a, self._run_bwd_b = ops.ReplayList(self.bwd[:k]), ops.ReplayList(self.bwd[k:])
-
-    def run_bwd(self, join=None):
-        """The data-gradient chain; `join()` runs in front of the first launch that reads the feature gradients of slices 1 / 2 (the fused step
-        computes those two MSE terms on another stream beside the first launches of this chain)."""
-        self._run_bwd_a()
-        if join is not None:
-            join()
-        self._run_bwd_b()
+        self.run_bwd = ops.ReplayList(self.bwd)
 
 
 class _VggFunction(torch.autograd.Function):

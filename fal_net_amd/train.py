@@ -250,7 +250,6 @@ def vgg_label_async(label, borrow=True):
 
 
 _FUSED_STEP = _os.environ.get("FALNET_FUSED_STEP", "1") == "1"
-_OVERLAP_LOSSES = L.ab("FALNET_OVERLAP_LOSSES", "1") == "1"  # fused step: HBM-bound loss passes on the auxiliary stream beside MFMA-bound launches
 _ADAM_PACK = L.ab("FALNET_ADAM_PACK", "1") == "1"  # FlatAdam.step: optimiser update fused with the weight re-pack (falnet_adam_pack_batched)
 _SEEDS = {}
 
@@ -311,13 +310,6 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
     rpan, ldisp = b["p_im0"], b["disp"]
     rt = right.detach().contiguous()
     st = L.stream_ptr()
-    # HBM-bound loss passes beside MFMA-bound launches (round 4): the smoothness term (needs only the disparity) runs on the auxiliary stream
-    # beside the VGG forward of the synthesised view, the perceptual MSE of slices 1 and 2 beside the first data gradients of the VGG adjoint
-    # (only slice 3's gradient is needed at its start).  Not in deterministic mode (the ordered scalar reductions share one workspace and
-    # must stay on one stream), not in bench.py's instrumented pass.
-    overlap = (_OVERLAP_LOSSES and a_p > 0 and not L.DETERMINISTIC and ops.TIMER is None and not torch.cuda.is_current_stream_capturing())
-    aux = _aux_stream(dev) if overlap else None
-    main = torch.cuda.current_stream() if overlap else None
     S = plan.buf.get("step_scalars")  # [rec = L1 + a_p * perceptual, sm]: zero on entry (falnet_step_scalars re-zeroes it at the end of every step)
     if S is None:
         S = plan.buf["step_scalars"] = torch.zeros(2, device=dev)
@@ -327,17 +319,6 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
     if a_p <= 0:  # no perceptual term: the L1 gradient is the whole gradient of the synthesised view
         L.check(lib.falnet_l1_fwd_bwd(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(g_pan), st),
                 "l1_fwd_bwd")  # loss_functions.py:53
-    x0 = int(0.20 * W)
-    sc_sm = 1.0 / (B * H * (W - x0))
-
-    def smooth(stream):
-        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), L.ptr(seed_sm),
-                                          L.ptr(g_disp), stream), "smooth_fwd_bwd")
-    smooth_on_aux = overlap and a_sm > 0
-    if smooth_on_aux:
-        aux.wait_stream(main)  # the disparity is out
-        with L.on_stream(aux):
-            smooth(L.stream_ptr())
     vplan = None
     if a_p > 0:
         vm = LF.vgg._get()
@@ -354,24 +335,17 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
             Bo, Ho, Wo, Co = o.shape
             sc = 1.0 / o.numel()
             feats.append((o, ln, Bo * Ho * Wo, Co, sc))
-        def mse(i, stream):
-            (o, ln, npix, Co, sc), go = feats[i], vplan.gouts[i]
-            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(seed_p), L.ptr(go), code, stream),
+        for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
+            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(seed_p), L.ptr(go), code, st),
                     "mse_fwd_bwd")
-        if overlap and len(feats) == 3:
-            mse(2, st)  # the deepest slice's gradient starts the adjoint chain
-            aux.wait_stream(main)
-            with L.on_stream(aux):
-                mse(0, L.stream_ptr())
-                mse(1, L.stream_ptr())
-        else:
-            for i in range(len(feats)):
-                mse(i, st)
-    if a_sm > 0 and not smooth_on_aux:  # Train_Stage1_K.py:255
-        smooth(st)
+    x0 = int(0.20 * W)
+    sc_sm = 1.0 / (B * H * (W - x0))
+    if a_sm > 0:  # Train_Stage1_K.py:255
+        L.check(lib.falnet_smooth_fwd_bwd(L.ptr(b["left"]), L.ptr(ldisp), B, H, W, x0, W, 2.0, sc_sm, L.ptr(S[1:]), L.ptr(seed_sm),
+                                          L.ptr(g_disp), st), "smooth_fwd_bwd")
     # ---- the VGG adjoint (every node is linear in its upstream scalar: s = loss scale) joins the L1 gradient ----
     if vplan is not None:
-        vplan.run_bwd(join=(lambda: main.wait_stream(aux)) if overlap else None)
+        vplan.run_bwd()
         # L1 term (loss_functions.py:53) and its gradient, with the VGG gradient of the synthesised view added in the same pass
         L.check(lib.falnet_l1_fwd_bwd_add(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(vplan.g_in), L.ptr(g_pan), st),
                 "l1_fwd_bwd_add")
