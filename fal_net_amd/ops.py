@@ -125,7 +125,14 @@ def conv_signature(d):
             + ("|up2" if d.weight_up2 else ""))
 
 
+# What-if probe (experiments only, FALNET_AB=1): launches whose name contains one of these comma-separated substrings are NOT issued -- wrong
+# results, valid timing: how much of the step does a launch (or a family) really cost beside everything that overlaps it?
+_PROBE_SKIP = [x for x in L.ab("FALNET_PROBE_SKIP", "").split(",") if x]
+
+
 def _timed(tag, flops, nbytes, launch, name=""):
+    if _PROBE_SKIP and any(x in name for x in _PROBE_SKIP):
+        launch = lambda *a: None  # noqa: E731
     def call(*a):
         t = TIMER
         if t is None:
