@@ -250,8 +250,8 @@ def test_conv_fused_maxpool_records_argmax_for_backward(B, cin, cout, H, W, dtyp
     x_t = to_nhwc(xs[0], dtype)
     # reference on the operands the kernel sees (rounded to the compute type), so that the arg-max of near-ties agrees
     xr, wr = xs[0].to(dtype).float(), w.to(dtype).float()
-    y = F.conv2d(xr, wr, b, padding=1).requires_grad_(True)  # pre-activation: the adjoint includes relu' (an all-zero window passes nothing)
-    pooled_ref = F.max_pool2d(F.relu(y), 2, 2)
+    y = F.relu(F.conv2d(xr, wr, b, padding=1)).requires_grad_(True)
+    pooled_ref = F.max_pool2d(y, 2, 2)
     g = torch.Generator().manual_seed(3)
     gy = torch.randn(B, cout, H // 2, W // 2, generator=g)
     pooled_ref.backward(gy)
@@ -265,7 +265,7 @@ def test_conv_fused_maxpool_records_argmax_for_backward(B, cin, cout, H, W, dtyp
     finally:
         ops.AUTOTUNE = old
     gy_t = to_nhwc(gy, dtype)
-    # (B, H, W, C) in the compute type: the pooled gradient at the arg-max where ReLU passes, zero elsewhere
+    want = to_nhwc(y.grad * 0 + y.grad, dtype)  # (B, H, W, C) in the compute type: the pooled gradient at the arg-max, zero elsewhere
     want = (to_nhwc(gy, dtype).float().repeat_interleave(2, 1).repeat_interleave(2, 2) * (y.grad != 0).permute(0, 2, 3, 1).to(DEV)).to(dtype)
     ran = []
     for variant in list(range(2, 11)) + [13, 16]:
