@@ -51,7 +51,7 @@ class Conv(C.Structure):
                 ("actout_kind", C.c_int32), ("dtype", C.c_int32), ("ksplit", C.c_int32), ("splitk_ws", C.c_void_p),
                 ("splitk_ws_bytes", C.c_int64), ("variant", C.c_int32), ("pool_out", C.c_void_p),
                 ("pool_mode", C.c_int32), ("pool_actout_kind", C.c_int32), ("pool_actout", C.c_void_p), ("weight_up2", C.c_void_p),
-                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64), ("pool_idx", C.c_void_p)]
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_int64)]
 
 
 class Wgrad(C.Structure):
@@ -127,7 +127,6 @@ SIGNATURES = {
     "falnet_wgrad_const_plane": [_P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "falnet_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "falnet_maxpool2_bwd_idx": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "falnet_act_bwd": [_P, _P, _P, _L, _I, _I, _P],
     "falnet_med_head_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "falnet_med_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -174,7 +173,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 402
+EXPECTED_VERSION = 401
 
 
 def lib():

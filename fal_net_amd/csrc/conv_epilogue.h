@@ -196,15 +196,7 @@ template <typename T, int MT, int NT>
 struct PackedOut {  // epilogue_direct<..., DEFER = true> fills it, epilogue_store_packed writes it out
     PackedTile<T> out[MT][NT];
     PackedTile<T> pool[(MT + 1) / 2][NT];
-    unsigned long long pidx[(MT + 1) / 2][NT];  // argmax / sign nibbles of the pooled tile (falnet_conv_t::pool_idx)
 };
-
-// word of falnet_conv_t::pool_idx for the pooled pixel at element offset `po` of pool_out (channel stride `cstride`), 32-channel block `cbase`, lane half h
-__device__ __forceinline__ void pool_idx_store(const falnet_conv_t& p, int64_t po, int cbase, int h, unsigned long long word) {
-    if (po < 0 || cbase >= p.Cout) return;
-    const int64_t pix = po / p.out_cstride;
-    reinterpret_cast<unsigned long long*>(p.pool_idx)[(pix * ((p.Cout + 31) >> 5) + (cbase >> 5)) * 2 + h] = word;
-}
 
 // ---- 16x16x32 MFMA form of a 32 (channels) x 32 (positions) tile -------------------------------------------------------------
 // v_mfma_f32_16x16x32 holds the chip's clock higher than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, MFMA shape: 1.12-1.15x
@@ -303,12 +295,10 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
     T* pool_out = reinterpret_cast<T*>(p.pool_out);
     const bool pooling = POOL && pool_out != nullptr;
     const bool psum = p.pool_mode == 1;
-    const bool want_idx = POOL && pooling && !psum && p.pool_idx != nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int cbase = nbase + nt * 32;
         float hp[16];
-        unsigned hx0 = 0;  // per value: the maximum of the upper row's pair sits in the odd column
         // residual / activation-output operands: fetched one row slab AHEAD (branch-free loads, conv_epilogue.h: tile_fetch), so their latency
         // sits behind the previous slab's arithmetic and stores instead of in front of every 16-B load
         constexpr int NR = AHEAD < 0 ? 1 : 1 + AHEAD;
@@ -367,38 +357,18 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
 #pragma unroll
                         for (int j = 0; j < 16; ++j) m[j] = fmaxf(v[j], lane_xor1(v[j]));
                     }
-                    unsigned hx = 0;  // (even lanes, the ones that store: this lane is the pair's first column; ties go to the first position)
-                    if (want_idx) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) hx |= (m[j] > v[j] ? 1u : 0u) << j;
-                    }
                     if ((mt & 1) == 0) {
 #pragma unroll
                         for (int j = 0; j < 16; ++j) hp[j] = m[j];
-                        hx0 = hx;
                     } else {
-                        unsigned long long word = 0;
                         if (psum) {
 #pragma unroll
                             for (int j = 0; j < 16; ++j) m[j] += hp[j];
                         } else {
-                            if (want_idx) {
-#pragma unroll
-                                for (int j = 0; j < 16; ++j) {
-                                    const bool lower = m[j] > hp[j];
-                                    const unsigned arg = lower ? 2u + ((hx >> j) & 1u) : ((hx0 >> j) & 1u);
-                                    const unsigned nib = arg | ((fmaxf(m[j], hp[j]) > 0.f ? 1u : 0u) << 2);
-                                    word |= (unsigned long long)nib << (4 * j);
-                                }
-                            }
 #pragma unroll
                             for (int j = 0; j < 16; ++j) m[j] = fmaxf(m[j], hp[j]);
                         }
                         const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
-                        if (want_idx) {
-                            if constexpr (DEFER) defer->pidx[mt >> 1][nt] = word;
-                            else pool_idx_store(p, po, cbase, h, word);
-                        }
                         if (p.pool_actout) {
                             float a[16];
                             tile_load<T>(reinterpret_cast<const T*>(p.pool_actout), po, cbase, h, p.Cout, a);
@@ -427,7 +397,6 @@ __device__ __forceinline__ void epilogue_store_packed(const falnet_conv_t& p, Pa
             if (out) tile_store_packed<T>(out, pixoff(mt), cbase, h, p.Cout, d.out[mt][nt]);
             if ((mt & 1) && pool_out) {
                 const int64_t po = (lane & 1) ? (int64_t)-1 : pooloff(mt);
-                if (p.pool_idx && p.pool_mode == 0) pool_idx_store(p, po, cbase, h, d.pidx[mt >> 1][nt]);
                 tile_store_packed<T>(pool_out, po, cbase, h, p.Cout, d.pool[mt >> 1][nt]);
             }
         }

@@ -204,38 +204,6 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_vec_kernel(const T* _
     }
 }
 
-// The same adjoint from the nibbles a fused-pool conv launch recorded (falnet_conv_t::pool_idx): a thread owns one pooled pixel x 32 channels --
-// two index words, 32 gradient values in, 4 x 32 out; the full-resolution activation is not read (it need not exist).
-template <typename T>
-__global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_idx_kernel(const unsigned long long* __restrict__ idx, const T* __restrict__ gy,
-                                                                      T* __restrict__ gx, int B, int H, int W, int C) {
-    const int OH = H / 2, OW = W / 2, nb = C / 32;
-    const int64_t total = (int64_t)B * OH * OW * nb;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cb = (int)(i % nb), ox = (int)((i / nb) % OW), oy = (int)((i / ((int64_t)nb * OW)) % OH);
-        const int b = (int)(i / ((int64_t)nb * OW * OH));
-        const ulonglong2 w = reinterpret_cast<const ulonglong2*>(idx)[i];
-        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + cb * 32;
-        const int64_t off[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
-        const T* gp = gy + (((int64_t)b * OH + oy) * OW + ox) * C + cb * 32;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {  // channels 8 q .. 8 q + 7
-            float g[8], o[4][8];
-            load8_as(gp + 8 * q, g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int hh = (e >> 2) & 1, jj = 4 * q + (e & 3);
-                const unsigned nib = (unsigned)(((hh ? w.y : w.x) >> (4 * jj)) & 15ull);
-                const float ge = (nib & 4u) ? g[e] : 0.f;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) o[a][e] = (nib & 3u) == (unsigned)a ? ge : 0.f;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) store8_as(gx + base + off[a] + 8 * q, o[a]);
-        }
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                              T* __restrict__ gx, int64_t n, int kind) {
@@ -427,16 +395,6 @@ extern "C" int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy,
     }
     const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
 #define EW_L(T) hipLaunchKernelGGL(maxpool2_bwd_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C)
-    FALNET_DISPATCH_DTYPE(dtype, EW_L);
-#undef EW_L
-    FALNET_RETURN_LAUNCH();
-}
-
-extern "C" int falnet_maxpool2_bwd_idx(const void* idx, const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream) {
-    FALNET_ENTER(stream);
-    FALNET_CHECK_ARG(idx && gy && gx && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 32 == 0, "maxpool2_bwd_idx: bad argument (even H, W; C %% 32 == 0)");
-    const int64_t total = (int64_t)B * (H / 2) * (W / 2) * (C / 32);
-#define EW_L(T) hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<T>, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const unsigned long long*)idx, (const T*)gy, (T*)gx, B, H, W, C)
     FALNET_DISPATCH_DTYPE(dtype, EW_L);
 #undef EW_L
     FALNET_RETURN_LAUNCH();

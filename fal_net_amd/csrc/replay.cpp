@@ -66,7 +66,7 @@ const Op g_ops[] = {
     FALNET_OP(falnet_bias_grad), FALNET_OP(falnet_pack_weights_batched), FALNET_OP(falnet_adam_pack_batched), FALNET_OP(falnet_adam_ranges),
     FALNET_OP(falnet_adam_tick), FALNET_OP(falnet_pack_up2_batched), FALNET_OP(falnet_wgrad_reduce_batched), FALNET_OP(falnet_bias_grad_batched),
     FALNET_OP(falnet_bias_grad_batched_det), FALNET_OP(falnet_pack_weights), FALNET_OP(falnet_nchw_to_nhwc), FALNET_OP(falnet_nhwc_to_nchw),
-    FALNET_OP(falnet_upsample_bwd), FALNET_OP(falnet_wgrad_const_plane), FALNET_OP(falnet_maxpool2_fwd), FALNET_OP(falnet_maxpool2_bwd), FALNET_OP(falnet_maxpool2_bwd_idx),
+    FALNET_OP(falnet_upsample_bwd), FALNET_OP(falnet_wgrad_const_plane), FALNET_OP(falnet_maxpool2_fwd), FALNET_OP(falnet_maxpool2_bwd),
     FALNET_OP(falnet_act_bwd), FALNET_OP(falnet_med_head_fwd), FALNET_OP(falnet_med_head_bwd), FALNET_OP(falnet_med_head_bwd_nhwc),
     FALNET_OP(falnet_med_masks_fwd), FALNET_OP(falnet_med_maskr_acfalse_fwd), FALNET_OP(falnet_l1_fwd), FALNET_OP(falnet_l1_bwd),
     FALNET_OP(falnet_mse_fwd), FALNET_OP(falnet_mse_bwd), FALNET_OP(falnet_smooth_fwd), FALNET_OP(falnet_smooth_bwd), FALNET_OP(falnet_l1_fwd_bwd),

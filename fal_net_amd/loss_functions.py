@@ -62,24 +62,14 @@ class _VggPlan:
                 pc = pcs[idx]
                 last = idx == convs[-1]
                 pooled = torch.empty(B, h // 2, w // 2, pc.cout, dtype=dtype, device=device) if last else None
+                y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device) if (need_grad or not last) else None
                 kw = dict(bias=pc.bias, act=L.ACT_RELU, name=f"vgg conv{idx}", flops=2 * B * h * w * pc.cout * pc.cin * 9)
                 args = (dtype, [ops.nhwc_src(cur)], h, w, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, h, w)
-                fused, pidx, y = False, None, None
-                if last and need_grad and cur is not x0 and pc.cout % 32 == 0 and L.ab("FALNET_FUSED_POOL", "1") == "1" and L.ab("FALNET_POOL_IDX", "1") == "1":
-                    # backward needs only WHERE each maximum came from and whether ReLU passed: the fused-pool epilogue records 4 bits per
-                    # pooled element (falnet_conv_t::pool_idx) and the full-resolution map is neither written here nor read by the adjoint
-                    pidx = torch.empty(B, h // 2, w // 2, pc.cout // 32, 2, dtype=torch.int64, device=device)
-                    try:
-                        self.fwd.append(_conv(*args, None, h, w, pc.cout, pc.cout, pool_out=pooled, pool_idx=pidx, **kw))
-                        fused = True
-                    except ValueError:
-                        pidx = None
-                if not fused:
-                    y = torch.empty(B, h, w, pc.cout, dtype=dtype, device=device) if (need_grad or not last) else None
+                fused = False
                 if cur is x0:
                     self.c3_call = ops.conv_c3_call(dtype, x_in, pc, y, L.ACT_RELU, name="vgg conv0(c3)")
                     self.fwd.append(self.c3_call)
-                elif not fused and last and L.ab("FALNET_FUSED_POOL", "1") == "1":
+                elif last and L.ab("FALNET_FUSED_POOL", "1") == "1":
                     try:  # 2x2 max pool in the conv epilogue: the full-resolution map is not re-read (nor written at all for labels)
                         self.fwd.append(_conv(*args, y, h, w, pc.cout, pc.cout, pool_out=pooled, **kw))
                         fused = True
@@ -93,7 +83,7 @@ class _VggPlan:
                     self.fwd.append(ops.simple_call("falnet_maxpool2_fwd", L.ptr(y), L.ptr(pooled), B, h, w, pc.cout, code))
                 acts.append((pc, cur, y, h, w))
                 cur = y
-            acts.append(("pool", cur, pooled, h, w, pidx))
+            acts.append(("pool", cur, pooled, h, w))
             self.outs.append(pooled)
             cur, h, w = pooled, h // 2, w // 2
         self.run_fwd = ops.ReplayList(self.fwd, eager_head=1)  # (the first conv reads the caller's image: set_input per call)
@@ -109,18 +99,13 @@ class _VggPlan:
         slice_i = len(self.outs) - 1
         for entry in reversed(acts):
             if entry[0] == "pool":
-                _, x, pooled, h, w, pidx = entry
+                _, x, pooled, h, w = entry
                 # deeper slices feed back into this pooled output: their data gradient already holds the sum (the conv below
                 # this pool took the slice's own gradient as its epilogue addend), the deepest slice has only its own
                 gy = self.gouts[slice_i] if g_next is None else g_next
-                C_ = pooled.shape[3]
-                gx = torch.empty(B, h, w, C_, dtype=dtype, device=device)  # gradient wrt the pre-ReLU conv output feeding the pool (relu' fused)
-                if pidx is not None:
-                    self.bwd.append(ops.simple_call("falnet_maxpool2_bwd_idx", L.ptr(pidx), L.ptr(gy), L.ptr(gx), B, h, w, C_, code,
-                                                    name="falnet_maxpool2_bwd"))
-                    self.keep.append(pidx)
-                else:
-                    self.bwd.append(ops.simple_call("falnet_maxpool2_bwd", L.ptr(x), L.ptr(pooled), L.ptr(gy), L.ptr(gx), B, h, w, C_, code))
+                gx = torch.empty_like(x)  # gradient wrt the pre-ReLU conv output feeding the pool (relu' fused)
+                self.bwd.append(ops.simple_call("falnet_maxpool2_bwd", L.ptr(x), L.ptr(pooled), L.ptr(gy), L.ptr(gx), B, h, w,
+                                                x.shape[3], code))
                 g_next, slice_i = gx, slice_i - 1
                 self.keep.append(gx)
             else:

@@ -122,7 +122,7 @@ def conv_signature(d):
     flags = f"{int(bool(d.bias))}{int(bool(d.addend))}{d.act}{int(bool(d.actout))}{d.actout_kind}{int(bool(d.pool_out))}{d.pool_mode}{int(bool(d.pool_actout))}{int(bool(d.out))}"
     return (f"conv|t{d.dtype}|{srcs}|{d.IH}x{d.IW}|k{d.cin_total}|{taps}|w{d.w_taps}x{d.w_rows}|s{d.isy}|B{d.B}|{d.TH}x{d.TW}|"
             f"o{d.osy},{d.ooy},{d.oox}|{d.OH}x{d.OW}|c{d.Cout},{d.out_cstride},{d.out_layout}|f{flags}|ws{int(d.splitk_ws_bytes > 0)}"
-            + ("|up2" if d.weight_up2 else "") + ("|pidx" if d.pool_idx else ""))
+            + ("|up2" if d.weight_up2 else ""))
 
 
 # What-if probe (experiments only, FALNET_AB=1): launches whose name contains one of these comma-separated substrings are NOT issued -- wrong
@@ -359,7 +359,7 @@ def _fill_taps(d, taps):
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
               act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
-              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE, weight_up2=None, pool_idx=None):
+              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE, weight_up2=None):
     """Build one falnet_conv2d launch; returns a zero-argument callable.  `pool_out`: fused 2x2 max pool of the output
     (halo-patch kernels only; `out` may then be None when only the pooled map is needed)."""
     lib = L.lib()
@@ -379,7 +379,6 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     d.pool_mode, d.pool_actout_kind = pool_mode, pool_actout_kind
     d.pool_actout = 0 if pool_actout is None else pool_actout.data_ptr()
     d.weight_up2 = 0 if weight_up2 is None else weight_up2.data_ptr()
-    d.pool_idx = 0 if pool_idx is None else pool_idx.data_ptr()
     dev_t = out if out is not None else pool_out
     d.bias = 0 if bias is None else bias.data_ptr()
     d.addend = 0 if addend is None else addend.data_ptr()
@@ -397,7 +396,7 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
         scratch = _deep_scratch(dev_t.device, ws_owner)
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel() * 4
     ref = C.byref(d)
-    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout, weight_up2, scratch, pool_idx)
+    keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout, weight_up2, scratch)
     if AUTOTUNE and autotune and dev_t.is_cuda:
         key = conv_signature(d)
         hit = cache_get(key)

@@ -148,10 +148,6 @@ typedef struct {
                                   ksplit * ceil(B TH TW / 128 | 256) * 128 | 256 * w_rows f32; contents are meaningless between launches;
                                   launches that share it must be stream-ordered */
     int64_t scratch_bytes;
-    void* pool_idx;            /* pool_mode 0 only, else NULL: where each 2x2 maximum came from, for falnet_maxpool2_bwd_idx -- 4 bits per pooled
-                                  element (bits 1:0 = position in the window, row-major; bit 2 = maximum > 0, i.e. ReLU passes), sixteen per
-                                  uint64, [B][OH/2][OW/2][ceil(Cout/32)][2] words (word h of a 32-channel block: nibble 4 (c >> 3) + (c & 3) of
-                                  the channels with ((c >> 2) & 1) == h).  With it the full-resolution map need not be kept for backward */
 } falnet_conv_t;
 int falnet_conv2d(const falnet_conv_t* p, void* stream);
 /* First layer: 3x3 / stride 1 / pad 1 convolution of a 3-channel planar f32 image (FAL_netB.py:99 conv0, VGG19 features[0];
@@ -299,9 +295,6 @@ int falnet_wgrad_const_plane(const void* gout, const void* plane, int64_t plane_
 int falnet_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int falnet_maxpool2_bwd(const void* x, const void* y, const void* gy, void* gx, int B, int H, int W, int C,
                         int dtype, void* stream);
-/* the same adjoint from the argmax / sign nibbles a fused-pool conv launch left in falnet_conv_t::pool_idx (no full-resolution activation read):
- * gx[b, 2 oy + (a >> 1), 2 ox + (a & 1), c] = positive ? gy[b, oy, ox, c] : 0 at the recorded position a, 0 elsewhere.  C % 32 == 0. */
-int falnet_maxpool2_bwd_idx(const void* idx, const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream);
 /* maxpool2_bwd: x is the (ReLU) pool input; the gradient goes to the first maximum of each window
  * (aten tie rule) and is zero where that maximum is 0 (fused relu'); H, W even. */
 /* gx = g * act'(y) elementwise on NHWC, act' from the activation OUTPUT y (ELU: y>0?1:y+1) */

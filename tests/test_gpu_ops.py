@@ -239,57 +239,6 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 64, 16, 64), (1, 32, 96, 24, 96), (1, 64, 128, 64, 128)])
-def test_conv_fused_maxpool_records_argmax_for_backward(B, cin, cout, H, W, dtype):
-    """pool_idx: the fused-pool epilogue records where each 2x2 maximum came from and whether ReLU passed (4 bits per pooled element), and
-    falnet_maxpool2_bwd_idx scatters the pooled gradient from those nibbles alone -- against autograd of max_pool2d(relu(conv)) on every
-    variant that fuses the pool (VGG slices, loss_functions.py:21-29; the full-resolution map is neither written nor read)."""
-    case = (B, [cin], cout, H, W, 1, 3, True, L.ACT_RELU, False)
-    xs, w, b = _conv_inputs(case, seed=11)
-    pc = packed(w, b, [cin], 1, dtype)
-    x_t = to_nhwc(xs[0], dtype)
-    # reference on the operands the kernel sees (rounded to the compute type), so that the arg-max of near-ties agrees
-    xr, wr = xs[0].to(dtype).float(), w.to(dtype).float()
-    y = F.relu(F.conv2d(xr, wr, b, padding=1)).requires_grad_(True)
-    pooled_ref = F.max_pool2d(y, 2, 2)
-    g = torch.Generator().manual_seed(3)
-    gy = torch.randn(B, cout, H // 2, W // 2, generator=g)
-    pooled_ref.backward(gy)
-    old = ops.AUTOTUNE
-    ops.AUTOTUNE = False
-    try:
-        pooled = torch.empty(B, H // 2, W // 2, cout, dtype=dtype, device=DEV)
-        pidx = torch.empty(B, H // 2, W // 2, cout // 32, 2, dtype=torch.int64, device=DEV)
-        call = ops.conv_call(dtype, [ops.nhwc_src(x_t)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, None, H, W,
-                             cout, cout, bias=pc.bias, act=L.ACT_RELU, pool_out=pooled, pool_idx=pidx)
-    finally:
-        ops.AUTOTUNE = old
-    gy_t = to_nhwc(gy, dtype)
-    want = to_nhwc(y.grad * 0 + y.grad, dtype)  # (B, H, W, C) in the compute type: the pooled gradient at the arg-max, zero elsewhere
-    want = (to_nhwc(gy, dtype).float().repeat_interleave(2, 1).repeat_interleave(2, 2) * (y.grad != 0).permute(0, 2, 3, 1).to(DEV)).to(dtype)
-    ran = []
-    for variant in list(range(2, 11)) + [13, 16]:
-        call.desc.variant = variant
-        pooled.fill_(float("nan"))
-        pidx.fill_(-1)
-        rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
-        if rc == -2:
-            continue
-        assert rc == 0, (variant, L.lib().falnet_last_error())
-        gx = torch.full((B, H, W, cout), float("nan"), dtype=dtype, device=DEV)
-        L.check(L.lib().falnet_maxpool2_bwd_idx(L.ptr(pidx), L.ptr(gy_t), L.ptr(gx), B, H, W, cout, L.dtype_code(dtype), L.stream_ptr()))
-        # positions: exact except where two window entries tie after the kernel's own accumulation order (count them: must be rare)
-        nz_got, nz_want = gx.float() != 0, want.float() != 0
-        mismatch = float((nz_got != nz_want).float().mean())
-        assert mismatch < (1e-5 if dtype == torch.float32 else 2e-3), (variant, mismatch)
-        agree = nz_got & nz_want
-        assert torch.equal(gx[agree], want[agree]), variant
-        assert float(nz_got.float().sum()) <= B * (H // 2) * (W // 2) * cout  # at most one position per window
-        ran.append(variant)
-    assert len(ran) >= 3, ran
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 64), (1, 128, 64, 24, 96), (1, 32, 96, 128, 256)])
 def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     """pool_mode 1: the 2x2 block sums of the conv output times elu'(low-resolution activation) -- the adjoint of the exact 2x
