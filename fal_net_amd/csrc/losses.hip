@@ -4,6 +4,7 @@
 // atomic per workgroup on the scalar (grids capped at RED_BLOCKS so the single-address atomic
 // chain stays in the microsecond range; cdna guide G12).
 #include <math.h>
+#include <pthread.h>
 #include "common.h"
 
 #define RED_THREADS 256
@@ -21,27 +22,53 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 //   default       : one f32 atomic per workgroup on the scalar -- the order of the <= RED_BLOCKS adds varies from run to run;
 //   deterministic : falnet_set_deterministic(1) -- every workgroup publishes its sum (agent-scope atomic store), takes a ticket,
 //                   and the LAST arriver adds the partials in workgroup order onto the scalar: bit-identical from run to run.
-//                   One static scratch per device: reductions of one device must not run concurrently on two streams (the
-//                   training steps run all of them on the main stream).
-__device__ float g_red_partial[RED_BLOCKS];
-__device__ unsigned g_red_ticket = 0;
+//                   The scratch (partials + ticket) is per STREAM: `det` = 1 + the slot the launcher assigned to its stream (red_det_slot:
+//                   up to RED_SLOTS streams per process), so reductions on different streams -- a loss on the auxiliary stream, two models
+//                   in one process -- never share a ticket; launches of one stream are ordered by the stream.
+#define RED_SLOTS 16
+__device__ float g_red_partial[RED_SLOTS][RED_BLOCKS];
+__device__ unsigned g_red_ticket[RED_SLOTS] = {};
 __device__ __forceinline__ void red_finish(float* out, float v, int det) {
     if (threadIdx.x != 0) return;
     if (!det) {
         atomicAdd(out, v);
         return;
     }
-    __hip_atomic_store(&g_red_partial[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* const partial = g_red_partial[det - 1];
+    unsigned* const ticket = &g_red_ticket[det - 1];
+    __hip_atomic_store(&partial[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
-    const unsigned t = __hip_atomic_fetch_add(&g_red_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (t + 1 == gridDim.x) {
         __threadfence();
         float s = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) s += __hip_atomic_load(&g_red_partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned i = 0; i < gridDim.x; ++i) s += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out[0] += s;  // the only writer of this launch; earlier launches are ordered by the stream
-        __hip_atomic_store(&g_red_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// 0 outside deterministic mode, else 1 + the scratch slot of `stream` (assigned on first use; -1: more than RED_SLOTS streams)
+static int red_det_slot(void* stream) {
+    if (!falnet_deterministic()) return 0;
+    static void* owner[RED_SLOTS] = {};
+    static bool used[RED_SLOTS] = {};
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    int slot = -1;
+    for (int i = 0; i < RED_SLOTS && slot < 0; ++i)
+        if (used[i] && owner[i] == stream) slot = i;
+    for (int i = 0; i < RED_SLOTS && slot < 0; ++i)
+        if (!used[i]) {
+            used[i] = true;
+            owner[i] = stream;
+            slot = i;
+        }
+    pthread_mutex_unlock(&mu);
+    return slot < 0 ? -1 : slot + 1;
+}
+#define FALNET_DET_SLOT(var, stream)                                                                                      \
+    const int var = red_det_slot(stream);                                                                                 \
+    FALNET_CHECK_ARG(var >= 0, "deterministic reductions: more than %d streams carry scalar reductions in this process", RED_SLOTS)
 
 static inline int zero_scalar_if(float* out, int accumulate, hipStream_t s) {
     if (!accumulate) {
@@ -521,11 +548,12 @@ __global__ __launch_bounds__(1024) void rowmax_kernel(const float* __restrict__ 
 extern "C" int falnet_l1_fwd(const float* a, const float* b, const float* mask, int B, int C, int64_t HW, float scale,
                              float* out, int accumulate, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(a && b && out && B > 0 && C > 0 && HW > 0, "l1_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, mask, C, HW,
-                       total, scale, out, (const float*)nullptr, (float*)nullptr, falnet_deterministic());
+                       total, scale, out, (const float*)nullptr, (float*)nullptr, det_slot);
     FALNET_RETURN_LAUNCH();
 }
 
@@ -542,12 +570,13 @@ extern "C" int falnet_l1_bwd(const float* a, const float* b, const float* mask, 
 extern "C" int falnet_mse_fwd(const void* a, const void* b, int64_t npix, int Cpad, float scale, float* out,
                               int accumulate, int dtype, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(a && b && out && npix > 0 && Cpad > 0, "mse_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     const int64_t total = npix * Cpad;
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total);
-#define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out, (const float*)nullptr, 0.f, (T*)nullptr, falnet_deterministic())
+#define MSE_FWD(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale, out, (const float*)nullptr, 0.f, (T*)nullptr, det_slot)
 #define MSE_FWD_T(T) if (vec) MSE_FWD(T, true); else MSE_FWD(T, false)
     FALNET_DISPATCH_DTYPE(dtype, MSE_FWD_T);
 #undef MSE_FWD_T
@@ -573,12 +602,13 @@ extern "C" int falnet_mse_bwd(const void* a, const void* b, int64_t npix, int Cp
 extern "C" int falnet_smooth_fwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma,
                                  float scale, float* out, int accumulate, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(img && disp && out && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd: bad argument");
     if (int r = zero_scalar_if(out, accumulate, (hipStream_t)stream)) return r;
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
     const int64_t ftiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((x1 - x0 + SM_TX - 1) / SM_TX);
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3((unsigned)(ftiles < RED_BLOCKS ? ftiles : RED_BLOCKS)), dim3(RED_THREADS), 0,
-                       (hipStream_t)stream, s, scale, out, falnet_deterministic());
+                       (hipStream_t)stream, s, scale, out, det_slot);
     FALNET_RETURN_LAUNCH();
 }
 
@@ -720,31 +750,34 @@ extern "C" int falnet_rowmax(const float* src, float* out, int B, int64_t n, voi
 extern "C" int falnet_l1_fwd_bwd(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale,
                                  float* ga, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(a && b && out && ga && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
-                       out, gscale, ga, falnet_deterministic(), (const float*)nullptr);
+                       out, gscale, ga, det_slot, (const float*)nullptr);
     FALNET_RETURN_LAUNCH();
 }
 
 extern "C" int falnet_l1_fwd_bwd_add(const float* a, const float* b, int B, int C, int64_t HW, float scale, float* out, const float* gscale,
                                      const float* gadd, float* ga, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(a && b && out && ga && gadd && B > 0 && C > 0 && HW > 0, "l1_fwd_bwd_add: bad argument");
     const int64_t total = (int64_t)B * C * HW;
     hipLaunchKernelGGL(l1_fwd_kernel, dim3(red_grid(total)), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, (const float*)nullptr, C, HW, total, scale,
-                       out, gscale, ga, falnet_deterministic(), gadd);
+                       out, gscale, ga, det_slot, gadd);
     FALNET_RETURN_LAUNCH();
 }
 
 extern "C" int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale_out, float* out, float scale_grad,
                                   const float* gscale, void* ga, int dtype, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(a && b && out && ga && npix > 0 && Cpad > 0, "mse_fwd_bwd: bad argument");
     const int64_t total = npix * Cpad;
     const bool vec = (total & 7) == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)ga) & 31) == 0);
     const int grid = red_grid(vec ? total / 8 : total);
-#define MSE_FB(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale_out, out, gscale, scale_grad, (T*)ga, falnet_deterministic())
+#define MSE_FB(T, V) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse_fwd_kernel<T, V>), dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, (const T*)a, (const T*)b, total, scale_out, out, gscale, scale_grad, (T*)ga, det_slot)
 #define MSE_FB_T(T) if (vec) MSE_FB(T, true); else MSE_FB(T, false)
     FALNET_DISPATCH_DTYPE(dtype, MSE_FB_T);
 #undef MSE_FB_T
@@ -755,10 +788,11 @@ extern "C" int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, in
 extern "C" int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale,
                                      float* out, const float* gscale, float* gdisp, void* stream) {
     FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
     FALNET_CHECK_ARG(img && disp && out && gdisp && B > 0 && H > 0 && 0 <= x0 && x0 < x1 && x1 <= W, "smooth_fwd_bwd: bad argument");
     SmoothArgs s{img, disp, B, H, W, x0, x1, gamma};
     const int64_t btiles = (int64_t)B * ((H + SM_TY - 1) / SM_TY) * ((W + SM_TX - 1) / SM_TX);
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3((unsigned)(btiles < RED_BLOCKS ? btiles : RED_BLOCKS)), dim3(RED_THREADS), 0, (hipStream_t)stream, s,
-                       scale, gscale, gdisp, 0, out, falnet_deterministic());
+                       scale, gscale, gdisp, 0, out, det_slot);
     FALNET_RETURN_LAUNCH();
 }
