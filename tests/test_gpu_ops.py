@@ -1,5 +1,7 @@
 """GPU parity tests, op level: every libfalnet_hip.so kernel against the CPU oracle / torch-CPU fp32
 on the same seeded inputs.  Calls go through the C-ABI (fal_net_amd.ops / _lib)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -541,6 +543,41 @@ def test_conv_backward(case, dtype):
         assert rel(gb, b.grad) < tol
     call(1)  # accumulate
     assert rel(gw, 2 * w.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cin,cout,H,W,nsplit", [(2, 64, 128, 16, 64, 1), (1, 128, 96, 9, 66, 2), (3, 256, 256, 31, 70, 5), (8, 64, 128, 64, 128, 16)])
+def test_stride2_wgrad_row_streaming_kernel(B, cin, cout, H, W, nsplit, dtype):
+    """falnet_wgrad variant 8 (wgrad3x3_rows8s2_kernel: LDS-DMA row ring, input rows de-interleaved by column parity while fetched, one gout
+    fragment in a register window) against autograd of a 3x3 / stride-2 / pad-1 conv2d (FAL_netB.py:103-107), with the fused bias gradient:
+    even and odd sizes, ragged 32-pixel strips, half-empty 64-channel blocks (cout 96), items that start mid-image (nsplit does not divide
+    the rows), and the parity-plane kernel (variant 5) on the same launch as a second opinion."""
+    g = torch.Generator().manual_seed(B * 7 + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    y = F.conv2d(x.to(dtype).float(), w, b, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(dtype).float())
+    OH, OW = y.shape[2], y.shape[3]
+    pc = packed(w.detach(), b.detach(), [cin], 2, dtype)
+    x_t, g_t = to_nhwc(x, dtype), to_nhwc(gy, dtype)
+    results = {}
+    for variant in (8, 5):
+        d = L.Wgrad()
+        ops._fill_wgrad(d, dtype, [ops.nhwc_src(x_t)], H, W, g_t, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)], 2, B, OH, OW, pc)
+        d.variant, d.nsplit = variant, nsplit
+        ws = torch.empty(int(L.lib().falnet_wgrad_workspace_bytes(C.byref(d))) // 4, device=DEV)
+        gb = torch.zeros(cout, device=DEV)
+        d.partial, d.bias_grad = ws.data_ptr(), gb.data_ptr()
+        assert L.lib().falnet_wgrad_fuses_bias(C.byref(d)) == 1
+        L.check(L.lib().falnet_wgrad(C.byref(d), L.stream_ptr()), f"wgrad variant {variant}")
+        gw = torch.full(w.shape, float("nan"), device=DEV)
+        c0_real, c0_pad = pc.group_channels()
+        L.check(L.lib().falnet_wgrad_reduce(L.ptr(ws), nsplit, 9, ops.pad_c(g_t.shape[-1]), pc.cin_pad, L.ptr(gw), cout, cin, c0_real, c0_pad, 0, L.stream_ptr()))
+        results[variant] = (gw, gb)
+        assert rel(gw, w.grad) < 3e-3 and rel(gb, b.grad) < 3e-3, variant  # (operands rounded alike: f32 accumulation order is the only difference)
+    assert rel(results[8][0], results[5][0]) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
