@@ -309,8 +309,13 @@ class FalnetPlan:
     def _deep_call(self, call):
         """A small weight gradient for the third stream (see __init__); handed over in groups like the side stream's launches."""
         def run(c=call):
-            if self._deep_stream is None:
-                c()
+            if self._deep_stream is None:  # no third stream in this pass (a bucket hook is installed, or the side streams are off): side stream
+                if self._side_stream is None:
+                    c()
+                    return
+                self._side_pending.append(c)
+                if len(self._side_pending) >= self._side_batch:
+                    self._flush_side()
                 return
             self._deep_pending.append(c)
             if len(self._deep_pending) >= self._deep_batch:
@@ -804,7 +809,11 @@ class FalnetPlan:
                     self._side = torch.cuda.Stream(device=self.device)
                 self._side_stream = self._side
                 self._stream_wait(self._side_stream, main)  # the previous step's Adam / repack must not be overtaken
-                if self._deep_max_px > 0:
+                # with a gradient-bucket hook (N > 1: torch.distributed collectives fired from the side stream) the third stream is OFF: on a
+                # world-size-1 RCCL group the step measured 8.4 ms with it against 5.5 ms without (exposed communication 3.0 vs 0.0 ms with 8 or 16
+                # hardware queues, none with 4: profiles/r04_ab_dist_third_stream.txt) -- the collective's stream, the side stream it waits on
+                # and the third stream the side stream waits on serialise against the main stream's data gradients
+                if self._deep_max_px > 0 and (getattr(self.model, "bucket_hook", None) is None or L.ab("FALNET_DEEP_WITH_HOOK", "0") == "1"):
                     if self._deep is None:
                         self._deep = torch.cuda.Stream(device=self.device)
                     self._deep_stream = self._deep
