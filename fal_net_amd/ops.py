@@ -539,7 +539,7 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
         cands += [(13, 1)]
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
-        if wgs < 1024 and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":
+        if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":
             cands += [(17, 1)]  # LDS-DMA on 4x32 tiles: the 16x32 maps of level 4
             if L.ab("FALNET_TILE8", "1") == "1":
                 cands += [(20, 1)]  # ... on 8x32 tiles: the 32x64 maps of level 3
