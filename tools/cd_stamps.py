@@ -28,11 +28,16 @@ for wv in range(8):
     t = st[wv]
     n = int((t > 0).sum())
     its = n // 6
-    agg = {ph: [] for ph in range(6)}
-    for k in range(1, its - 1):
-        base = k * 6
-        for ph in range(6):
-            if base + ph + 1 < n:
-                agg[ph].append(int(t[base + ph + 1]) - int(t[base + ph]))
+    nch = ops.pad_c(cin) // 32
     tot = (int(t[(its - 1) * 6]) - int(t[6])) / max(its - 2, 1)
-    print(f"wave {wv}: {its} chunks, {tot:.0f} ticks per chunk: " + ", ".join(f"{names[ph]} {sum(v) / max(len(v), 1):.0f}" for ph, v in agg.items()))
+    print(f"wave {wv}: {its} chunks, {tot:.0f} ticks per chunk (s_memtime ticks: 100 MHz)")
+    for cpos in range(nch):  # by position of the chunk inside its tile (the last one carries the epilogue)
+        agg = {ph: [] for ph in range(6)}
+        for k in range(1, its - 1):
+            if k % nch != cpos:
+                continue
+            base = k * 6
+            for ph in range(6):
+                if base + ph + 1 < n:
+                    agg[ph].append(int(t[base + ph + 1]) - int(t[base + ph]))
+        print(f"   chunk {cpos} of {nch}: " + ", ".join(f"{names[ph]} {sum(v) / max(len(v), 1):.0f}" for ph, v in agg.items()))
