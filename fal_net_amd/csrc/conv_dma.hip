@@ -59,12 +59,14 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
     constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
     constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
     __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    stage_bias_lds(p, n0, BN, lds_bias);  // (read by the tile epilogues: at least one barrier later)
 
     // ---- K walk: chunks over (source, channel offset) ----
     const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float bias[1][16];  // (loaded per tile and slice: registers that would otherwise stay live across the MFMA loop)
-                load_bias16<1>(p, n0 + 32 * nt, h, bias);
+                load_bias16_lds(lds_bias, 32 * nt, h, bias);
                 epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff, pooloff);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -357,6 +359,8 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    stage_bias_lds(p, n0, BN, lds_bias);  // (read by the tile epilogues: at least one barrier later)
     const falnet_src_t& S = p.src[0];
     const int nchunks = S.C / KCV;
     int my_tiles = 0;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
             ctile += gridDim.x;
             const int cstride = p.out_cstride;
             float bias[1][16];
-            load_bias16<1>(p, n0, h, bias);
+            load_bias16_lds(lds_bias, 0, h, bias);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int py = c >> 1, px = c & 1;
@@ -605,6 +609,8 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    stage_bias_lds(p, n0, BN, lds_bias);  // (read by the tile epilogues: at least one barrier later)
     const falnet_src_t& S = p.src[0];
     const int nchunks = S.C / KCV;
     int my_tiles = 0;
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
             ctile += gridDim.x;
             const int cstride = p.out_cstride;
             float bias[1][16];
-            load_bias16<1>(p, n0, h, bias);
+            load_bias16_lds(lds_bias, 0, h, bias);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int py = c >> 1, px = c & 1;
@@ -1150,6 +1156,8 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
     const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    stage_bias_lds(p, n0, BN, lds_bias);  // (read by the tile epilogues: at least one barrier later)
     const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
     const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
     const int nchunks = (C0 + C1) / KCV;
@@ -1316,7 +1324,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float bias[1][16];
-                load_bias16<1>(p, n0 + 32 * nt, h, bias);
+                load_bias16_lds(lds_bias, 32 * nt, h, bias);
                 epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;

@@ -276,6 +276,22 @@ __device__ __forceinline__ void load_bias16(const falnet_conv_t& p, int nbase, i
             bias[nt][j] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
         }
 }
+// The same values from a copy of the workgroup's channel block in LDS (stage_bias_lds once per kernel, visible behind the kernel's first barrier): the
+// persistent LDS-DMA kernels fetch the bias per TILE and slice -- registers that must not stay live across the MFMA loop -- and sixteen global loads
+// per lane in front of every epilogue were 1-1.5 k cycles of exposed latency per slice; four ds_read_b128 are ~100.
+__device__ __forceinline__ void stage_bias_lds(const falnet_conv_t& p, int n0, int bn, float* lds_bias) {
+    for (int i = threadIdx.x; i < bn; i += blockDim.x) lds_bias[i] = (p.bias && n0 + i < p.Cout) ? p.bias[n0 + i] : 0.f;
+}
+__device__ __forceinline__ void load_bias16_lds(const float* lds_bias, int cb, int h, float (&bias)[1][16]) {  // cb: slice offset inside the staged block
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 v = *reinterpret_cast<const float4*>(lds_bias + cb + 8 * m + 4 * h);
+        bias[0][4 * m + 0] = v.x;
+        bias[0][4 * m + 1] = v.y;
+        bias[0][4 * m + 2] = v.z;
+        bias[0][4 * m + 3] = v.w;
+    }
+}
 __device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
