@@ -1580,10 +1580,11 @@ __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const 
                     for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ks][nt][0], a, acc[0][nt], 0, 0, 0);
                 }
             }
-            epilogue_direct<T, 1, NT>(p, acc, bias, 0, lane, [&](int) -> int64_t {  // operands exchanged above: pixels on lanes
+            auto pixoff = [&](int) -> int64_t {  // operands exchanged above: pixels on lanes
                 const int y = ty0 + wave * MT + mt, xx = tx0 + r;
                 return (y < p.OH && xx < p.OW) ? (((int64_t)b * p.OH + y) * p.OW + xx) * cstride : (int64_t)-1;
-            });
+            };
+            epilogue_direct<T, 1, NT, decltype(pixoff), NoPool, 1, false, true>(p, acc, bias, 0, lane, pixoff);  // (NHWC only: falnet_conv3x3_c3)
         }
     }
     C3_STAMP(5);

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
                     if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
                     return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
                 };
-                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[c], bias, n0, lane, pixoff);
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD, false, true>(p, acc[c], bias, n0, lane, pixoff);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
                     if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
                     return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
                 };
-                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[c], bias, n0, lane, pixoff);
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD, false, true>(p, acc[c], bias, n0, lane, pixoff);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2f_dma_kernel(const falnet_conv_
             for (int nt = 0; nt < NT; ++nt) {
                 float bias[1][16];
                 load_bias16_lds(lds_bias, 32 * nt, h, bias);
-                epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
+                epilogue_direct<T, 1, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD, false, true>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[nt][0][0][j] = 0.f;
             }

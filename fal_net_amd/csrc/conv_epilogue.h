@@ -300,7 +300,9 @@ __device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP
 // AHEAD = operand slabs in flight beyond the current one (1: conv.hip's kernels; -1: the LDS-DMA kernels, which have no registers to spare:
 // conditional loads at the point of use)
 // DEFER: nothing is stored; the finished tiles go to *defer (NHWC outputs only), epilogue_store_packed writes them later.
-template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1, bool DEFER = false>
+// NHWC_ONLY: the planar-f32 output form is compiled out (kernels whose dispatcher admits NHWC launches only): its sixteen 64-bit store addresses are
+// ~60 registers at a kernel's high-water mark even when the branch is never taken.
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1, bool DEFER = false, bool NHWC_ONLY = false>
 __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
                                                 PixOff pixoff, PoolOff pooloff = PoolOff(), PackedOut<T, MT, NT>* defer = nullptr) {
     constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
@@ -350,7 +352,7 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
             }
             if constexpr (DEFER) {
                 tile_pack<T>(v, defer->out[mt][nt]);
-            } else if (p.out_layout == FALNET_OUT_PLANAR_F32) {
+            } else if (!NHWC_ONLY && p.out_layout == FALNET_OUT_PLANAR_F32) {
                 // planar f32 [B][Cout][OH][OW] (the MED logits): o = offset of channel 0 of this lane's pixel, channel stride
                 // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
                 float* po = reinterpret_cast<float*>(p.out);
