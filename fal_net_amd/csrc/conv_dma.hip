@@ -22,6 +22,9 @@
 #include <stdlib.h>
 #include "conv_epilogue.h"
 
+#ifndef FALNET_DMA_ROW_REUSE
+#define FALNET_DMA_ROW_REUSE 1  // 16 x 32 tiles: pixel fragments read once per (row, dx, channel half) instead of once per tap (0: A/B builds)
+#endif
 #ifndef FALNET_DMA_EPI_AHEAD
 #define FALNET_DMA_EPI_AHEAD -1  // conv_epilogue.h: epilogue_direct's operand prefetch depth (-1: conditional loads at the point of use)
 #endif
@@ -231,8 +234,44 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             for (int dx = 0; dx < 3; ++dx) aa[rs][dx] = a_addr[rs][dx] + bo;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) bb[ks] = b_lane[ks] + bo;
-        // 18 steps (tap, 16-channel half): the fragment reads of step i + 1 are issued in front of the four MFMAs of step i (two
-        // register sets); sched_group_barrier pins that order -- left alone, hipcc hoists a dozen steps of reads and spills
+        // 18 steps of four MFMAs; the fragment reads of step i + 1 are issued in front of the MFMAs of step i; sched_group_barrier pins that order --
+        // left alone, hipcc hoists a dozen steps of reads and spills.
+        if constexpr (MT == 2 && FALNET_DMA_ROW_REUSE) {
+            // Two rows per wave: the pixel fragment of patch row rs, column offset dx, channel half ks serves output row mt under tap row dy = rs - mt,
+            // i.e. up to TWO taps.  Steps walk (dx, ks) groups x dy, and a group's four row fragments are read once: 24 + 36 fragment reads per chunk
+            // instead of 36 + 36 (the weight fragments have no such reuse).  Row r of a group is first needed at dy = max(0, r - 1) and its registers
+            // are free from the step after its last use, so the rows rotate through FOUR fragment registers with every read one step ahead.
+            s16x8_t fr[4], fb[2][NT];
+            auto a_read = [&](int g, int rs) { return *reinterpret_cast<const s16x8_t*>(Bf + (aa[rs][g >> 1] ^ ((g & 1) << 5))); };
+            auto b_read = [&](int st, int set) {
+                const int g = st / 3, dy = st % 3, t = dy * 3 + (g >> 1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const s16x8_t*>(Bf + bb[g & 1] + (t * BN + nt * 32) * 64);
+            };
+            fr[0] = a_read(0, 0);
+            fr[1] = a_read(0, 1);
+            b_read(0, 0);
+#pragma unroll
+            for (int st = 0; st < 18; ++st) {
+                const int g = st / 3, dy = st % 3;
+                if (st + 1 < 18) b_read(st + 1, (st + 1) & 1);
+                if (dy == 0) fr[2] = a_read(g, 2);
+                else if (dy == 1) fr[3] = a_read(g, 3);
+                else if (g + 1 < 6) {
+                    fr[0] = a_read(g + 1, 0);
+                    fr[1] = a_read(g + 1, 1);
+                }
+                if (st < KP + KW && more) issue_piece(qi, (it + 1) & 1, st);  // (wave-uniform)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][mt][0] = H16<T>::mma(fb[st & 1][nt], fr[mt + dy], acc[nt][mt][0]);
+                if (st + 1 == 18) __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
+                else if (dy == 2) __builtin_amdgcn_sched_group_barrier(0x100, NT + 2, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);  // DS reads of the next step
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);      // this step's MFMAs
+            }
+        } else {
         s16x8_t fa[2][MT], fb[2][NT];
         auto load_step = [&](int st, int set) {
             const int t = st >> 1, ks = st & 1;
@@ -252,6 +291,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
                 for (int nt = 0; nt < NT; ++nt) acc[nt][mt][0] = H16<T>::mma(fb[st & 1][nt], fa[st & 1][mt], acc[nt][mt][0]);
             __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS reads of the next step
             __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
+        }
         }
         if (more) advance(qi);
         CD_STAMP();  // 4: MFMAs issued
