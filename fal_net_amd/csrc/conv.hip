@@ -1467,7 +1467,11 @@ __global__ __launch_bounds__(512) void conv3x3_ws2_kernel(const falnet_conv_t p,
 #ifndef C3_OCC
 #define C3_OCC 2
 #endif
-#define C3_TPW 4  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, ONE patch load for the whole 8 x 128 strip
+#ifndef C3_TPW
+#define C3_TPW 8  // 8x32 tiles (consecutive along x) per workgroup: weights fetched once, ONE patch load for the whole 8 x 256 strip (round 4: 8 instead
+                  // of 4 -- the per-workgroup prologue, 7.6 us of index arithmetic and uncoalesced weight loads, is paid half as often: 64 channels
+                  // 41.1 -> 35.8 us, 32 channels 26.5 -> 25.3 us at B = 8, 256 x 512; 2 tiles: 48.2 / 30.1 us; profiles/r04_c3_strip.txt)
+#endif
 template <typename T, int NT>
 __global__ __launch_bounds__(CONV_THREADS, C3_OCC) void conv3x3_c3_kernel(const float* __restrict__ x, const float* __restrict__ w_oihw,
                                                                   const falnet_conv_t p, int groups_x, int tiles_y) {
