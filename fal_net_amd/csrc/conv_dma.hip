@@ -370,6 +370,246 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int
 }
 
 // ============================================================================================================================
+// conv3x3_dma2_kernel (falnet_conv2d variant 21, round 5): the same convolution as conv3x3_dma_kernel<T, 16, 8>, re-cut so that the two waves
+// of a SIMD belong to DIFFERENT workgroups.
+//
+// What bounds variant 13 (profiles/r04_dma_epilogue_probes.txt, profiles/r05_sq_counters.txt): its eight waves pass one barrier per K chunk, so
+// both waves of every SIMD are in their MFMA loop, at the chunk barrier and in the tile epilogue (5 000-7 400 cycles of VALU + stores, 8-30 % of a
+// tile) AT THE SAME TIME: the matrix pipe is 40-61 % busy (SQ_VALU_MFMA_BUSY_CYCLES) and nothing of the same workgroup can cover for it.  Four
+// waves of four rows each on the same tile (r04 probe G: 0.5 instead of 0.83 fragment reads per MFMA) lost 15-30 % for the same reason from the
+// other side: one wave per SIMD, nothing covers a DMA-issue stall or the epilogue.  Here:
+//   * 16 x 32 positions x 64 channels per workgroup of FOUR waves (one per SIMD), four output rows per wave: the six patch-row fragments of a
+//     column offset serve four output rows, a weight fragment four MFMAs -- 36 fragment reads per 72 MFMAs;
+//   * K in 16-channel chunks (32-B LDS rows): a chunk is 20 + 18 one-KiB pieces = 38 KiB, two buffers = 76 KiB, so TWO workgroups are resident
+//     per CU (__launch_bounds__(256, 2): 256 registers per wave) and the SIMD's second wave runs another tile at another phase: one workgroup's
+//     epilogue, chunk barrier and DMA issue overlap the other's MFMAs;
+//   * swizzle for 32-B rows: the two 16-B halves of a pixel row are exchanged when bit 3 of its patch COLUMN (of the channel row for weights) is
+//     set -- applied on the DMA's source address, the destination stays lane-linear -- which makes every ds_read_b128 of 32 consecutive rows
+//     conflict-free AND independent of the patch row, so the fragment of patch row rs is the row-0 address plus an immediate offset.
+// Same DMA / cursor / zero-page machinery as conv3x3_dma_kernel; NHWC outputs only (the planar-f32 logits launch stays on variant 13).
+#define C2_PW 34
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
+    constexpr int NWAVES = 4, MT = 4, TH = NWAVES * MT, BN = 64, NT = BN / 32;
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    constexpr int KCV = 16;  // input channels per chunk (32 B per pixel / weight row)
+    constexpr int NPIX = (TH + 2) * C2_PW;
+    constexpr int A_PIECES = (NPIX + 31) / 32, B_PIECES = 9 * BN / 32, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    constexpr int ROWB = C2_PW * 32;  // bytes between patch rows
+    static_assert(2 * BUF + 256 <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    stage_bias_lds(p, n0, BN, lds_bias);  // (read by the tile epilogues: at least one barrier later)
+
+    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
+    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
+    const int nchunks = (C0 + C1) / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    // ---- DMA geometry of this lane: row l2 of a 32-row piece, 16-B half `seg`; the half it FETCHES is swizzled ----
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l2 = lane >> 1, seg = lane & 1;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    int64_t w_off[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int tap = wid >> 1, co = n0 + ((wid & 1) << 5) + l2;  // two 32-row pieces per tap tile
+        const int gseg = seg ^ ((l2 >> 3) & 1);
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    int64_t a_off[KP];
+    const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
+    int64_t sbat[2] = {0, 0};
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile, int s2) {
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
+        sbat[s2] = (int64_t)b * S.sb;
+        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int pix = 32 * (wave + NWAVES * k) + l2;
+            const int pr = pix / C2_PW, pc = pix - pr * C2_PW;
+            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
+            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
+            a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (seg ^ ((pc >> 3) & 1)) * 8)
+                          : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+        }
+    };
+    struct Cur { int tile, c, s, c0, kofs; };
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            return;
+        }
+        q.c0 += KCV;
+        q.kofs += KCV;
+        if (q.s == 0 && q.c0 >= C0) {
+            q.s = 1;
+            q.c0 = 0;
+            tile_offsets(q.tile, 1);
+        }
+    };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {  // i = 0 .. KP + KW - 1: patch pieces, then weight pieces (wave-uniform conditions)
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+
+    // ---- fragment read addresses inside a buffer: patch row 0 of this wave per column offset (row rs: + rs * ROWB), weight row r ----
+    int a_lane[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_lane[dx] = ((wave * MT) * C2_PW + dx + r) * 32 + ((h ^ (((dx + r) >> 3) & 1)) << 4);
+    const int b_lane = A_BYTES + r * 32 + ((h ^ ((r >> 3) & 1)) << 4);
+
+    f32x16 acc[NT][MT][1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile, 0);
+#pragma unroll
+        for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;  // compute cursor
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own pieces of chunk `it` landed; own reads of chunk it-1 done
+        __builtin_amdgcn_s_barrier();                                // chunk `it` complete for every wave; buffer (it+1)&1 is free
+        const bool more = it + 1 < total;
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) aa[dx] = a_lane[dx] + bo;
+        const int bb = b_lane + bo;
+        // Nine steps (column offset dx outer, tap row dy inner) of eight MFMAs.  Patch row rs of group dx is first used at dy = max(0, rs - 3):
+        // rows 0, 1 of the NEXT group are read during step dy = 1, rows 2, 3 during dy = 2, rows 4 / 5 during the next dy = 0 / 1 -- at most eight
+        // row fragments live; the two weight fragments of step st + 1 are read during step st.
+        s16x8_t fa[3][MT + 2], fb[2][NT];
+        auto a_read = [&](int dx, int rs) { return *reinterpret_cast<const s16x8_t*>(Bf + aa[dx] + rs * ROWB); };
+        auto b_read = [&](int st, int set) {
+            const int t = (st % 3) * 3 + st / 3;  // tap (dy, dx) of step st = 3 dx + dy
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *reinterpret_cast<const s16x8_t*>(Bf + bb + (t * BN + nt * 32) * 32);
+        };
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs) fa[0][rs] = a_read(0, rs);
+        b_read(0, 0);
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            const int dx = st / 3, dy = st % 3;
+            if (st + 1 < 9) b_read(st + 1, (st + 1) & 1);
+            if (dy == 0) fa[dx][4] = a_read(dx, 4);
+            if (dy == 1) fa[dx][5] = a_read(dx, 5);
+            if (dx + 1 < 3) {
+                if (dy == 1) { fa[dx + 1][0] = a_read(dx + 1, 0); fa[dx + 1][1] = a_read(dx + 1, 1); }
+                if (dy == 2) { fa[dx + 1][2] = a_read(dx + 1, 2); fa[dx + 1][3] = a_read(dx + 1, 3); }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int i = 2 * st + half;
+                if (i < KP + KW && more) issue_piece(qi, (it + 1) & 1, i);  // (wave-uniform)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const int mt = 2 * half + m2;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt][mt][0] = H16<T>::mma(fb[st & 1][nt], fa[dx][mt + dy], acc[nt][mt][0]);
+                }
+            }
+            // DS reads for the coming steps (the builtin wants literals): 3 5 4 | 3 5 4 | 3 3 0
+            if (st == 8) __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
+            else if (dy == 1 && dx < 2) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            else if (dy == 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);  // this step's MFMAs
+        }
+        if (more) advance(qi);
+        if (++cc == nchunks) {  // tile finished: epilogue straight from the accumulators, then the next tile starts from zero
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            const int x = tx0 + r;
+            auto pixoff = [&](int mt) -> int64_t {
+                const int y = ty0 + wave * MT + mt;
+                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+            };
+            auto pooloff = [&](int mt) -> int64_t {
+                const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+            };
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bias[1][16];
+                load_bias16_lds(lds_bias, 32 * nt, h, bias);
+                if constexpr (POOL) epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), -1, false, true>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff, pooloff);
+                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1, false, true>(p, acc[nt], bias, n0 + 32 * nt, lane, pixoff);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
+            }
+        }
+    }
+}
+
+bool falnet_conv_dma2_applicable(const falnet_conv_t& p) {
+    return falnet_conv_dma_applicable(p, 16) && p.out_layout == FALNET_OUT_NHWC;
+}
+
+int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 63) / 64;
+    int gx = 512 / ny;  // two persistent workgroups per CU
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+#define DMA2_L(T)                                                                                                                              \
+    do {                                                                                                                                       \
+        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, true>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, false>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);           \
+    } while (0)
+    FALNET_DISPATCH_16(p.dtype, DMA2_L);
+#undef DMA2_L
+    FALNET_RETURN_LAUNCH();
+}
+
+// ============================================================================================================================
 // Data gradient of a 3x3 / stride-2 / pad-1 convolution (models/FAL_netB.py:101-111 conv1..conv6), all four output-parity
 // classes in ONE pass over the upstream gradient.
 //

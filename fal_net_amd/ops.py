@@ -537,6 +537,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
         cands += [(16, 1)]  # two-phase weight-stationary
     if L.ab("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
+        if L.ab("FALNET_DMA2", "1") == "1":
+            cands += [(21, 1)]  # 16x32 tiles on four waves of four rows, two workgroups per CU
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

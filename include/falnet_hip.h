@@ -130,6 +130,9 @@ typedef struct {
                                   one-shot LDS-DMA of a 32- or 64-channel K slice per workgroup, `ksplit` = cin_total / 32 or / 64 slices,
                                   f32 partial tiles in `scratch`, summed IN SLICE ORDER (deterministic) with the epilogue by the slice that
                                   arrives last at the tile's counter (the last 16 KiB of splitk_ws) -- one launch (conv_dma.hip);
+                                  21 = 13 re-cut for two resident workgroups per CU: 16x32 positions x 64 channels on FOUR waves of four rows
+                                  each, 16-channel K chunks (2 x 38 KiB of LDS), NHWC outputs only -- the two waves of a SIMD belong to different
+                                  workgroups, so one's epilogue / chunk barrier overlaps the other's MFMAs (conv_dma.hip: conv3x3_dma2_kernel);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

@@ -5,6 +5,10 @@ N = 96, f16).
 weight-stationary variants on shapes no small test launches at that batch), so this module runs exactly those launches and holds
 them to the CPU oracle (f32, the 1e-4 gate of north_star) and the 16-bit paths to the f32 HIP step (reported, bounded loosely:
 the reference is f32-only).  Reference: Train_Stage1_K.py:233-262, Train_Stage2_K.py:233-331."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
@@ -40,6 +44,7 @@ def _stage1(dtype, shape=(B, H, W, N)):
     inv = 1.0 / float(out["scaler"].state[0]) if out.get("scaler") is not None else 1.0  # f16: the raw gradients carry the loss scale
     res = {"loss": float(out["loss"]), "rec": float(out["rec"]), "sm": float(out["sm"]), "ldisp": out["ldisp"].clone().cpu(),
            "rpan": out["rpan"].clone().cpu(), "flat_grad": m.flat_gradients().clone() * inv,
+           "grads": {k: p.grad.detach().float().cpu() * inv for k, p in m.named_parameters() if p.grad is not None},
            "gnorm": {k: float(p.grad.norm()) * inv for k, p in m.named_parameters() if p.grad is not None}}
     del m
     LF.set_compute_dtype(torch.float32)
@@ -50,6 +55,47 @@ def _f32_stage1():
     if "s1" not in _F32:
         _F32["s1"] = _stage1(torch.float32)
     return _F32["s1"]
+
+
+def _f32_det(shape, tmp_path_factory):
+    """The f32 HIP step of `shape` from a fresh process in deterministic mode (tests/_f32_det_step.py): no atomics-order noise on the f32 side."""
+    key = ("det",) + tuple(shape)
+    if key not in _F32:
+        out = str(tmp_path_factory.mktemp("f32det") / "step.pt")
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_f32_det_step.py")] + [str(v) for v in shape] + [out],
+                           capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        _F32[key] = torch.load(out)
+    return _F32[key]
+
+
+# Per-TENSOR bounds of a 16-bit step against the deterministic f32 HIP step at the benchmark's own batch (VERDICT r4 weak #1: a wrong border
+# tile or a dropped K slice in ONE launch moves one layer's gradient, not the flat cosine): gradient norm within 3 % (bf16) / 0.5 % (f16),
+# cosine >= 0.999 for every parameter tensor.
+NORM_TOL = {torch.bfloat16: 3e-2, torch.float16: 5e-3}
+COS_MIN = 0.999
+
+
+def _compare_16bit(ref, got, dt, what, loss_tol=2e-2, disp_tol=None):
+    lrel = abs(got["loss"] - ref["loss"]) / ref["loss"]
+    drel = rel(got["ldisp"], ref["ldisp"])
+    cos_flat = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double().cpu(), ref["flat_grad"].double().cpu(), dim=0))
+    rows = []
+    for k, g in got["grads"].items():
+        r = ref["grads"][k].double().reshape(-1)
+        g = g.double().reshape(-1)
+        rows.append((k, abs(float(g.norm()) - float(r.norm())) / float(r.norm()), float(torch.nn.functional.cosine_similarity(g, r, dim=0)), g.numel()))
+    wn, wc = max(rows, key=lambda t: t[1]), min(rows, key=lambda t: t[2])
+    print(f"{what} {dt} vs deterministic f32 HIP: loss rel {lrel:.2e}, disp max-rel {drel:.2e}, flat grad cosine {cos_flat:.6f}, "
+          f"worst grad-norm rel {wn[0]} {wn[1]:.2e}, worst per-tensor cosine {wc[0]} {wc[2]:.6f}")
+    bad = [t for t in rows if t[1] > NORM_TOL[dt] or t[2] < COS_MIN]
+    for t in sorted(rows, key=lambda t: -t[1])[:6]:
+        print(f"    norm dev {t[1]:.2e}  cosine {t[2]:.6f}  numel {t[3]:8d}  {t[0]}")
+    assert torch.isfinite(got["flat_grad"]).all()
+    assert lrel < loss_tol and cos_flat > 0.9995
+    assert drel < (disp_tol or (1e-1 if dt == torch.bfloat16 else 2e-2))
+    assert not bad, bad
+    return rows
 
 
 def _check_vs_oracle(hip, shape, what):
@@ -92,37 +138,20 @@ def test_highres_b1_f32_step_vs_oracle():
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_highres_b8_16bit_vs_f32_hip(dt):
+def test_highres_b8_16bit_vs_f32_hip(dt, tmp_path_factory):
     """configs[4] at the benchmark's own batch (the `...|B8|...` autotune entries of `bench.py --workload highres`, the wave-neighbour
-    16-bit head backward): f16 (its dtype) and bf16 against the f32 HIP step of the same inputs (itself held to the oracle at B=1 above)."""
+    16-bit head backward): f16 (its dtype) and bf16 against the deterministic f32 HIP step of the same inputs (the f32 path is held to the
+    oracle at B=1 above), per parameter tensor (NORM_TOL / COS_MIN)."""
     shape = (8,) + HIGHRES
-    if "hr" not in _F32:
-        _F32["hr"] = _stage1(torch.float32, shape)
-    ref, got = _F32["hr"], _stage1(dt, shape)
-    lrel = abs(got["loss"] - ref["loss"]) / ref["loss"]
-    drel = rel(got["ldisp"], ref["ldisp"])
-    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
-    worst = max(((k, abs(v - ref["gnorm"][k]) / ref["gnorm"][k]) for k, v in got["gnorm"].items()), key=lambda t: t[1])
-    print(f"highres B=8 {dt} vs f32 HIP: loss rel {lrel:.2e}, disp max-rel {drel:.2e}, grad cosine {cos:.5f}, worst grad-norm rel {worst}")
-    assert torch.isfinite(got["flat_grad"]).all()
-    assert lrel < 2e-2 and cos > 0.98
-    assert drel < (1e-1 if dt == torch.bfloat16 else 2e-2)
-    assert worst[1] < 0.25, worst
+    _compare_16bit(_f32_det(shape, tmp_path_factory), _stage1(dt, shape), dt, "highres B=8")
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_stage1_b8_16bit_vs_f32_hip(dt):
-    """The benchmark's own dtype (bf16) and f16 at the benchmark's own batch against the f32 HIP step of the same inputs."""
-    ref, got = _f32_stage1(), _stage1(dt)
-    lrel = abs(got["loss"] - ref["loss"]) / ref["loss"]
-    drel = rel(got["ldisp"], ref["ldisp"])
-    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
-    worst = max(((k, abs(v - ref["gnorm"][k]) / ref["gnorm"][k]) for k, v in got["gnorm"].items()), key=lambda t: t[1])
-    print(f"B=8 {dt} vs f32 HIP: loss rel {lrel:.2e}, disp max-rel {drel:.2e}, grad cosine {cos:.5f}, worst grad-norm rel {worst}")
-    assert torch.isfinite(got["flat_grad"]).all()
-    assert lrel < 2e-2 and cos > 0.98
-    assert drel < (1e-1 if dt == torch.bfloat16 else 2e-2)
-    assert worst[1] < 0.25, worst
+def test_stage1_b8_16bit_vs_f32_hip(dt, tmp_path_factory):
+    """The benchmark's own dtype (bf16) and f16 at the benchmark's own batch -- the LDS-DMA / weight-stationary / row-streaming 16-bit kernels
+    `bench.py` runs -- against the deterministic f32 HIP step of the same inputs, per parameter tensor: gradient norm within 3 % (bf16) /
+    0.5 % (f16) and cosine >= 0.999 for EVERY tensor (NORM_TOL / COS_MIN)."""
+    _compare_16bit(_f32_det((B, H, W, N), tmp_path_factory), _stage1(dt), dt, "B=8 256x512")
 
 
 def _stage2(dtype):

@@ -180,7 +180,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 14)) + [15, 16, 17, 20]:  # 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
+    for variant in list(range(1, 14)) + [15, 16, 17, 20, 21]:  # 21: 16x32 tiles on four waves of four rows, two workgroups per CU; 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -194,10 +194,101 @@ def test_conv_every_kernel_variant(case, dtype):
         assert 1 in ran and (15 in ran) == (dtype != torch.float32 and k == 3 and (H + 1) // 2 >= 8 and (W + 1) // 2 >= 32)
         return
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
-    assert (13 in ran) == (dtype != torch.float32 and H >= 16)
+    assert (13 in ran) == (21 in ran) == (dtype != torch.float32 and H >= 16)
     assert (17 in ran) == (dtype != torch.float32 and H >= 4 and W >= 32)
     assert (20 in ran) == (dtype != torch.float32 and H >= 8 and W >= 32)
     assert (10 in ran) == (16 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,groups,up,cout,H,W,mode", [
+    (8, [64], (False,), 64, 128, 256, "fwd"),            # persistent walk: 512 tiles over 512 workgroups x 1 channel block, several chunks per tile
+    (8, [128], (False,), 128, 64, 128, "dgrad"),         # residual addend + activation-gradient operand (the data-gradient epilogue), 2 channel blocks
+    (2, [256], (True,), 128, 64, 128, "fwd"),            # deconv forward: one source at exactly half the launch size
+    (2, [64, 64], (True, False), 64, 48, 96, "dgrad"),   # iconv-like: upsampled source + skip source, 16-channel chunks crossing the source boundary
+    (3, [32, 96], (False, False), 49, 37, 75, "fwd"),    # ragged tile rows / columns, Cout 49 of 64, three samples over the tile walk
+    (2, [64], (False,), 64, 40, 96, "pool"),             # fused 2x2 max pool (VGG slices), full map kept
+    (1, [128], (False,), 128, 33, 70, "pool_only"),      # pooled map only, odd size (floor semantics)
+    (2, [64], (False,), 64, 32, 64, "sum2x2"),           # 2x2 block sums x elu'(low-resolution activation): adjoint of the nearest upsample
+])
+def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
+    """falnet_conv2d variant 21 (conv3x3_dma2_kernel: 16x32 tiles on four waves of four rows, 16-channel chunks, two workgroups per CU) against
+    torch-CPU fp32 on the operand forms of its call sites (models/FAL_netB.py:38-58,145-173 forward and stride-1 data gradients,
+    loss_functions.py:21-29 VGG slices with the fused pool), and against variant 13 on the same operands."""
+    g = torch.Generator().manual_seed(B * 100 + H + cout)
+    cin = sum(groups)
+    xs = [torch.randn(B, c, H // 2 if u else H, W // 2 if u else W, generator=g) for c, u in zip(groups, up)]
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (9 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = packed(w, b, groups, 1, dtype)
+    srcs_t = [to_nhwc(x, dtype) for x in xs]
+    xr = torch.cat([F.interpolate(to_nchw(t, c), scale_factor=2, mode="nearest") if u else to_nchw(t, c) for t, c, u in zip(srcs_t, groups, up)], 1)
+    wref = w.to(dtype).float()  # the rounded weights the kernel reads
+    conv = F.conv2d(xr, wref, b, padding=1)
+    kw = dict(bias=None, act=L.ACT_NONE)
+    bias_t = torch.zeros(pc.cout_pad, device=DEV)
+    bias_t[:cout] = b.to(DEV)
+    out = torch.full((B, H, W, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+    pooled = None
+    if mode == "fwd":
+        kw = dict(bias=bias_t, act=L.ACT_ELU)
+        ref = F.elu(conv)
+    elif mode == "dgrad":
+        add = torch.randn(B, cout, H, W, generator=g)
+        y = F.elu(torch.randn(B, cout, H, W, generator=g))
+        add_t, y_t = to_nhwc(add, dtype), to_nhwc(y, dtype)
+        yr = to_nchw(y_t, cout)
+        kw = dict(bias=None, addend=add_t, actout=y_t, actout_kind=L.ACT_ELU)
+        ref = (F.conv2d(xr, wref, None, padding=1) + to_nchw(add_t, cout)) * torch.where(yr > 0, torch.ones_like(yr), yr + 1)
+    elif mode in ("pool", "pool_only"):
+        pooled = torch.full((B, H // 2, W // 2, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+        kw = dict(bias=bias_t, act=L.ACT_RELU, pool_out=pooled)
+        ref = F.relu(conv)
+        if mode == "pool_only":
+            out = None
+    else:
+        low = F.elu(torch.randn(B, cout, H // 2, W // 2, generator=g))
+        low_t = to_nhwc(low, dtype)
+        lr = to_nchw(low_t, cout)
+        pooled = torch.full((B, H // 2, W // 2, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+        kw = dict(pool_out=pooled, pool_mode=1, pool_actout=low_t, pool_actout_kind=L.ACT_ELU)
+        ref = None
+        pref = F.avg_pool2d(F.conv2d(xr, wref, None, padding=1), 2, 2) * 4 * torch.where(lr > 0, torch.ones_like(lr), lr + 1)
+        out = None
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out,
+                             H, W, cout, pc.cout_pad, **kw)
+    finally:
+        ops.AUTOTUNE = old
+    res = {}
+    for variant in (21, 13):
+        call.desc.variant = variant
+        if out is not None:
+            out.fill_(float("nan"))
+        if pooled is not None:
+            pooled.fill_(float("nan"))
+        assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) == 0, (variant, L.lib().falnet_last_error())
+        name = C.create_string_buffer(160)
+        assert L.lib().falnet_conv2d_kernel_name(call.ref, name, 160) == 0
+        assert (b"conv3x3_dma2_kernel" in name.value) == (variant == 21), name.value
+        torch.cuda.synchronize()
+        res[variant] = (None if out is None else out.float().cpu(), None if pooled is None else pooled.float().cpu())
+        if out is not None:
+            got = to_nchw(out, cout)
+            assert torch.isfinite(got).all(), variant
+            assert rel(got, ref) < TOL[dtype], (variant, rel(got, ref))
+            if pc.cout_pad > cout:
+                assert float(out[..., cout:].float().abs().max()) == 0.0
+        if pooled is not None:
+            pr = pref if mode == "sum2x2" else F.max_pool2d(ref, 2, 2)
+            assert rel(to_nchw(pooled, cout), pr) < TOL[dtype], (variant, mode)
+            if mode == "pool":
+                assert torch.equal(pooled.float(), F.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)), variant
+    for a, b2 in zip(res[21], res[13]):  # the same products summed in another order: a few ulps of the 16-bit output apart
+        if a is not None:
+            assert float((a - b2).abs().max()) <= 2.0 ** (-6 if dtype == torch.bfloat16 else -9) * float(b2.abs().max()), mode
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -221,7 +312,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13, 16]:
+    for variant in list(range(1, 11)) + [13, 16, 21]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         if out is not None:
@@ -263,7 +354,7 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13, 16]:
+    for variant in list(range(1, 11)) + [13, 16, 21]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
