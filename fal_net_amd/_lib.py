@@ -82,7 +82,7 @@ class PackUp2Desc(C.Structure):
 
 class Cmd(C.Structure):  # falnet_cmd_t
     _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("event", C.c_int32), ("nint", C.c_int32), ("nflt", C.c_int32), ("reserved", C.c_int32),
-                ("iarg", C.c_uint64 * 18), ("farg", C.c_double * 6)]
+                ("iarg", C.c_uint64 * 18), ("farg", C.c_double * 8)]
 
 
 CMD_RECORD, CMD_WAIT = -1, -2
@@ -173,7 +173,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 401
+EXPECTED_VERSION = 500
 
 
 def lib():

@@ -53,7 +53,12 @@ struct OpThunk {  // FN: int (*)(A..., void* stream)
     }
     static constexpr int nflt() { return count_flt(std::make_index_sequence<N - 1>{}); }
     static constexpr int nint() { return (int)(N - 1) - nflt(); }
+    // a command has FALNET_CMD_MAX_INT integer / pointer slots and FALNET_CMD_MAX_FLT floating-point ones: an entry point that needs more is a
+    // compile error here, not an out-of-bounds read of the next command at run time (falnet_augment_normalize takes eight floats)
+    static_assert(nint() <= FALNET_CMD_MAX_INT && nflt() <= FALNET_CMD_MAX_FLT, "entry point does not fit a falnet_cmd_t: widen iarg / farg");
 };
+static_assert(sizeof(((falnet_cmd_t*)0)->iarg) / sizeof(uint64_t) == FALNET_CMD_MAX_INT && sizeof(((falnet_cmd_t*)0)->farg) / sizeof(double) == FALNET_CMD_MAX_FLT,
+              "falnet_cmd_t slot counts");
 
 struct Op {
     const char* name;
@@ -97,13 +102,32 @@ extern "C" int falnet_replay_op_args(int op, int* nint, int* nflt) {
 
 extern "C" int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* streams, int nstreams, void* const* events, int nevents, int* failed_at) {
     FALNET_CHECK_ARG(cmds && n >= 0 && streams && nstreams > 0, "replay: bad argument");
-    // every stream of a replay belongs to one device: select it once instead of per launch (falnet_enter_stream is skipped while depth > 0)
-    falnet_enter_stream(streams[0] ? streams[0] : (nstreams > 1 ? streams[1] : nullptr));
+    // Every stream of a replay must belong to ONE device: checked once per call (hipStreamGetDevice is a table lookup), then that device is
+    // selected once instead of per launch (falnet_enter_stream is skipped while depth > 0).  With a NULL main stream (the thread's current
+    // device decides where it runs) the per-launch selection stays on.
+    hipDevice_t dev0 = -1;
+    for (int s = 0; s < nstreams; ++s) {
+        if (!streams[s]) continue;
+        hipDevice_t d;
+        if (hipStreamGetDevice((hipStream_t)streams[s], &d) != hipSuccess) {
+            (void)hipGetLastError();
+            falnet_set_error("replay: stream %d is not a valid stream handle", s);
+            return -1;
+        }
+        if (dev0 >= 0 && d != dev0) {
+            falnet_set_error("replay: streams of devices %d and %d in one sequence", (int)dev0, (int)d);
+            return -1;
+        }
+        dev0 = d;
+    }
+    const bool pin = streams[0] != nullptr;
+    if (pin) falnet_enter_stream(streams[0]);
     struct Depth {
         int* d;
-        Depth() : d(falnet_replay_depth()) { ++*d; }
-        ~Depth() { --*d; }
-    } depth_guard;
+        bool on;
+        explicit Depth(bool o) : d(falnet_replay_depth()), on(o) { if (on) ++*d; }
+        ~Depth() { if (on) --*d; }
+    } depth_guard(pin);
     for (int i = 0; i < n; ++i) {
         const falnet_cmd_t& c = cmds[i];
         int rc = 0;
@@ -123,7 +147,7 @@ extern "C" int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* strea
                 }
             }
         } else if (c.op >= 0 && c.op < g_nops) {
-            if (c.nint != g_ops[c.op].nint || c.nflt != g_ops[c.op].nflt) {
+            if (c.nint < 0 || c.nint > FALNET_CMD_MAX_INT || c.nflt < 0 || c.nflt > FALNET_CMD_MAX_FLT || c.nint != g_ops[c.op].nint || c.nflt != g_ops[c.op].nflt) {
                 falnet_set_error("replay: command %d (%s) carries %d + %d arguments, the entry point takes %d + %d", i, g_ops[c.op].name, c.nint, c.nflt,
                                  g_ops[c.op].nint, g_ops[c.op].nflt);
                 rc = -1;

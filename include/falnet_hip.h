@@ -452,8 +452,10 @@ int falnet_augment_normalize(const uint8_t* src, int H, int W, int x1, int y1, i
 typedef struct {
     int32_t op, stream, event, nint, nflt, reserved;
     uint64_t iarg[18];
-    double farg[6];
+    double farg[8];
 } falnet_cmd_t;
+#define FALNET_CMD_MAX_INT 18
+#define FALNET_CMD_MAX_FLT 8
 int falnet_replay_op_index(const char* name);
 int falnet_replay_op_args(int op, int* nint, int* nflt);
 int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* streams, int nstreams, void* const* events, int nevents, int* failed_at);

@@ -126,6 +126,13 @@ def test_stage1_b8_f32_vs_oracle():
     _check_vs_oracle(_f32_stage1(), (B, H, W, N), "B=8 256x512 N=49")
 
 
+def test_stage1_default_training_crop_f32_vs_oracle():
+    """The reference's DEFAULT training crop, 192 x 640 (Train_Stage1_K.py:48-49 --crop_height 192 --crop_width 640; the benchmark's 256 x 512 is
+    BASELINE's shape, not the script's): one f32 Stage-1 step at B=2 against the CPU oracle, same bounds as the configs[1] test."""
+    shape = (2, 192, 640, N)
+    _check_vs_oracle(_stage1(torch.float32, shape), shape, "B=2 192x640 N=49")
+
+
 HIGHRES = (384, 1280, 96)  # BASELINE configs[4]
 
 

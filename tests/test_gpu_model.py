@@ -57,9 +57,11 @@ def test_odd_size_forward(golden_dir):
     assert rel(disp, g["disp"]) < F32_TOL
 
 
-def test_backward_vs_oracle():
-    """Gradients of an arbitrary scalar of (p_im0, disp) wrt every parameter, f32 path."""
-    n_levels, B, H, W = 7, 2, 64, 128
+@pytest.mark.parametrize("n_levels,B,H,W", [(7, 2, 64, 128), (7, 1, 75, 250)])
+def test_backward_vs_oracle(n_levels, B, H, W):
+    """Gradients of an arbitrary scalar of (p_im0, disp) wrt every parameter, f32 path.  75 x 250 (golden G7's odd size, forward-only there): every
+    decoder level upsamples by a non-x2 ratio (2x4 -> 3x8 -> 5x16 -> 10x32 -> 19x63 -> 38x125 -> 75x250), so the full-model backward runs the
+    general nearest-upsample adjoint (FAL_netB.py:57 F.interpolate(size=...)) and the odd-size stride-2 data / weight gradients."""
     left, right, mn, mx = synthetic.synthetic_pair(B, H, W, seed=77, distinct=True)
     gen = torch.Generator().manual_seed(78)
     gp, gd = torch.randn(B, 3, H, W, generator=gen), torch.randn(B, 1, H, W, generator=gen) * 0.01
