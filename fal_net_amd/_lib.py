@@ -166,6 +166,7 @@ SIGNATURES = {
     "falnet_replay": [_P, _I, _P, _I, _P, _I, C.POINTER(C.c_int)],
     "falnet_fill_f32": [_P, _L, _F, _P],
     "falnet_copy_bytes": [_P, _P, _L, _P],
+    "falnet_spin": [_I, _P],
 }
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
 
@@ -245,13 +246,36 @@ class Segment:
             raise RuntimeError(f"libfalnet_hip replay failed at command {self.failed.value} (rc={rc}): {msg}")
 
 
+class SegmentChain:
+    """Recorded launch sequences with Python calls between them (Recorder.cut): run() issues segment, call, segment, ... in order.  The parts share
+    ONE stream / event table, so a wait in a later segment may name an event recorded in an earlier one."""
+
+    def __init__(self, parts):
+        self.parts = parts  # Segment | zero-argument callable
+
+    def run(self, main_ptr):
+        for p in self.parts:
+            if isinstance(p, Segment):
+                p.run(main_ptr)
+            else:
+                p()
+
+
 class Recorder:
     """`with Recorder(main_stream_ptr) as r: <launches>` -> r.finalize() is the Segment of everything the block would have launched."""
 
     def __init__(self, main_ptr):
         self.streams = [int(main_ptr or 0)]
         self.events, self.cmds, self.keep = [], [], []
+        self.parts = []
         self._ops = {}
+
+    def cut(self, fn):
+        """Something that cannot be replayed from C happens HERE in the sequence (a torch.distributed collective issued from Python): the commands
+        recorded so far become one segment, `fn` is called between it and the next one on every replay."""
+        self.parts.append(self.cmds)
+        self.parts.append(fn)
+        self.cmds = []
 
     def __enter__(self):
         assert getattr(_TLS, "rec", None) is None, "recorders do not nest"
@@ -309,7 +333,10 @@ class Recorder:
         self.cmds.append(c)
 
     def finalize(self):
-        return Segment(self.cmds, self.streams, self.events, self.keep)
+        if not self.parts:
+            return Segment(self.cmds, self.streams, self.events, self.keep)
+        parts = [p if callable(p) else Segment(p, self.streams, self.events, self.keep) for p in self.parts + [self.cmds] if callable(p) or p]
+        return SegmentChain(parts)
 
 
 class _LibProxy:
@@ -335,6 +362,11 @@ class _LibProxy:
 
 def recording():
     return getattr(_TLS, "rec", None) is not None
+
+
+def cut(fn):
+    """Inside a Recorder block: call `fn` at this point of every replay (Recorder.cut)."""
+    _TLS.rec.cut(fn)
 
 
 def ev_record(ev, stream):

@@ -528,3 +528,15 @@ extern "C" int falnet_disp_prologue(const float* max_disp, const float* min_disp
 #undef EW_L
     FALNET_RETURN_LAUNCH();
 }
+
+// ---- stream self-test probe (include/falnet_hip.h: falnet_spin) -----------------------------------------------------------------------
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int falnet_spin(int microseconds, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "spin: 0..100000 us");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+    FALNET_RETURN_LAUNCH();
+}

@@ -80,7 +80,7 @@ const Op g_ops[] = {
     FALNET_OP(falnet_adam_step_guarded), FALNET_OP(falnet_loss_scale_update), FALNET_OP(falnet_loss_seeds), FALNET_OP(falnet_occlusion_mask),
     FALNET_OP(falnet_mirror_weight), FALNET_OP(falnet_hflip), FALNET_OP(falnet_rowmax), FALNET_OP(falnet_gemm_f32_small),
     FALNET_OP(falnet_resize_planar), FALNET_OP(falnet_disp_prologue), FALNET_OP(falnet_resample_u8), FALNET_OP(falnet_augment_normalize),
-    FALNET_OP(falnet_fill_f32), FALNET_OP(falnet_copy_bytes),
+    FALNET_OP(falnet_fill_f32), FALNET_OP(falnet_copy_bytes), FALNET_OP(falnet_spin),
 };
 constexpr int g_nops = (int)(sizeof(g_ops) / sizeof(g_ops[0]));
 

@@ -264,7 +264,20 @@ class FAL_net(nn.Module):
         # would be reduced once per micro-batch; train.allreduce_gradients then falls back to ONE sum over the whole buffer
         if hook is not None and not getattr(self, "_accumulating", False):
             lo, hi = self.gradient_buckets()[bucket]
-            hook(bucket, self._flat_grad[lo:hi])
+            view = self._flat_grad[lo:hi]
+            if L.recording():
+                # a recorded backward (plan.run_backward) is CUT here: the collective is issued from Python between two replayed segments, on the
+                # stream that was current when the sequence was recorded (the weight-gradient side stream)
+                stream = torch.cuda.current_stream()
+
+                def fire(bucket=bucket, view=view, stream=stream):
+                    h = getattr(self, "bucket_hook", None)
+                    if h is not None:
+                        with torch.cuda.stream(stream):
+                            h(bucket, view)
+                L.cut(fire)
+            else:
+                hook(bucket, view)
 
     def flat_parameters(self):
         return self._flat

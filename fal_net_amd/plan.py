@@ -24,6 +24,55 @@ _TAIL_MAIN = ""  # default of FALNET_TAIL_MAIN: extra weight gradients for the m
 _TAIL_LEVELS = int(L.ab("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
+_AUX_STREAMS = {}
+
+
+def aux_stream(device):
+    """The auxiliary stream of a device (the label image's VGG pass beside the network forward, train.vgg_label_async): one per device, kept
+    here so that the stream self-test of a plan sees every stream the step keeps busy."""
+    key = (device.type, device.index)
+    if key not in _AUX_STREAMS:
+        _AUX_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _AUX_STREAMS[key]
+
+
+def _spin_pair_ms(a, b, us=200):
+    """Wall time (ms) of two `us`-microsecond spin kernels issued to streams a and b behind a common gate: ~us when they overlap, ~2 us when HIP
+    has mapped both streams onto one hardware queue."""
+    lib = L.lib()
+    gate, e0 = torch.cuda.Event(), torch.cuda.Event(enable_timing=True)
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.check(lib.falnet_spin(50, a.cuda_stream), "spin")  # (both spins are queued by the time the gate opens)
+    gate.record(a)
+    b.wait_event(gate)
+    e0.record(a)
+    L.check(lib.falnet_spin(us, a.cuda_stream), "spin")
+    ea.record(a)
+    L.check(lib.falnet_spin(us, b.cuda_stream), "spin")
+    eb.record(b)
+    ea.synchronize()
+    eb.synchronize()
+    return max(e0.elapsed_time(ea), e0.elapsed_time(eb))
+
+
+def _spin_vs_call_ms(x, probe, fn, us=300):
+    """ms from the start of a `us` spin on stream x to the completion of fn() (a collective issued from stream `probe`, which is known not to
+    collide with x): ~the call's own time when its internal stream runs beside x, > us when it is queued behind the spin."""
+    lib = L.lib()
+    gate, e0, e1 = torch.cuda.Event(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.check(lib.falnet_spin(50, x.cuda_stream), "spin")
+    gate.record(x)
+    probe.wait_event(gate)
+    e0.record(x)
+    L.check(lib.falnet_spin(us, x.cuda_stream), "spin")
+    with torch.cuda.stream(probe):
+        fn()
+        e1.record(probe)
+    e1.synchronize()
+    x.synchronize()
+    return e0.elapsed_time(e1)
+
+
 class _WgradPart:
     """One input-channel group of a two-source convolution presented to ops.WgradBatch as a layer of its own: `cin` stays the row stride
     of the full OIHW gradient, the group's channels are the packed columns [0, c_pad) -> real columns [0, c_real) of the gradient VIEW
@@ -65,6 +114,9 @@ class FalnetPlan:
         self._sync_events, self._sync_ev_next = [], 0
         self._bwd_segments, self._bwd_eager_runs = {}, {}
         self._fwd_segments, self._fwd_eager_runs = {}, {}
+        self.selftest = None          # result of stream_selftest (bench.py prints it): None = not run yet
+        self._selftest_hooked = None  # whether the last self-test included the collective's stream
+        self._deep_with_hook = L.ab("FALNET_DEEP_WITH_HOOK", "1") == "1"  # third stream beside a bucket hook -- when the self-test found it a queue of its own
         self._main_stream = None
         self._deep_batch = max(1, int(L.ab("FALNET_DEEP_BATCH", "3")))
         self._deep_alt = L.ab("FALNET_DEEP_ALT", "0") == "1"  # experiment: every second larger weight gradient on the third stream as well
@@ -695,15 +747,29 @@ class FalnetPlan:
         # (which upstream gradients exist, accumulating or not); after two eager passes it is recorded once and every later backward is ONE
         # falnet_replay call -- the same launches on the same three streams.  Not with a gradient-bucket hook installed (torch.distributed
         # collectives are issued from Python between the buckets) and not inside bench.py's instrumented pass.
-        key = (g_disp is not None, g_pan is not None, bool(self._accumulate))
-        can = use_side and ops.replay_ok() and getattr(self.model, "bucket_hook", None) is None
+        hooked = getattr(self.model, "bucket_hook", None) is not None and not self._accumulate
+        if use_side and self._selftest_hooked != hooked and L.ab("FALNET_STREAM_SELFTEST", "1") == "1":
+            self.stream_selftest(main, hooked)  # (may re-create the side / third stream: recorded sequences are dropped)
+        key = (g_disp is not None, g_pan is not None, bool(self._accumulate), hooked)
+        can = use_side and ops.replay_ok() and (not hooked or L.ab("FALNET_REPLAY_HOOKED", "1") == "1")
         seg = self._bwd_segments.get(key) if can else None
         if seg is None and can and self._bwd_eager_runs.get(key, 0) >= 2:
-            with L.Recorder(main.cuda_stream) as rec:
-                self._backward_body(main, use_side, key)
+            try:
+                with L.Recorder(main.cuda_stream) as rec:
+                    self._backward_body(main, use_side, key)
+            except BaseException:
+                self._reset_handover_state()  # a recording that raised mid-body must not leave half-advanced hand-over lists for the next eager pass
+                raise
             seg = self._bwd_segments[key] = rec.finalize()
         if seg is not None:
-            seg.run(main.cuda_stream)
+            try:
+                seg.run(main.cuda_stream)
+            except BaseException:
+                # a failed replay leaves the side / third streams without their join waits: drain the device, drop the sequence, re-raise
+                torch.cuda.synchronize(self.device)
+                self._bwd_segments.pop(key, None)
+                self._reset_handover_state()
+                raise
         else:
             self._backward_body(main, use_side, key)
             if can:
@@ -734,7 +800,7 @@ class FalnetPlan:
                 # world-size-1 RCCL group the step measured 8.4 ms with it against 5.5 ms without (exposed communication 3.0 vs 0.0 ms with 8 or 16
                 # hardware queues, none with 4: profiles/r04_ab_dist_third_stream.txt) -- the collective's stream, the side stream it waits on
                 # and the third stream the side stream waits on serialise against the main stream's data gradients
-                if self._deep_max_px > 0 and (getattr(self.model, "bucket_hook", None) is None or L.ab("FALNET_DEEP_WITH_HOOK", "0") == "1"):
+                if self._deep_max_px > 0 and (not key[3] or self._deep_with_hook):
                     if self._deep is None:
                         self._deep = torch.cuda.Stream(device=self.device)
                     self._deep_stream = self._deep
@@ -750,6 +816,90 @@ class FalnetPlan:
             self._join_deep(main)
             if self._side_stream is not None:
                 self._stream_wait(main, self._side_stream)
+
+    def _reset_handover_state(self):
+        self._side_pending.clear()
+        self._deep_pending.clear()
+        self._side_ev_next = self._deep_ev_next = self._sync_ev_next = 0
+        self._deep_dirty = False
+
+    def invalidate_segments(self):
+        """Drop every recorded launch sequence of this plan (they hold raw stream / event handles and by-value state): call it when a stream is
+        re-created, a descriptor's buffers change, or a bucket hook is installed / removed."""
+        self._bwd_segments.clear()
+        self._fwd_segments.clear()
+        self._bwd_eager_runs.clear()
+        self._fwd_eager_runs.clear()
+        self._reset_handover_state()
+
+    def stream_selftest(self, main, hooked, tries=12):
+        """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order; two BUSY streams of the step on one queue serialise it
+        (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt) and nothing in the API says which queue a stream got.  So measure it: on every
+        pair of (main, side, third, auxiliary) two 200-us spin kernels must take ~200 us, not ~400; an offending side / third / auxiliary stream
+        is replaced by a fresh one from torch's pool until the pair overlaps.  With a bucket hook (`hooked`) the collective's own stream is in
+        the picture too: an all-reduce issued beside a spin on each of the plan's streams must not wait for the spin.  In-process, no re-exec;
+        ~10 ms once per plan and hook state.  The result goes to `self.selftest` (bench.py's allreduce_report prints it)."""
+        dev = self.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        if self._deep is None and self._deep_max_px > 0:
+            self._deep = torch.cuda.Stream(device=dev)
+        roles = [("main", lambda: main, None), ("side", lambda: self._side, lambda s: setattr(self, "_side", s))]
+        if self._deep is not None:
+            roles.append(("third", lambda: self._deep, lambda s: setattr(self, "_deep", s)))
+        roles.append(("aux", lambda: aux_stream(dev), lambda s: _AUX_STREAMS.__setitem__((dev.type, dev.index), s)))
+        coll = None
+        if hooked and torch.distributed.is_available() and torch.distributed.is_initialized():
+            buf = torch.zeros(1 << 18, device=dev)
+
+            def coll():
+                torch.distributed.all_reduce(buf, async_op=True).wait()
+        log, accepted, replaced = [], [], 0
+        torch.cuda.synchronize(dev)
+        for name, get, put in roles:
+            n, worst = 0, 0.0
+            while True:
+                s = get()
+                worst = max([_spin_pair_ms(o, s) for _, o in accepted] + [0.0])
+                if worst < 0.3 or put is None or n >= tries:
+                    break
+                put(torch.cuda.Stream(device=dev))
+                n += 1
+                replaced += 1
+            log.append({"stream": name, "handle": hex(get().cuda_stream), "replaced": n, "worst_pair_ms": round(worst, 3)})
+            accepted.append((name, get()))
+        collective = None
+        if coll is not None:
+            # Every rank issues the SAME number of collectives whatever it measures (three rounds of one probe per stream): a rank that
+            # re-tried on its own would leave the others waiting in a collective it never joins.
+            coll()  # (first call: communicator / stream set-up outside the measurement)
+            torch.cuda.synchronize(dev)
+            for _ in range(3):
+                collective = {}
+                for i, (name, s) in enumerate(accepted):
+                    collective[name] = round(_spin_vs_call_ms(s, accepted[(i + 1) % len(accepted)][1], coll), 3)
+                for i, (name, s) in enumerate(accepted):
+                    if collective[name] <= 0.25 or name == "main":
+                        continue
+                    put = [r[2] for r in roles if r[0] == name][0]  # the collective's stream shares this stream's queue: move OUR stream
+                    for _t in range(tries):
+                        put(torch.cuda.Stream(device=dev))
+                        replaced += 1
+                        s = [r[1] for r in roles if r[0] == name][0]()
+                        if max(_spin_pair_ms(o, s) for nm, o in accepted if nm != name) < 0.3:
+                            break
+                    accepted[i] = (name, s)
+            for e in log:
+                e["handle"] = hex(dict(accepted)[e["stream"]].cuda_stream)
+            self._deep_with_hook = self._deep_with_hook and collective.get("third", 0.0) <= 0.25 and collective.get("main", 0.0) <= 0.25
+        torch.cuda.synchronize(dev)
+        self.selftest = {"pairs_overlap": all(e["worst_pair_ms"] < 0.3 for e in log), "streams": log, "collective_beside_spin_ms": collective,
+                         "streams_replaced": replaced, "third_stream_with_hook": bool(self._deep_with_hook) if hooked else None,
+                         "hw_queues": __import__("os").environ.get("GPU_MAX_HW_QUEUES")}
+        self._selftest_hooked = hooked
+        if replaced:
+            self.invalidate_segments()
+        return self.selftest
 
     def _stream_wait(self, waiter, waited):
         """waiter.wait_stream(waited) as an explicit event pair (recordable)."""

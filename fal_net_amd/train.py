@@ -217,14 +217,9 @@ def allreduce_gradients(model):
     return 1.0 / dist.get_world_size()
 
 
-_AUX_STREAMS = {}
-
-
 def _aux_stream(device):
-    key = (device.type, device.index)
-    if key not in _AUX_STREAMS:
-        _AUX_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _AUX_STREAMS[key]
+    from .plan import aux_stream  # (one per device, kept beside the plans' streams: plan.stream_selftest checks it too)
+    return aux_stream(device)
 
 
 def vgg_label_async(label, borrow=True):

@@ -462,6 +462,10 @@ int falnet_replay(const falnet_cmd_t* cmds, int n, void* const* streams, int nst
 /* p[0..n) = value (hipMemsetAsync / hipMemsetD32Async) and a device-to-device copy: the two aten launches of a static step, replayable */
 int falnet_fill_f32(float* p, int64_t n, float value, void* stream);
 int falnet_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
+/* One wave that does nothing for `microseconds` (s_memrealtime, the 100 MHz constant clock) on `stream`: the probe of the plan's stream self-test
+ * (fal_net_amd/plan.py: stream_selftest) -- two of them on two streams take ONE period when the streams sit on different hardware queues and TWO
+ * when HIP has mapped both onto the same queue.  Not part of any step. */
+int falnet_spin(int microseconds, void* stream);
 
 #ifdef __cplusplus
 }
