@@ -389,7 +389,7 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int
 // Same DMA / cursor / zero-page machinery as conv3x3_dma_kernel; NHWC outputs only (the planar-f32 logits launch stays on variant 13).
 #define C2_PW 34
 template <typename T, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
+__global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles, int skew) {
     constexpr int NWAVES = 4, MT = 4, TH = NWAVES * MT, BN = 64, NT = BN / 32;
     static_assert(sizeof(T) == 2, "16-bit operands");
     constexpr int KCV = 16;  // input channels per chunk (32 B per pixel / weight row)
@@ -414,6 +414,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_
     int my_tiles = 0;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
     const int total = my_tiles * nchunks;
+    // Phase skew: every workgroup walks tiles of the same length from the same start, so the two residents of a CU would reach their epilogues
+    // together -- exactly what the two-workgroup cut is there to avoid.  The second half of the grid (dispatched as the CUs' SECOND residents)
+    // starts `skew` x 64 cycles late (about half a tile); its partner has the SIMDs to itself meanwhile, so the wait is not idle matrix time.
+    if (skew > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) >= (int)(gridDim.x * gridDim.y + 1) / 2) {
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)skew * 64) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- DMA geometry of this lane: row l2 of a 32-row piece, 16-B half `seg`; the half it FETCHES is swizzled ----
     constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
@@ -599,10 +606,16 @@ int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-#define DMA2_L(T)                                                                                                                              \
-    do {                                                                                                                                       \
-        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, true>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, false>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles);           \
+    // start skew of the CUs' second residents: FALNET_DMA2_SKEW percent (experiment builds; default 50) of a tile's time, taken as 5 200 cycles
+    // per 16-channel chunk (two waves per SIMD at ~65 % of the matrix pipe's rate); none when the grid has a single resident per CU
+    static const int skew_pct = [] { const char* e = falnet_ab_env("FALNET_DMA2_SKEW"); return e ? atoi(e) : 50; }();
+    int cin = 0;
+    for (int s = 0; s < p.nsrc; ++s) cin += p.src[s].C;
+    const int skew = gx * ny > 256 ? (int)((int64_t)skew_pct * (cin / 16) * 5200 / 100 / 64) : 0;
+#define DMA2_L(T)                                                                                                                                    \
+    do {                                                                                                                                             \
+        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, true>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles, skew);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, false>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles, skew);           \
     } while (0)
     FALNET_DISPATCH_16(p.dtype, DMA2_L);
 #undef DMA2_L

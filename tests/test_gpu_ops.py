@@ -259,7 +259,7 @@ def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
     ops.AUTOTUNE = False
     try:
         call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out,
-                             H, W, cout, pc.cout_pad, **kw)
+                             H, W, pc.cout_pad, pc.cout_pad, **kw)  # (Cout = the padded count, as the plans pass it: padded channels are written as zeros)
     finally:
         ops.AUTOTUNE = old
     res = {}
