@@ -388,16 +388,20 @@ int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int
 //     conflict-free AND independent of the patch row, so the fragment of patch row rs is the row-0 address plus an immediate offset.
 // Same DMA / cursor / zero-page machinery as conv3x3_dma_kernel; NHWC outputs only (the planar-f32 logits launch stays on variant 13).
 #define C2_PW 34
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles, int skew) {
-    constexpr int NWAVES = 4, MT = 4, TH = NWAVES * MT, BN = 64, NT = BN / 32;
+// NWAVES = 8 (variant 22): the same wave program on 32 x 32-position tiles, ONE workgroup of eight waves per CU (2 x 55 KiB of LDS) -- the tile
+// VERDICT r4 next #1 prescribes: 55 instead of 75 KiB staged per 576 MFMAs (the 34 x 34 patch serves 32 rows) AND 0.5 instead of 0.83 fragment
+// reads per MFMA.  Both cuts of the 16 x 32 tile are paced at ~10 B/clk of LDS-DMA per CU (variant 13: 75 KiB per ~7 500-cycle chunk; variant
+// 21 the same bytes per MFMA); fewer reads alone (variant 21) or fewer bytes alone (r03's 128-channel tile) each left the other bound standing.
+template <typename T, bool POOL, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_dma2_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles, int skew) {
+    constexpr int MT = 4, TH = NWAVES * MT, BN = 64, NT = BN / 32;
     static_assert(sizeof(T) == 2, "16-bit operands");
     constexpr int KCV = 16;  // input channels per chunk (32 B per pixel / weight row)
     constexpr int NPIX = (TH + 2) * C2_PW;
     constexpr int A_PIECES = (NPIX + 31) / 32, B_PIECES = 9 * BN / 32, NPIECES = A_PIECES + B_PIECES;
     constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
     constexpr int ROWB = C2_PW * 32;  // bytes between patch rows
-    static_assert(2 * BUF + 256 <= 80 * 1024, "two workgroups per CU");
+    static_assert(2 * BUF + 256 <= (NWAVES == 4 ? 80 : 160) * 1024, "two workgroups (four waves) / one workgroup (eight waves) per CU");
     __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
     __shared__ __attribute__((aligned(16))) float lds_bias[BN];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -414,9 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_
     int my_tiles = 0;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
     const int total = my_tiles * nchunks;
-    // Phase skew: every workgroup walks tiles of the same length from the same start, so the two residents of a CU would reach their epilogues
-    // together -- exactly what the two-workgroup cut is there to avoid.  The second half of the grid (dispatched as the CUs' SECOND residents)
-    // starts `skew` x 64 cycles late (about half a tile); its partner has the SIMDs to itself meanwhile, so the wait is not idle matrix time.
+    // Phase skew (experiment switch, 0 in the product): the second half of the grid (dispatched as the CUs' SECOND residents) starts
+    // `skew` x 64 cycles late, so that the two residents of a CU do not reach their epilogues together.
     if (skew > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) >= (int)(gridDim.x * gridDim.y + 1) / 2) {
         const long long t0 = (long long)__builtin_amdgcn_s_memtime();
         while ((long long)__builtin_amdgcn_s_memtime() - t0 < (long long)skew * 64) __builtin_amdgcn_s_sleep(32);
@@ -594,31 +597,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma2_kernel(const falnet_conv_
     }
 }
 
-bool falnet_conv_dma2_applicable(const falnet_conv_t& p) {
-    return falnet_conv_dma_applicable(p, 16) && p.out_layout == FALNET_OUT_NHWC;
+bool falnet_conv_dma2_applicable(const falnet_conv_t& p, int th) {
+    return falnet_conv_dma_applicable(p, th) && p.out_layout == FALNET_OUT_NHWC;
 }
 
-int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
-    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + th - 1) / th;
     const int ntiles = p.B * tiles_x * tiles_y;
     const int ny = (p.Cout + 63) / 64;
-    int gx = 512 / ny;  // two persistent workgroups per CU
+    int gx = (th == 32 ? 256 : 512) / ny;  // one persistent eight-wave workgroup per CU, or two four-wave ones
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-    // start skew of the CUs' second residents: FALNET_DMA2_SKEW percent (experiment builds; default 50) of a tile's time, taken as 5 200 cycles
-    // per 16-channel chunk (two waves per SIMD at ~65 % of the matrix pipe's rate); none when the grid has a single resident per CU
-    static const int skew_pct = [] { const char* e = falnet_ab_env("FALNET_DMA2_SKEW"); return e ? atoi(e) : 50; }();
+    // start skew of the CUs' second residents: FALNET_DMA2_SKEW percent (experiment builds only; default 0) of a tile's time, taken as 5 200
+    // cycles per 16-channel chunk; none when the grid has a single resident per CU.  Measured (profiles/r05_dma2_probes.txt): 25 % +-0, 50 % and
+    // 100 % cost what they delay -- a workgroup alone on its CU does not run faster than beside its partner, so the two are not fighting over
+    // the matrix pipe and de-phasing them buys nothing.
+    static const int skew_pct = [] { const char* e = falnet_ab_env("FALNET_DMA2_SKEW"); return e ? atoi(e) : 0; }();
     int cin = 0;
     for (int s = 0; s < p.nsrc; ++s) cin += p.src[s].C;
-    const int skew = gx * ny > 256 ? (int)((int64_t)skew_pct * (cin / 16) * 5200 / 100 / 64) : 0;
-#define DMA2_L(T)                                                                                                                                    \
-    do {                                                                                                                                             \
-        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, true>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles, skew);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, false>), grid, dim3(256), 0, st, p, tiles_x, tiles_y, flip, ntiles, skew);           \
+    const int skew = (th == 16 && gx * ny > 256) ? (int)((int64_t)skew_pct * (cin / 16) * 5200 / 100 / 64) : 0;
+#define DMA2_K(T, PL, NW) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma2_kernel<T, PL, NW>), grid, dim3(NW * 64), 0, st, p, tiles_x, tiles_y, flip, ntiles, skew)
+#define DMA2_L(T)                                              \
+    do {                                                       \
+        if (th == 32) {                                        \
+            if (p.pool_out) DMA2_K(T, true, 8);                \
+            else DMA2_K(T, false, 8);                          \
+        } else {                                               \
+            if (p.pool_out) DMA2_K(T, true, 4);                \
+            else DMA2_K(T, false, 4);                          \
+        }                                                      \
     } while (0)
     FALNET_DISPATCH_16(p.dtype, DMA2_L);
 #undef DMA2_L
+#undef DMA2_K
     FALNET_RETURN_LAUNCH();
 }
 

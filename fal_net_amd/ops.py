@@ -538,7 +538,7 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     if L.ab("FALNET_NO_DMA", "0") != "1":
         cands += [(13, 1)]
         if L.ab("FALNET_DMA2", "1") == "1":
-            cands += [(21, 1)]  # 16x32 tiles on four waves of four rows, two workgroups per CU
+            cands += [(21, 1), (22, 1)]  # four rows per wave, 16-channel chunks: 16x32 tiles on two four-wave workgroups per CU / 32x32 tiles on eight waves
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

@@ -133,6 +133,8 @@ typedef struct {
                                   21 = 13 re-cut for two resident workgroups per CU: 16x32 positions x 64 channels on FOUR waves of four rows
                                   each, 16-channel K chunks (2 x 38 KiB of LDS), NHWC outputs only -- the two waves of a SIMD belong to different
                                   workgroups, so one's epilogue / chunk barrier overlaps the other's MFMAs (conv_dma.hip: conv3x3_dma2_kernel);
+                                  22 = the wave program of 21 on 32x32-position tiles, eight waves, one workgroup per CU (2 x 55 KiB of LDS): 27 % fewer
+                                  staged bytes and 40 % fewer fragment reads per MFMA than 13;
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,
