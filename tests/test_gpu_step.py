@@ -519,6 +519,28 @@ def test_overlapped_allreduce_equals_single_allreduce_world1():
         assert x["w_maxabs"] <= 2.1e-4, (name, x)  # one Adam step of lr = 1e-4: at most a flipped +-lr on sign-unstable elements
 
 
+def test_hooked_backward_replay_world1():
+    """the N > 1 step must be the benchmarked step.  With gradient-bucket hooks installed (world-size-1 RCCL group) the
+    backward is a RECORDED sequence cut at the hooks -- segment, Python collective, segment, ... (`_lib.SegmentChain`) -- and must be bit-identical to
+    the same steps issued launch by launch (deterministic mode, six steps), fire every in-backward hook exactly once per step in bucket order, and
+    have run the stream / hardware-queue self-test with the collective's stream in the picture (tests/_dist_world1_replay.py)."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_dist_world1_replay.py")], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rep, eag = res["replayed"], res["eager"]
+    assert res["identical"], (rep["steps"], eag["steps"])
+    assert rep["segments"] == ["SegmentChain"] and rep["cuts"] == [3], rep  # buckets 0, 1, 2 inside backward; the last one fires behind the join
+    assert eag["segments"] == []
+    for x in (rep, eag):
+        assert x["fired"] == [0, 1, 2, 3] * 5, x["fired"]
+        assert x["hooked_selftest"] is True and x["selftest"]["pairs_overlap"], x["selftest"]
+        assert x["selftest"]["collective_beside_spin_ms"] is not None
+    print("stream self-test:", rep["selftest"])
+
+
 def test_deterministic_mode_is_bit_identical():
     """FALNET_DETERMINISTIC=1: two fresh model instances, two optimiser steps each (Stage-1 in f32 and bf16, Stage-2 in f32) from the
     same weights and inputs give bit-identical losses, gradients, weights and disparities -- ordered scalar reductions, no
