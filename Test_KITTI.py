@@ -17,7 +17,7 @@ import json
 import os
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # application-level choice, before HIP initialises (fal_net_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")  # application-level choice, before HIP initialises (fal_net_amd/__init__.py)
 
 def _flag(v):
     """The reference declares its switches as untyped options with a default (`-fpp True`, `-eval False`, Test_KITTI.py:41-60), so the

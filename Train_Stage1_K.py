@@ -19,7 +19,7 @@ import json
 import os
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # application-level choice, before HIP initialises (fal_net_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")  # application-level choice, before HIP initialises (fal_net_amd/__init__.py)
 
 parser = argparse.ArgumentParser(description='FAL_net Stage 1 on MI355X', formatter_class=argparse.ArgumentDefaultsHelpFormatter)
 parser.add_argument('-d', '--data', metavar='DIR', default=None, help='path to dataset (unused with --synthetic)')

@@ -18,10 +18,11 @@ import os
 import sys
 import time
 
-# The step runs three concurrent HIP streams; on HIP's default four hardware queues two of them sometimes share a queue and
-# serialize (1.5-13 % slower, one run in four to eight).  An application-level, process-global choice that must be made before HIP
-# initialises -- so it is made HERE (and in the Train_* / Test_KITTI scripts), not by importing the library (fal_net_amd/__init__.py).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The step keeps four HIP streams busy (plus a collective's when N > 1): five hardware queues, and the plan's stream self-test re-creates any
+# stream that shares a queue with another (fal_net_amd/__init__.py has the measurements: with 8 queues the data-parallel step falls off a cliff,
+# 9.1 vs 5.3 ms).  An application-level, process-global choice that must be made before HIP initialises -- so it is made HERE (and in the
+# Train_* / Test_KITTI scripts), not by importing the library.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 
 import torch
 import torch.distributed as dist
@@ -451,6 +452,12 @@ def main():
                                                                        else "eager launches from Python"),
                    "host_issue_ms_per_step": issue_idle * 1e3, "host_issue_ms_per_step_in_timed_loop": issued * 1e3 / args.steps},
     }
+    st_plan = next((p for p in getattr(model, "_plans", {}).values() if getattr(p, "selftest", None)), None)
+    if st_plan is not None:  # stream / hardware-queue self-test of the step's streams (plan.stream_selftest)
+        t = st_plan.selftest
+        result["config"]["stream_selftest"] = {"pairs_overlap": t["pairs_overlap"], "streams_replaced": t["streams_replaced"], "hw_queues": t["hw_queues"],
+                                               "worst_pair_ms": max(e["worst_pair_ms"] for e in t["streams"]), "collective_beside_spin_ms": t["collective_beside_spin_ms"],
+                                               "all_streams_3x200us_ms": t.get("all_streams_3x200us_ms")}
     if wins:
         result["ms_per_step_10step_windows"] = {"min": round(wins[0], 4), "median": round(wins[len(wins) // 2], 4), "max": round(wins[-1], 4), "n": len(wins),
                                                 "source": "HIP events on the step's stream every 10 steps inside the timed region (rank 0's device)"}

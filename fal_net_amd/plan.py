@@ -73,6 +73,31 @@ def _spin_vs_call_ms(x, probe, fn, us=300):
     return e0.elapsed_time(e1)
 
 
+def _spin_all_ms(streams, fn=None, us=200, rounds=3):
+    """Wall time (ms) of `rounds` rounds of one `us` spin on EVERY stream of `streams` at once (behind a common gate), fn() -- a collective --
+    issued from the second stream in every round: ~rounds x us when the hardware runs all of them side by side."""
+    lib = L.lib()
+    a = streams[0]
+    gate, e0 = torch.cuda.Event(), torch.cuda.Event(enable_timing=True)
+    ends = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    L.check(lib.falnet_spin(50, a.cuda_stream), "spin")
+    gate.record(a)
+    for s in streams[1:]:
+        s.wait_event(gate)
+    e0.record(a)
+    for _ in range(rounds):
+        for i, s in enumerate(streams):
+            L.check(lib.falnet_spin(us, s.cuda_stream), "spin")
+            if fn is not None and i == 1:
+                with torch.cuda.stream(s):
+                    fn()
+    for s, e in zip(streams, ends):
+        e.record(s)
+    for e in ends:
+        e.synchronize()
+    return max(e0.elapsed_time(e) for e in ends)
+
+
 class _WgradPart:
     """One input-channel group of a two-source convolution presented to ops.WgradBatch as a layer of its own: `cin` stays the row stride
     of the full OIHW gradient, the group's channels are the packed columns [0, c_pad) -> real columns [0, c_real) of the gradient VIEW
@@ -893,7 +918,10 @@ class FalnetPlan:
                 e["handle"] = hex(dict(accepted)[e["stream"]].cuda_stream)
             self._deep_with_hook = self._deep_with_hook and collective.get("third", 0.0) <= 0.25 and collective.get("main", 0.0) <= 0.25
         torch.cuda.synchronize(dev)
+        all_ms = _spin_all_ms([s for _, s in accepted], coll)  # every stream of the step busy at once (three rounds of 200 us), the collective among them
+        torch.cuda.synchronize(dev)
         self.selftest = {"pairs_overlap": all(e["worst_pair_ms"] < 0.3 for e in log), "streams": log, "collective_beside_spin_ms": collective,
+                         "all_streams_3x200us_ms": round(all_ms, 3),
                          "streams_replaced": replaced, "third_stream_with_hook": bool(self._deep_with_hook) if hooked else None,
                          "hw_queues": __import__("os").environ.get("GPU_MAX_HW_QUEUES")}
         self._selftest_hooked = hooked

@@ -2,7 +2,7 @@
 """Where does the HOST spend its time issuing a Stage-1 step?  cProfile over K un-synchronised steps of the bench workload
 (bench.py reports the total as config.host_issue_ms_per_step).  Tuning tool only."""
 import cProfile, os, pstats, sys, io
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from fal_net_amd import loss_functions as LF, synthetic, train
