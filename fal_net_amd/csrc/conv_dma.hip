@@ -635,6 +635,251 @@ int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, in
 }
 
 // ============================================================================================================================
+// conv3x3_dma16_kernel (falnet_conv2d variant 23, round 5): conv3x3_dma_kernel<T, 16, 8> on v_mfma_f32_16x16x32.
+//
+// profiles/r05_sq_counters.txt: on the 128- and 256-channel layers the dominant kernel runs at the clock the chip holds under bf16 MFMA load
+// (the same launches on all-zero activations are 1.15-1.26x faster; cuts that need 5-6 % fewer shader cycles are not faster), and
+// MI355X_MICROARCH.md (DVFS give-back, item 7) measures the 16x16x32 shape at 1.12-1.15x the FLOP/s of 32x32x16 at equal cycles per FLOP on
+// random data, operands re-read from LDS: the chip holds a higher clock on it.  Same tile (16 x 32 positions x 64 channels, eight waves of two rows),
+// same LDS-DMA machinery and 32-channel chunks (K = 32 = ONE 16x16x32 per tap), same bytes read per FLOP; what changes:
+//   * a 32 x 32 (channels x positions) tile is 2 x 2 MFMAs (conv_epilogue.h: Acc16); the weight fragment of channel half ct reads row
+//     m16_row_channel(lane & 15), so that Acc16::to32 lands the results in epilogue_direct's layout with one v_permlane16_swap per register;
+//   * lane = (row / position lane & 15, K block lane >> 4) reads 16 B of a 64-B row: the 16-B segments are exchanged in pairs (seg ^ 2) when bit 2
+//     of the patch COLUMN (of the weight row) is set -- on the DMA's source address -- which makes every ds_read_b128 of this lane pattern
+//     conflict-free for the column offsets 0..2 and both 16-position halves (found by exhaustive search over the 4-entry tables; the (row >> 2) & 3
+//     swizzle of the 32x32x16 kernel is 2-way conflicted under this pattern), and independent of the patch row: rows are immediate offsets;
+//   * nine steps (column offset outer, tap row inner) of 16 MFMAs; a pixel fragment serves the two output rows it meets, as in variant 13.
+// NHWC outputs only (the planar-f32 logits launch stays on variant 13).
+template <typename T, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
+    constexpr int NWAVES = 8, MT = 2, TH = NWAVES * MT, BN = 64, NT = BN / 32;
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    constexpr int KCV = 32;
+    constexpr int NPIX = (TH + 2) * CD_PW;
+    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    constexpr int ROWB = CD_PW * 64;  // bytes between patch rows
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31, h = lane >> 5;  // epilogue layout (position, lane half)
+    const int lp = lane & 15, lg = lane >> 4;  // MFMA operand layout (row / position, K block)
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    stage_bias_lds(p, n0, BN, lds_bias);
+
+    const int nsrc = p.nsrc, IH = p.IH, IW = p.IW;
+    const int C0 = p.src[0].C, C1 = nsrc > 1 ? p.src[1].C : 0;
+    const int nchunks = (C0 + C1) / KCV;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    const int l4 = lane >> 2, segpos = lane & 3;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    int64_t w_off[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int tap = wid >> 2, co = n0 + ((wid & 3) << 4) + l4;  // four 16-row pieces per tap tile
+        const int gseg = segpos ^ (((l4 >> 2) & 1) << 1);            // (row >> 2) & 1: pieces start at multiples of 16 rows
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    int64_t a_off[KP];
+    const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
+    int64_t sbat[2] = {0, 0};
+    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
+        const int tix = tile % tiles_x;
+        const int q = tile / tiles_x;
+        ty0 = (q % tiles_y) * TH;
+        tx0 = tix * 32;
+        b = q / tiles_y;
+    };
+    auto tile_offsets = [&](int tile, int s2) {
+        int b, ty0, tx0;
+        tile_coords(tile, b, ty0, tx0);
+        const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
+        sbat[s2] = (int64_t)b * S.sb;
+        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int pix = 16 * (wave + NWAVES * k) + l4;
+            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
+            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
+            a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ (((pc >> 2) & 1) << 1)) * 8)
+                          : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+        }
+    };
+    struct Cur { int tile, c, s, c0, kofs; };
+    auto advance = [&](Cur& q) {
+        if (++q.c == nchunks) {
+            q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
+            q.tile += gridDim.x;
+            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            return;
+        }
+        q.c0 += KCV;
+        q.kofs += KCV;
+        if (q.s == 0 && q.c0 >= C0) {
+            q.s = 1;
+            q.c0 = 0;
+            tile_offsets(q.tile, 1);
+        }
+    };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
+            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+
+    // ---- fragment read addresses: position 16 pt + lp of patch row 0 of this wave per (column offset, half); weight row m16_row_channel(lp) ----
+    int a_lane[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int col = dx + 16 * pt + lp;
+            a_lane[dx][pt] = ((wave * MT) * CD_PW + col) * 64 + ((lg ^ (((col >> 2) & 1) << 1)) << 4);
+        }
+    const int wrow = m16_row_channel(lp);
+    const int b_lane = A_BYTES + wrow * 64 + ((lg ^ (((wrow >> 2) & 1) << 1)) << 4);
+
+    Acc16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt].zero();
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    if (total > 0) {
+        tile_offsets(qi.tile, 0);
+#pragma unroll
+        for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
+        advance(qi);
+    }
+    int ctile = blockIdx.x, cc = 0;
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = it + 1 < total;
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[3][2];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) aa[dx][pt] = a_lane[dx][pt] + bo;
+        const int bb = b_lane + bo;
+        // step st = 3 dx + dy: tap (dy, dx); patch row rs of group dx serves output row mt under dy = rs - mt.  Rows 0, 1 of the NEXT group are read
+        // during step dy = 2, row 2 during dy = 0, row 3 during dy = 1; the four weight fragments of step st + 1 during step st.
+        s16x8_t fa[3][MT + 2][2], fb[2][NT][2];
+        auto a_read = [&](int dx, int rs, int pt) { return *reinterpret_cast<const s16x8_t*>(Bf + aa[dx][pt] + rs * ROWB); };
+        auto b_read = [&](int st, int set) {
+            const int t = (st % 3) * 3 + st / 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) fb[set][nt][ct] = *reinterpret_cast<const s16x8_t*>(Bf + bb + (t * BN + nt * 32 + ct * 16) * 64);
+        };
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) fa[0][rs][pt] = a_read(0, rs, pt);
+        b_read(0, 0);
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            const int dx = st / 3, dy = st % 3;
+            if (st + 1 < 9) b_read(st + 1, (st + 1) & 1);
+            if (dy == 0) { fa[dx][2][0] = a_read(dx, 2, 0); fa[dx][2][1] = a_read(dx, 2, 1); }
+            if (dy == 1) { fa[dx][3][0] = a_read(dx, 3, 0); fa[dx][3][1] = a_read(dx, 3, 1); }
+            if (dy == 2 && dx + 1 < 3) {
+#pragma unroll
+                for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) fa[dx + 1][rs][pt] = a_read(dx + 1, rs, pt);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int i = 2 * st + mt;
+                if (i < KP + KW && more) issue_piece(qi, (it + 1) & 1, i);  // (wave-uniform)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt)
+                            acc[mt][nt].t[ct][pt] = H16<T>::mma16(fb[st & 1][nt][ct], fa[dx][mt + dy][pt], acc[mt][nt].t[ct][pt]);
+            }
+            // DS reads for the coming steps (literals): 6 6 8 | 6 6 8 | 6 6 0
+            if (st == 8) __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
+            else if (dy == 2) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        if (more) advance(qi);
+        if (++cc == nchunks) {
+            cc = 0;
+            int b, ty0, tx0;
+            tile_coords(ctile, b, ty0, tx0);
+            ctile += gridDim.x;
+            const int cstride = p.out_cstride;
+            const int x = tx0 + r;
+            auto pixoff = [&](int mt) -> int64_t {
+                const int y = ty0 + wave * MT + mt;
+                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+            };
+            auto pooloff = [&](int mt) -> int64_t {
+                const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
+                return (py < PH && px < PW) ? (((int64_t)b * PH + py) * PW + px) * cstride : (int64_t)-1;
+            };
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bias[1][16];
+                load_bias16_lds(lds_bias, 32 * nt, h, bias);
+                f32x16 v[MT][1];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][nt].to32(v[mt][0]);
+                    acc[mt][nt].zero();
+                }
+                if constexpr (POOL) epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff, pooloff);
+                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff);
+            }
+        }
+    }
+}
+
+int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 63) / 64;
+    int gx = 256 / ny;  // one persistent workgroup per CU
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+#define DMA16_L(T)                                                                                                                                  \
+    do {                                                                                                                                            \
+        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma16_kernel<T, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma16_kernel<T, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);           \
+    } while (0)
+    FALNET_DISPATCH_16(p.dtype, DMA16_L);
+#undef DMA16_L
+    FALNET_RETURN_LAUNCH();
+}
+
+// ============================================================================================================================
 // Data gradient of a 3x3 / stride-2 / pad-1 convolution (models/FAL_netB.py:101-111 conv1..conv6), all four output-parity
 // classes in ONE pass over the upstream gradient.
 //

@@ -541,6 +541,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
             # four rows per wave, 16-channel chunks: 16x32 tiles on two four-wave workgroups per CU / 32x32 tiles on eight waves.  NOT candidates by
             # default: equal within 1-5 % in isolation (fewer cycles, returned by the chip as clock: profiles/r05_sq_counters.txt), +0.6 % on the step
             cands += [(21, 1), (22, 1)]
+        if L.ab("FALNET_DMA16", "1") == "1":
+            cands += [(23, 1)]  # variant 13's tile on v_mfma_f32_16x16x32
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

@@ -180,7 +180,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 14)) + [15, 16, 17, 20, 21, 22]:  # 21 / 22: four rows per wave, 16-channel chunks, on 16x32 tiles (two workgroups per CU) / 32x32 tiles; 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
+    for variant in list(range(1, 14)) + [15, 16, 17, 20, 21, 22, 23]:  # 21 / 22: four rows per wave, 16-channel chunks, on 16x32 tiles (two workgroups per CU) / 32x32 tiles; 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -194,7 +194,7 @@ def test_conv_every_kernel_variant(case, dtype):
         assert 1 in ran and (15 in ran) == (dtype != torch.float32 and k == 3 and (H + 1) // 2 >= 8 and (W + 1) // 2 >= 32)
         return
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
-    assert (13 in ran) == (21 in ran) == (dtype != torch.float32 and H >= 16)
+    assert (13 in ran) == (21 in ran) == (23 in ran) == (dtype != torch.float32 and H >= 16)
     assert (22 in ran) == (dtype != torch.float32 and H >= 32)
     assert (17 in ran) == (dtype != torch.float32 and H >= 4 and W >= 32)
     assert (20 in ran) == (dtype != torch.float32 and H >= 8 and W >= 32)
@@ -264,7 +264,7 @@ def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
     finally:
         ops.AUTOTUNE = old
     res = {}
-    for variant in (21, 22, 13):
+    for variant in (21, 22, 23, 13):
         call.desc.variant = variant
         if out is not None:
             out.fill_(float("nan"))
@@ -273,7 +273,7 @@ def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
         assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) == 0, (variant, L.lib().falnet_last_error())
         name = C.create_string_buffer(160)
         assert L.lib().falnet_conv2d_kernel_name(call.ref, name, 160) == 0
-        assert (b"conv3x3_dma2_kernel" in name.value) == (variant != 13), name.value
+        assert (b"conv3x3_dma2_kernel" in name.value) == (variant in (21, 22)) and (b"conv3x3_dma16_kernel" in name.value) == (variant == 23), name.value
         torch.cuda.synchronize()
         res[variant] = (None if out is None else out.float().cpu(), None if pooled is None else pooled.float().cpu())
         if out is not None:
@@ -287,7 +287,7 @@ def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
             assert rel(to_nchw(pooled, cout), pr) < TOL[dtype], (variant, mode)
             if mode == "pool":
                 assert torch.equal(pooled.float(), F.max_pool2d(out.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)), variant
-    for v in (21, 22):
+    for v in (21, 22, 23):
         for a, b2 in zip(res[v], res[13]):  # the same products summed in another order: a few ulps of the 16-bit output apart
             if a is not None:
                 assert float((a - b2).abs().max()) <= 2.0 ** (-6 if dtype == torch.bfloat16 else -9) * float(b2.abs().max()), (mode, v)
@@ -314,7 +314,7 @@ def test_conv_fused_maxpool(B, cin, cout, H, W, keep_full, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13, 16, 21, 22]:
+    for variant in list(range(1, 11)) + [13, 16, 21, 22, 23]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         if out is not None:
@@ -356,7 +356,7 @@ def test_conv_fused_sum2x2(B, cin, cout, H, W, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 11)) + [13, 16, 21, 22]:
+    for variant in list(range(1, 11)) + [13, 16, 21, 22, 23]:
         call.desc.variant = variant
         pooled.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
