@@ -2873,7 +2873,7 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh);        // c
 int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);
 bool falnet_conv_dma2_applicable(const falnet_conv_t& p, int th);           // four rows per wave, 16-channel chunks: 16x32 tiles, two four-wave workgroups per CU (21) / 32x32 tiles, eight waves (22)
 int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);
-int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st);  // variant 13's tile on v_mfma_f32_16x16x32 (variant 23)
+int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);  // variants 13 / 17 / 20 on v_mfma_f32_16x16x32 (variants 23 / 24 / 25)
 bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // deconv forward in sub-pixel form (variant 18)
 int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
 bool falnet_conv_deep_applicable(const falnet_conv_t& p);                   // maps of <= 128 positions: one-shot LDS-DMA, K slices, last-arriver epilogue (variant 19)
@@ -2920,7 +2920,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || variant == 21 || variant == 22 || variant == 23, "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || (variant >= 21 && variant <= 25), "conv2d: unknown variant %d", variant);
     if (variant == 19) {  // levels 5-6: K-sliced one-shot LDS-DMA kernel with the epilogue in the last slice (conv_dma.hip: conv3x3_deep_kernel)
         if (!falnet_conv_deep_applicable(p)) {
             falnet_set_error("conv2d: variant 19 needs a 16-bit nine-tap stride-1/2 launch on maps of at most 128 positions (128 %% (TH TW) == 0), dense NHWC output, "
@@ -2955,15 +2955,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.bn = 32; c.kcb = 64; c.tps = 16; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
-    if (variant == 23) {  // variant 13's tile on v_mfma_f32_16x16x32 (conv_dma.hip: conv3x3_dma16_kernel)
-        if (!(dense3x3 && falnet_conv_dma2_applicable(p, 16))) {
-            falnet_set_error("conv2d: variant 23 needs a 16-bit dense 3x3 stride-1 NHWC launch (>= 16 x 32 positions) with sources at the launch size or half of it");
+    if (variant >= 23 && variant <= 25) {  // variants 13 / 17 / 20 on v_mfma_f32_16x16x32 (conv_dma.hip: conv3x3_dma16_kernel)
+        const int th = variant == 23 ? 16 : (variant == 24 ? 4 : 8);
+        if (!(dense3x3 && falnet_conv_dma_applicable(p, th)) || (th != 16 && (p.pool_out || planar)) || (planar && p.pool_out)) {
+            falnet_set_error("conv2d: variant %d needs a 16-bit dense 3x3 stride-1 launch (>= %d x 32 positions%s) with sources at the launch size or half of it",
+                             variant, th, th != 16 ? ", NHWC output, no fused pool" : "");
             return -2;
         }
         c.flip = flip;
         c.swap = 0;
         c.patch = 8;
-        c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 16; c.nwaves = 8;
+        c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = th; c.nwaves = th == 4 ? 4 : 8;
         return 0;
     }
     if (variant == 21 || variant == 22) {  // LDS-DMA, four rows per wave, 16-channel chunks: 16x32 tiles on two four-wave workgroups per CU (21), 32x32 tiles on eight waves (22) (conv_dma.hip: conv3x3_dma2_kernel)
@@ -3064,7 +3066,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
     if (c.patch == 8)
-        snprintf(buf, len, "_Z20conv3x3_dma16_kernelI%sLb%dEEv13falnet_conv_tiiii", t, pp->pool_out ? 1 : 0);
+        snprintf(buf, len, "_Z20conv3x3_dma16_kernelI%sLb%dELi%dELi%dELb%dEEv13falnet_conv_tiiii", t, pp->pool_out ? 1 : 0, c.th, c.nwaves, planar ? 1 : 0);
     else if (c.patch == 7)
         snprintf(buf, len, "_Z19conv3x3_dma2_kernelI%sLb%dELi%dEEv13falnet_conv_tiiiii", t, pp->pool_out ? 1 : 0, c.nwaves);
     else if (c.patch == 6)
@@ -3117,7 +3119,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
-    if (c.patch == 8) return falnet_conv_dma16_launch(p, c.flip, st);
+    if (c.patch == 8) return falnet_conv_dma16_launch(p, c.flip, st, c.th);
     if (c.patch == 7) return falnet_conv_dma2_launch(p, c.flip, st, c.th);
     if (c.patch == 6) return falnet_conv_deep_launch(p, st);
     if (c.patch == 5) return falnet_conv_up2_dma_launch(p, st);

@@ -649,11 +649,13 @@ int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, in
 //     conflict-free for the column offsets 0..2 and both 16-position halves (found by exhaustive search over the 4-entry tables; the (row >> 2) & 3
 //     swizzle of the 32x32x16 kernel is 2-way conflicted under this pattern), and independent of the patch row: rows are immediate offsets;
 //   * nine steps (column offset outer, tap row inner) of 16 MFMAs; a pixel fragment serves the two output rows it meets, as in variant 13.
-// NHWC outputs only (the planar-f32 logits launch stays on variant 13).
-template <typename T, bool POOL>
-__global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
-    constexpr int NWAVES = 8, MT = 2, TH = NWAVES * MT, BN = 64, NT = BN / 32;
-    static_assert(sizeof(T) == 2, "16-bit operands");
+// <T, POOL, 16, 8, PLANAR>: variant 23 (PLANAR: the planar-f32 output form of the logits launch, an instantiation of its own -- its sixteen 64-bit
+// store addresses cost ~60 registers).  <T, false, 4, 4, false> / <T, false, 8, 8, false>: variants 24 / 25, the 4 x 32 / 8 x 32 tiles of variants
+// 17 / 20 (one row per wave) for the maps of levels 4 / 3.
+template <typename T, bool POOL, int TH, int NWAVES, bool PLANAR>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma16_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int flip, int ntiles) {
+    constexpr int MT = TH / NWAVES, BN = 64, NT = BN / 32;
+    static_assert(sizeof(T) == 2 && (MT == 1 || MT == 2) && (MT == 2 || !POOL), "16-bit operands; one or two rows per wave; the fused pool needs row pairs");
     constexpr int KCV = 32;
     constexpr int NPIX = (TH + 2) * CD_PW;
     constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 9 * BN / 16, NPIECES = A_PIECES + B_PIECES;
@@ -781,8 +783,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) aa[dx][pt] = a_lane[dx][pt] + bo;
         const int bb = b_lane + bo;
-        // step st = 3 dx + dy: tap (dy, dx); patch row rs of group dx serves output row mt under dy = rs - mt.  Rows 0, 1 of the NEXT group are read
-        // during step dy = 2, row 2 during dy = 0, row 3 during dy = 1; the four weight fragments of step st + 1 during step st.
+        // step st = 3 dx + dy: tap (dy, dx); patch row rs of group dx serves output row mt under dy = rs - mt.  Rows 0 .. MT-1 of the NEXT group are
+        // read during step dy = 2, row MT during dy = 0, row MT + 1 during dy = 1; the four weight fragments of step st + 1 during step st.
         s16x8_t fa[3][MT + 2][2], fb[2][NT][2];
         auto a_read = [&](int dx, int rs, int pt) { return *reinterpret_cast<const s16x8_t*>(Bf + aa[dx][pt] + rs * ROWB); };
         auto b_read = [&](int st, int set) {
@@ -792,8 +794,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) fb[set][nt][ct] = *reinterpret_cast<const s16x8_t*>(Bf + bb + (t * BN + nt * 32 + ct * 16) * 64);
         };
+        static_assert(KP + KW <= 18, "two DMA issue slots per step");
 #pragma unroll
-        for (int rs = 0; rs < 2; ++rs)
+        for (int rs = 0; rs < MT; ++rs)
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) fa[0][rs][pt] = a_read(0, rs, pt);
         b_read(0, 0);
@@ -801,31 +804,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv
         for (int st = 0; st < 9; ++st) {
             const int dx = st / 3, dy = st % 3;
             if (st + 1 < 9) b_read(st + 1, (st + 1) & 1);
-            if (dy == 0) { fa[dx][2][0] = a_read(dx, 2, 0); fa[dx][2][1] = a_read(dx, 2, 1); }
-            if (dy == 1) { fa[dx][3][0] = a_read(dx, 3, 0); fa[dx][3][1] = a_read(dx, 3, 1); }
+            if (dy < 2) { fa[dx][MT + dy][0] = a_read(dx, MT + dy, 0); fa[dx][MT + dy][1] = a_read(dx, MT + dy, 1); }
             if (dy == 2 && dx + 1 < 3) {
 #pragma unroll
-                for (int rs = 0; rs < 2; ++rs)
+                for (int rs = 0; rs < MT; ++rs)
 #pragma unroll
                     for (int pt = 0; pt < 2; ++pt) fa[dx + 1][rs][pt] = a_read(dx + 1, rs, pt);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int i = 2 * st + mt;
+            for (int half = 0; half < 2; ++half) {  // two DMA issue slots per step, each in front of half of the step's MFMAs
+                const int i = 2 * st + half;
                 if (i < KP + KW && more) issue_piece(qi, (it + 1) & 1, i);  // (wave-uniform)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                    for (int nt = (MT == 2 ? 0 : half); nt < (MT == 2 ? NT : half + 1); ++nt) {
+                        if (MT == 2 && mt != half) continue;
 #pragma unroll
-                        for (int pt = 0; pt < 2; ++pt)
-                            acc[mt][nt].t[ct][pt] = H16<T>::mma16(fb[st & 1][nt][ct], fa[dx][mt + dy][pt], acc[mt][nt].t[ct][pt]);
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt)
+                                acc[mt][nt].t[ct][pt] = H16<T>::mma16(fb[st & 1][nt][ct], fa[dx][mt + dy][pt], acc[mt][nt].t[ct][pt]);
+                    }
             }
-            // DS reads for the coming steps (literals): 6 6 8 | 6 6 8 | 6 6 0
+            // DS reads for the coming steps (the builtin wants literals): two rows per wave 6 6 8 | 6 6 8 | 6 6 0, one row 6 6 6 | 6 6 6 | 6 6 0
             if (st == 8) __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
-            else if (dy == 2) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            else if (dy == 2 && MT == 2) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
             else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if constexpr (MT == 2) __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
         if (more) advance(qi);
         if (++cc == nchunks) {
@@ -838,7 +845,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv
             auto pixoff = [&](int mt) -> int64_t {
                 const int y = ty0 + wave * MT + mt;
                 if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                if constexpr (PLANAR) return ((int64_t)b * p.Cout * p.OH + y) * p.OW + x;  // planar f32 [B][Cout][OH][OW]: offset of channel 0
+                else return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
             };
             auto pooloff = [&](int mt) -> int64_t {
                 const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
@@ -855,27 +863,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma16_kernel(const falnet_conv
                     acc[mt][nt].zero();
                 }
                 if constexpr (POOL) epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff, pooloff);
-                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff);
+                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1, false, !PLANAR>(p, v, bias, n0 + 32 * nt, lane, pixoff);
             }
         }
     }
 }
 
-int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
-    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + th - 1) / th;
     const int ntiles = p.B * tiles_x * tiles_y;
     const int ny = (p.Cout + 63) / 64;
     int gx = 256 / ny;  // one persistent workgroup per CU
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-#define DMA16_L(T)                                                                                                                                  \
-    do {                                                                                                                                            \
-        if (p.pool_out) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma16_kernel<T, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);  \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma16_kernel<T, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, flip, ntiles);           \
+    const bool planar = p.out_layout == FALNET_OUT_PLANAR_F32;
+#define DMA16_K(T, PL, TH_, NW, PN) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_dma16_kernel<T, PL, TH_, NW, PN>), grid, dim3(NW * 64), 0, st, p, tiles_x, tiles_y, flip, ntiles)
+#define DMA16_L(T)                                        \
+    do {                                                  \
+        if (th == 4) DMA16_K(T, false, 4, 4, false);      \
+        else if (th == 8) DMA16_K(T, false, 8, 8, false); \
+        else if (planar) DMA16_K(T, false, 16, 8, true);  \
+        else if (p.pool_out) DMA16_K(T, true, 16, 8, false); \
+        else DMA16_K(T, false, 16, 8, false);             \
     } while (0)
     FALNET_DISPATCH_16(p.dtype, DMA16_L);
 #undef DMA16_L
+#undef DMA16_K
     FALNET_RETURN_LAUNCH();
 }
 

@@ -543,6 +543,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
             cands += [(21, 1), (22, 1)]
         if L.ab("FALNET_DMA16", "1") == "1":
             cands += [(23, 1)]  # variant 13's tile on v_mfma_f32_16x16x32
+            if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")):
+                cands += [(24, 1), (25, 1)]  # ... variants 17 / 20 (4x32 / 8x32 tiles)
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

@@ -136,7 +136,7 @@ typedef struct {
                                   22 = the wave program of 21 on 32x32-position tiles, eight waves, one workgroup per CU (2 x 55 KiB of LDS): 27 % fewer
                                   staged bytes and 40 % fewer fragment reads per MFMA than 13;
                                   23 = 13 on v_mfma_f32_16x16x32 (a 32x32 tile as 2 x 2 MFMAs of K = 32): the MFMA shape the chip holds a higher clock on
-                                  (conv_dma.hip: conv3x3_dma16_kernel; NHWC outputs only);
+                                  (conv_dma.hip: conv3x3_dma16_kernel); 24 / 25 = 17 / 20 in the same way (NHWC outputs, no fused pool);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

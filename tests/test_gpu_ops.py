@@ -180,7 +180,7 @@ def test_conv_every_kernel_variant(case, dtype):
     finally:
         ops.AUTOTUNE = old
     ran = []
-    for variant in list(range(1, 14)) + [15, 16, 17, 20, 21, 22, 23]:  # 21 / 22: four rows per wave, 16-channel chunks, on 16x32 tiles (two workgroups per CU) / 32x32 tiles; 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
+    for variant in list(range(1, 14)) + [15, 16, 17, 20, 21, 22, 23, 24, 25]:  # 21 / 22: four rows per wave, 16-channel chunks, on 16x32 tiles (two workgroups per CU) / 32x32 tiles; 11 / 12: gather with 32 / 64 output channels per workgroup; 13: LDS-DMA double-buffered persistent; 15: LDS-DMA stride 2; 16: two-phase weight-stationary; 17 / 20: LDS-DMA on 4x32 / 8x32 tiles
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())
@@ -196,8 +196,8 @@ def test_conv_every_kernel_variant(case, dtype):
     assert 1 in ran and 4 in ran and (7 in ran or H < 16) and 11 in ran
     assert (13 in ran) == (21 in ran) == (23 in ran) == (dtype != torch.float32 and H >= 16)
     assert (22 in ran) == (dtype != torch.float32 and H >= 32)
-    assert (17 in ran) == (dtype != torch.float32 and H >= 4 and W >= 32)
-    assert (20 in ran) == (dtype != torch.float32 and H >= 8 and W >= 32)
+    assert (17 in ran) == (24 in ran) == (dtype != torch.float32 and H >= 4 and W >= 32)
+    assert (20 in ran) == (25 in ran) == (dtype != torch.float32 and H >= 8 and W >= 32)
     assert (10 in ran) == (16 in ran) == (sum(ops.pad_c(c) for c in groups) * (4 if dtype == torch.float32 else 2) <= 128)
 
 
@@ -415,7 +415,7 @@ def test_conv_few_output_channels_planar(cout, dtype):
     call = ops.conv_call(dtype, [ops.nhwc_src(src)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out,
                          H, W, cout, 0, out_layout=L.OUT_PLANAR_F32)
     ran = []
-    for variant in (1, 2, 4, 10, 16, 13):
+    for variant in (1, 2, 4, 10, 16, 13, 23):  # (23: the planar-f32 instantiation of the 16x16x32 LDS-DMA kernel)
         call.desc.variant = variant
         out.fill_(float("nan"))
         rc = L.lib().falnet_conv2d(call.ref, L.stream_ptr())

@@ -32,7 +32,7 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("deconv3 256->128 @64x128 (up)", [256], 128, 64, 128, (32, 64)),
     ("deconv2 128->64 @128x256 (up)", [128], 64, 128, 256, (64, 128)),
 ]
-VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dma2", 21), ("dma32", 22), ("dma16", 23), ("dma4", 17), ("dma8", 20), ("up2", 18), ("gather", 1), ("g8", 108), ("g16", 116), ("deep32", 1932), ("deep64", 1964)]
+VARIANTS = [("p128", 2), ("p64", 3), ("S", 4), ("p64M512", 6), ("S512", 7), ("ws", 10), ("ws2", 16), ("dma", 13), ("dma2", 21), ("dma32", 22), ("dma16", 23), ("dma16t4", 24), ("dma16t8", 25), ("dma4", 17), ("dma8", 20), ("up2", 18), ("gather", 1), ("g8", 108), ("g16", 116), ("deep32", 1932), ("deep64", 1964)]
 if os.environ.get("BENCH_VARIANTS"):  # e.g. BENCH_VARIANTS=dma,ws
     VARIANTS = [v for v in VARIANTS if v[0] in os.environ["BENCH_VARIANTS"].split(",")]
 if os.environ.get("BENCH_LAYERS"):  # substring filter, comma separated
