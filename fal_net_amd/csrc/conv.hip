@@ -3066,7 +3066,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
     if (c.patch == 8)
-        snprintf(buf, len, "_Z20conv3x3_dma16_kernelI%sLb%dELi%dELi%dELb%dEEv13falnet_conv_tiiii", t, pp->pool_out ? 1 : 0, c.th, c.nwaves, planar ? 1 : 0);
+        snprintf(buf, len, "_Z20conv3x3_dma16_kernelI%sLb%dELi%dELi%dELb%dEEv13falnet_conv_tiiii", t, pp->pool_out ? 1 : 0, c.th, c.nwaves, pp->out_layout == FALNET_OUT_PLANAR_F32 ? 1 : 0);
     else if (c.patch == 7)
         snprintf(buf, len, "_Z19conv3x3_dma2_kernelI%sLb%dELi%dEEv13falnet_conv_tiiiii", t, pp->pool_out ? 1 : 0, c.nwaves);
     else if (c.patch == 6)
