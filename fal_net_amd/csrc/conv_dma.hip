@@ -28,6 +28,9 @@
 #ifndef FALNET_DMA_EPI_AHEAD
 #define FALNET_DMA_EPI_AHEAD -1  // conv_epilogue.h: epilogue_direct's operand prefetch depth (-1: conditional loads at the point of use)
 #endif
+#ifndef FALNET_DMA16_EPI_AHEAD
+#define FALNET_DMA16_EPI_AHEAD 0  // the same for conv3x3_dma16_kernel: branch-free fetch of the slab's residual / activation operands in front of its arithmetic (218 registers; -1 -> 0: 3-10 % on launches with such operands, 1 no better: profiles/r05_dma16.txt)
+#endif
 
 // 32 KiB of zeros: the 'pixel' / 'weight row' every out-of-image or out-of-range 16-B piece is fetched from.  Invalid lanes carry
 // the OFFSET of this page relative to their tensor, so a piece's address is always base + offset (+ channel offset < 16 K
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
                     acc[mt][nt].zero();
                 }
                 if constexpr (POOL) epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff, pooloff);
-                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, -1, false, !PLANAR>(p, v, bias, n0 + 32 * nt, lane, pixoff);
+                else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, (PLANAR ? -1 : FALNET_DMA16_EPI_AHEAD), false, !PLANAR>(p, v, bias, n0 + 32 * nt, lane, pixoff);
             }
         }
     }

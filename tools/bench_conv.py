@@ -55,8 +55,14 @@ for name, groups, cout, H, W, up in LAYERS:
     out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
     ops.AUTOTUNE = False
     pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV) if os.environ.get('BENCH_POOL') else None  # BENCH_POOL=1: only the 2x2-pooled map is stored
+    # BENCH_DGRAD=1: the data-gradient epilogue (residual addend + activation-gradient operand, no activation) instead of bias-free ELU
+    dg = os.environ.get('BENCH_DGRAD') == '1' and pooled is None
+    addend = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if dg else None
+    actout = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if dg else None
     call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
-                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled, act={'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')], weight_up2=pc.wu)
+                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled,
+                         act=0 if dg else {'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')], weight_up2=None if dg else pc.wu,
+                         addend=addend, actout=actout, actout_kind=L.ACT_ELU if dg else L.ACT_NONE)
     flops = 2.0 * B * H * W * cout * cin * 9
     times = {v: [] for v, _ in VARIANTS}
     ref = None
