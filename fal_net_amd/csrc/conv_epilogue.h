@@ -302,7 +302,9 @@ __device__ __forceinline__ float lane_xor1(float v) {  // value of lane ^ 1 (DPP
 // DEFER: nothing is stored; the finished tiles go to *defer (NHWC outputs only), epilogue_store_packed writes them later.
 // NHWC_ONLY: the planar-f32 output form is compiled out (kernels whose dispatcher admits NHWC launches only): its sixteen 64-bit store addresses are
 // ~60 registers at a kernel's high-water mark even when the branch is never taken.
-template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1, bool DEFER = false, bool NHWC_ONLY = false>
+// PLANAR_PTR: the planar-f32 stores walk ONE running 64-bit pointer (channel stride added between stores, pinned by an empty asm) instead of sixteen
+// independent addresses: 2 address registers instead of 32 (conv3x3_dma16_kernel's planar instantiation spilled 136 B per lane without it).
+template <typename T, int MT, int NT, typename PixOff, typename PoolOff = NoPool, int AHEAD = 1, bool DEFER = false, bool NHWC_ONLY = false, bool PLANAR_PTR = false>
 __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (&acc)[MT][NT], const float (&bias)[NT][16], int nbase, int lane,
                                                 PixOff pixoff, PoolOff pooloff = PoolOff(), PackedOut<T, MT, NT>* defer = nullptr) {
     constexpr bool POOL = !std::is_same<PoolOff, NoPool>::value;
@@ -357,7 +359,18 @@ __device__ __forceinline__ void epilogue_direct(const falnet_conv_t& p, f32x16 (
                 // OH*OW; the 32 lanes of a half are consecutive columns -> 128-B runs per channel
                 float* po = reinterpret_cast<float*>(p.out);
                 const int64_t cs = (int64_t)p.OH * p.OW;
-                if (o >= 0) {
+                if constexpr (PLANAR_PTR) {
+                    if (o >= 0) {
+                        float* q = po + o + (int64_t)(cbase + 4 * h) * cs;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
+                            asm volatile("" : "+v"(q));  // keep ONE address: hipcc otherwise materialises all sixteen up front
+                            if (c < p.Cout) *q = v[j];
+                            q += ((j & 3) == 3) ? 5 * cs : cs;  // next channel; after four, the lane half's next group of four (8 channels on)
+                        }
+                    }
+                } else if (o >= 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int c = cbase + 8 * (j >> 2) + 4 * h + (j & 3);
