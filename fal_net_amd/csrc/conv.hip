@@ -2873,7 +2873,6 @@ bool falnet_conv_dma_applicable(const falnet_conv_t& p, int min_oh);        // c
 int falnet_conv_dma_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);
 bool falnet_conv_dma2_applicable(const falnet_conv_t& p, int th);           // four rows per wave, 16-channel chunks: 16x32 tiles, two four-wave workgroups per CU (21) / 32x32 tiles, eight waves (22)
 int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);
-bool falnet_up2_m16();  // conv_dma.hip: the sub-pixel deconv kernel on v_mfma_f32_16x16x32 (default on)
 int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);  // variants 13 / 17 / 20 on v_mfma_f32_16x16x32 (variants 23 / 24 / 25)
 bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // deconv forward in sub-pixel form (variant 18)
 int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
@@ -3073,7 +3072,7 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     else if (c.patch == 6)
         snprintf(buf, len, "_Z19conv3x3_deep_kernelI%sLi%dELi%dEEv13falnet_conv_t18falnet_deep_geom_t", t, c.kcb, c.nwaves);
     else if (c.patch == 5)
-        snprintf(buf, len, "_Z22conv3x3_up2_dma_kernelI%sLb%dEEv13falnet_conv_tiiiii", t, (int)falnet_up2_m16());
+        snprintf(buf, len, "_Z22conv3x3_up2_dma_kernelI%sEv13falnet_conv_tiiiii", t);
     else if (c.patch == 4)
         snprintf(buf, len, "_Z22conv3x3_s2f_dma_kernelI%sLi%dEEv13falnet_conv_tiii", t, c.bn);
     else if (c.patch == 3)

@@ -600,16 +600,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void conv3x3_dma2_kernel(const faln
     }
 }
 
-// 16x16x32 forms of the sub-pixel deconv / stride-2 data-gradient kernels (default on; FALNET_UP2_M16=0 / FALNET_S2D_M16=0 in experiment builds)
-bool falnet_up2_m16() {
-    static const bool on = [] { const char* e = falnet_ab_env("FALNET_UP2_M16"); return !(e && e[0] == '0'); }();
-    return on;
-}
-bool falnet_s2d_m16() {
-    static const bool on = [] { const char* e = falnet_ab_env("FALNET_S2D_M16"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 bool falnet_conv_dma2_applicable(const falnet_conv_t& p, int th) {
     return falnet_conv_dma_applicable(p, th) && p.out_layout == FALNET_OUT_NHWC;
 }
@@ -922,8 +912,7 @@ int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, i
 
 // MT = rows per wave: 2 -> 16 x 32 gout positions per tile; 1 -> 8 x 32 (round 4): conv3 / conv4 have 32 / 8 sixteen-row tiles per
 // channel block at B = 8 -- 128 / 64 workgroups for 256 CUs -- and twice as many eight-row ones.
-// M16 (round 5): the same kernel on v_mfma_f32_16x16x32 (conv3x3_dma16_kernel has the reasoning, the segment swizzle and the operand maps).
-template <typename T, int MT = 2, bool M16 = false>
+template <typename T, int MT = 2>
 __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles, int GH, int GW) {
     constexpr int NWAVES = 8, BN = 32, TH = NWAVES * MT;
     constexpr int KCV = 32;
@@ -955,7 +944,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
     for (int k = 0; k < KW; ++k) {
         const int wid = wave + NWAVES * k;
         const int tap = wid >> 1, co = n0 + ((wid & 1) << 4) + l4;  // two 16-row pieces per tap tile
-        const int gseg = M16 ? segpos ^ (((l4 >> 2) & 1) << 1) : segpos ^ ((lane >> 4) & 3);
+        const int gseg = segpos ^ ((lane >> 4) & 3);
         w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + tap) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
     }
     int64_t a_off[KP];
@@ -977,8 +966,7 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
             const int pr = pix / SD_PW, pc = pix - pr * SD_PW;
             const int vy = ty0 + pr, vx = tx0 + pc;
             const bool ok = pix < NPIX && vy < GH && vx < GW;
-            const int sw = M16 ? ((pc >> 2) & 1) << 1 : (pix >> 2) & 3;
-            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ sw) * 8) : (int64_t)(zero_t - (sptr + sbat));
+            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8) : (int64_t)(zero_t - (sptr + sbat));
         }
     };
     struct Cur { int tile, c; };
@@ -1014,101 +1002,6 @@ __global__ __launch_bounds__(512) void conv3x3_s2d_dma_kernel(const falnet_conv_
             if (wid < B_PIECES) cd_glds16(wbase + w_off[k], dst0 + A_BYTES + wid * 1024);
         }
     };
-    if constexpr (M16) {
-        // ---- v_mfma_f32_16x16x32 form: lane = (position / weight row lane & 15, K block lane >> 4) ----
-        constexpr int ROWB = SD_PW * 64;
-        const int lp = lane & 15, lg = lane >> 4;
-        int a16[2][2];  // patch row 0 of this wave, column offset ox, 16-position half pt (row rs: + rs * ROWB)
-#pragma unroll
-        for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int col = ox + 16 * pt + lp;
-                a16[ox][pt] = ((wave * MT) * SD_PW + col) * 64 + ((lg ^ (((col >> 2) & 1) << 1)) << 4);
-            }
-        const int wrow = m16_row_channel(lp);
-        const int b16 = A_BYTES + wrow * 64 + ((lg ^ (((wrow >> 2) & 1) << 1)) << 4);
-        Acc16 acc[4][MT];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[c][mt].zero();
-        Cur qi = {(int)blockIdx.x, 0};
-        if (total > 0) {
-            tile_offsets(qi.tile);
-            issue(qi, 0);
-            advance(qi);
-        }
-        int ctile = blockIdx.x, cc = 0;
-        for (int it = 0; it < total; ++it) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const bool more = it + 1 < total;
-            int bo = (it & 1) * BUF;
-            asm volatile("" : "+s"(bo));
-            const char* const Bf = lds + bo;
-            s16x8_t fa[2][MT][2], fb[2][2];
-            auto load_tap = [&](int t, int set) {
-                const int kh = t / 3, kw = t % 3;
-                const int oy = kh == 0 ? 1 : 0, ox = kw == 0 ? 1 : 0;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) fa[set][mt][pt] = *reinterpret_cast<const s16x8_t*>(Bf + a16[ox][pt] + (mt + oy) * ROWB);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) fb[set][ct] = *reinterpret_cast<const s16x8_t*>(Bf + b16 + (t * BN + ct * 16) * 64);
-            };
-            load_tap(0, 0);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) load_tap(t + 1, (t + 1) & 1);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int i = 2 * t + half;
-                    if (i < KP + KW && more) issue_piece(qi, (it + 1) & 1, i);
-                }
-                const int cls = (((t / 3) + 1) & 1) * 2 + (((t % 3) + 1) & 1);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt)
-                            acc[cls][mt].t[ct][pt] = H16<T>::mma16(fb[t & 1][ct], fa[t & 1][mt][pt], acc[cls][mt].t[ct][pt]);
-                if (t + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);
-            }
-            if (more) advance(qi);
-            if (++cc == nchunks) {
-                cc = 0;
-                int b, ty0, tx0;
-                tile_coords(ctile, b, ty0, tx0);
-                ctile += gridDim.x;
-                const int cstride = p.out_cstride;
-                float bias[1][16];
-                load_bias16_lds(lds_bias, 0, h, bias);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int py = c >> 1, px = c & 1;
-                    const int x = 2 * (tx0 + r) + px;
-                    auto pixoff = [&](int mt) -> int64_t {
-                        const int y = 2 * (ty0 + wave * MT + mt) + py;
-                        if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                        return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
-                    };
-                    f32x16 v[MT][1];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        acc[c][mt].to32(v[mt][0]);
-                        acc[c][mt].zero();
-                    }
-                    epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD, false, true>(p, v, bias, n0, lane, pixoff);
-                }
-            }
-        }
-        return;
-    }
     // fragment read addresses: gout position (2 wave + rs, ox + r) of the tile, rs = mt + oy in 0..2, ox in 0..1
     int a_addr[3][2];
 #pragma unroll
@@ -1246,29 +1139,13 @@ int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-#define S2D_K(T, M, X) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<T, M, X>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW)
-#ifdef FALNET_AB  // (experiment builds only: FALNET_S2D_M16=0 selects the 32x32x16 form; the product library does not carry it)
-    const bool m16 = falnet_s2d_m16();
-#define S2D_L(T)                                     \
-    do {                                             \
-        if (small) {                                 \
-            if (m16) S2D_K(T, 1, true);              \
-            else S2D_K(T, 1, false);                 \
-        } else {                                     \
-            if (m16) S2D_K(T, 2, true);              \
-            else S2D_K(T, 2, false);                 \
-        }                                            \
+#define S2D_L(T)                                                                                                                                     \
+    do {                                                                                                                                             \
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<T, 1>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);  \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_s2d_dma_kernel<T, 2>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);        \
     } while (0)
-#else
-#define S2D_L(T)                                     \
-    do {                                             \
-        if (small) S2D_K(T, 1, true);                \
-        else S2D_K(T, 2, true);                      \
-    } while (0)
-#endif
     FALNET_DISPATCH_16(p.dtype, S2D_L);
 #undef S2D_L
-#undef S2D_K
     FALNET_RETURN_LAUNCH();
 }
 
@@ -1285,9 +1162,7 @@ int falnet_conv_s2d_dma_launch(const falnet_conv_t* d, hipStream_t st) {
 // output channels; per 32-channel chunk the (16+2) x (32+2) patch of L and the sixteen 32 x 32 (class, tap) weight tiles arrive by LDS-DMA
 // (double buffer, one barrier per chunk, persistent); four accumulator sets (class x 2 rows); bias / activation epilogue per class on the
 // interleaved output positions.  Weights: packed [CoutPad][16][CinTot] by falnet_pack_up2_batched, pair index = 4 class + 2 a + b.
-// M16 (round 5): the same kernel on v_mfma_f32_16x16x32 (one K = 32 MFMA group per (class, tap) pair instead of two K = 16 steps; conv3x3_dma16_kernel
-// has the reasoning, the segment swizzle and the operand maps).
-template <typename T, bool M16>
+template <typename T>
 __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles, int GH, int GW) {
     constexpr int TH = 16, NWAVES = 8, BN = 32, MT = 2, NPAIR = 16;
     constexpr int KCV = 32;
@@ -1318,7 +1193,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
     int64_t w_off0;
     {
         const int pair = wave >> 1, co = n0 + ((wave & 1) << 4) + l4;
-        const int gseg = M16 ? segpos ^ (((l4 >> 2) & 1) << 1) : segpos ^ ((lane >> 4) & 3);
+        const int gseg = segpos ^ ((lane >> 4) & 3);
         w_off0 = co < p.w_rows ? (int64_t)(co * NPAIR + pair) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
     }
     const int w_step = (n0 + 32 <= p.w_rows) ? (NWAVES / 2) * p.cin_total : 0;  // (a partial last row block reads the zero page for every k)
@@ -1342,8 +1217,7 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
             const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
             const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
             const bool ok = pix < NPIX && vy >= 0 && vy < GH && vx >= 0 && vx < GW;
-            const int sw = M16 ? ((pc >> 2) & 1) << 1 : (pix >> 2) & 3;
-            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ sw) * 8) : (int64_t)(zero_t - (sptr + sbat));
+            a_off[k] = ok ? (int64_t)(vy * (int)S.sy + vx * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8) : (int64_t)(zero_t - (sptr + sbat));
         }
     };
     struct Cur { int tile, c; };
@@ -1364,104 +1238,6 @@ __global__ __launch_bounds__(512) void conv3x3_up2_dma_kernel(const falnet_conv_
             cd_glds16(wptr + q.c * KCV + w_off0 + (i - KP) * w_step, dst0 + A_BYTES + wid * 1024);
         }
     };
-    if constexpr (M16) {
-        // ---- v_mfma_f32_16x16x32 form: lane = (position / weight row lane & 15, K block lane >> 4) ----
-        constexpr int ROWB = CD_PW * 64;
-        const int lp = lane & 15, lg = lane >> 4;
-        int a16[3][2];  // patch row 0 of this wave, column offset dxi, 16-position half pt (row rs: + rs * ROWB)
-#pragma unroll
-        for (int dxi = 0; dxi < 3; ++dxi)
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int col = dxi + 16 * pt + lp;
-                a16[dxi][pt] = ((wave * MT) * CD_PW + col) * 64 + ((lg ^ (((col >> 2) & 1) << 1)) << 4);
-            }
-        const int wrow = m16_row_channel(lp);
-        int b16 = A_BYTES + wrow * 64 + ((lg ^ (((wrow >> 2) & 1) << 1)) << 4);
-        Acc16 acc[4][MT];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[c][mt].zero();
-        Cur qi = {(int)blockIdx.x, 0};
-        if (total > 0) {
-            tile_offsets(qi.tile);
-#pragma unroll
-            for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
-            advance(qi);
-        }
-        int ctile = blockIdx.x, cc = 0;
-        for (int it = 0; it < total; ++it) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const bool more = it + 1 < total;
-            const char* const Bf = lds;
-            s16x8_t fa[2][MT][2], fb[2][2];
-            auto load_pair = [&](int pr_, int set) {
-                const int cls = pr_ >> 2, a = (pr_ >> 1) & 1, b2 = pr_ & 1;
-                const int dyi = (cls >> 1) + a, dxi = (cls & 1) + b2;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) fa[set][mt][pt] = *reinterpret_cast<const s16x8_t*>(Bf + a16[dxi][pt] + (mt + dyi) * ROWB);
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) fb[set][ct] = *reinterpret_cast<const s16x8_t*>(Bf + b16 + (pr_ * BN + ct * 16) * 64);
-            };
-            load_pair(0, 0);
-#pragma unroll
-            for (int st = 0; st < NPAIR; ++st) {
-                if (st + 1 < NPAIR) load_pair(st + 1, (st + 1) & 1);
-                if (st < KP + KW && more) issue_piece(qi, (it + 1) & 1, st);
-                const int cls = st >> 2;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt)
-                            acc[cls][mt].t[ct][pt] = H16<T>::mma16(fb[st & 1][ct], fa[st & 1][mt][pt], acc[cls][mt].t[ct][pt]);
-                if (st + 1 < NPAIR) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT, 0);
-            }
-            if (more) advance(qi);
-            {
-                const int d = (it & 1) ? -BUF : BUF;
-#pragma unroll
-                for (int dxi = 0; dxi < 3; ++dxi)
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) a16[dxi][pt] += d;
-                b16 += d;
-            }
-            if (++cc == nchunks) {
-                cc = 0;
-                int b, ty0, tx0;
-                tile_coords(ctile, b, ty0, tx0);
-                ctile += gridDim.x;
-                const int cstride = p.out_cstride;
-                float bias[1][16];
-                load_bias16_lds(lds_bias, 0, h, bias);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int py = c >> 1, px = c & 1;
-                    const int x = 2 * (tx0 + r) + px;
-                    auto pixoff = [&](int mt) -> int64_t {
-                        const int y = 2 * (ty0 + wave * MT + mt) + py;
-                        if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                        return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
-                    };
-                    f32x16 v[MT][1];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        acc[c][mt].to32(v[mt][0]);
-                        acc[c][mt].zero();
-                    }
-                    epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA_EPI_AHEAD, false, true>(p, v, bias, n0, lane, pixoff);
-                }
-            }
-        }
-        return;
-    }
     auto issue = [&](const Cur& q, int buf) {
 #pragma unroll
         for (int i = 0; i < KP + KW; ++i) issue_piece(q, buf, i);
@@ -1578,17 +1354,10 @@ int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st) {
     if (gx < 1) gx = 1;
     if (gx > ntiles) gx = ntiles;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-#ifdef FALNET_AB  // (experiment builds only: FALNET_UP2_M16=0 selects the 32x32x16 form; the product library does not carry it)
-    if (!falnet_up2_m16()) {
-        if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<f16_t, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<bf16_t, false>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
-        FALNET_RETURN_LAUNCH();
-    }
-#endif
     if (p.dtype == FALNET_F16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<f16_t, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<bf16_t, true>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_up2_dma_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles, GH, GW);
     FALNET_RETURN_LAUNCH();
 }
 

@@ -339,7 +339,7 @@ struct Wr8Item { int u, n, T, t, b, x0, y0; };  // rows [y0, y0+n) of strip x0 o
 template <typename T, int D, int ABL = 0, bool STAGGER = true, bool ILV = true, int SPB = 1>
 __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
     constexpr int NS = D + SPB;
-    static_assert(D >= 1 && D <= 4 && SPB >= 1 && SPB <= 2 && D >= SPB, "prefetch distance / steps per barrier");
+    static_assert(D >= 1 && D <= 4 && (SPB == 1 || SPB == 2 || SPB == 4) && D >= SPB, "prefetch distance / steps per barrier");
     constexpr int LDS_BYTES = NS * WR8_SLOT > WR8_RED ? NS * WR8_SLOT : WR8_RED;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1098,6 +1098,9 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
 #ifdef FALNET_WR_SPB1  // A/B build: one barrier per step (D = 2), the round-2 form
     if (p.dtype == FALNET_F16) WR_LAUNCH8(f16_t, 2, 0);
     else WR_LAUNCH8(bf16_t, 2, 0);
+#elif defined(FALNET_WR_SPB4)  // A/B build: FOUR steps (72 MFMAs per wave) per barrier over an eight-slot ring (144 KiB, every piece of the next four steps drained at the barrier)
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
 #else
     if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);

@@ -509,7 +509,7 @@ def conv_multi_call(calls, name="conv multi", bn=None, ksplit=1, s2d=False):
 
     def launch(_keep=keep):
         L.check(lib.falnet_conv2d_multi(arr, n, L.stream_ptr()), name)
-    sym = f"_Z22conv3x3_s2d_dma_kernelI{dn}Li2ELb1EEv13falnet_conv_tiiiii" if s2d else f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t"
+    sym = f"_Z22conv3x3_s2d_dma_kernelI{dn}Ev13falnet_conv_tiiiii" if s2d else f"_Z23conv_igemm_multi_kernelI{dn}Li{bn}EEv14falnet_conv4_t"
     return _timed(sym, sum(c.flops for c in calls), 0, launch, name)
 
 
