@@ -692,6 +692,309 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// wgrad3x3_rows16_kernel (round 5): the eight-wave row-streaming kernel on v_mfma_f32_16x16x32.
+//
+// profiles/r05_sq_counters.txt / r05_dma16.txt: the chip holds a higher clock on the 16x16x32 shape (the LDS-DMA convolutions gained 8-12 % from
+// nothing else), and with K = 32 ONE wave multiplies a whole 32-pixel strip row, so the strip no longer has to be split into two 16-pixel halves
+// whose accumulators are summed through LDS at the end:
+//   * wave = (c_t: 32-channel half of the 64 gout channels, a_q: 16-channel quarter of the 64 input channels); its output is 32 (cout) x 16 (cin)
+//     x 9 taps = 18 tiles of 16 x 16: 72 accumulator registers instead of 144, every slab element written by exactly one wave (no reduction);
+//   * a step still moves two image rows through the same LDS ring by the same LDS-DMA pieces; per row a wave reads two gout fragments (its two
+//     16-channel tiles x 32 pixels) and three input fragments (column offsets 0, 1, 2) -- ten transposed 8-B reads -- and issues 18 MFMAs
+//     (3 tap rows x 3 tap columns x 2 gout tiles; the gout fragments of the two previous rows stay in a register window as before);
+//   * operand = [16 channels x 32 pixels]: 16-lane group g reads pixels 8g .. 8g+7 (two ds_read_b64_tr_b16 of four pixel rows each), so a 32-lane
+//     half reads two blocks 8 pixels apart in the same columns: besides the 64-B half exchange on pixel bit 1 the 32-B quarters are exchanged on
+//     pixel bit 3 (source-side, as everything the DMA writes): conflict-free for every column offset and both reads (exhaustive check).
+template <typename T, int D, int SPB>
+__global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
+    constexpr int NS = D + SPB;
+    static_assert(D >= 1 && D <= 4 && (SPB == 1 || SPB == 2) && D >= SPB, "prefetch distance / steps per barrier");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * WR8_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(wr_lptr_t)lds;
+    const int nsplit = p.nsplit;
+    int tile, split;
+    {
+        const int wg = blockIdx.x;
+        if ((nsplit & 7) == 0) {  // the channel tiles of one pixel range share an XCD (blocks b and b + 8 do)
+            const int idx = wg >> 3;
+            split = (idx / ntiles) * 8 + (wg & 7);
+            tile = idx % ntiles;
+        } else {
+            tile = wg % ntiles;
+            split = wg / ntiles;
+        }
+    }
+    const int ci0 = (tile % ntci) * 64, co0 = (tile / ntci) * 64;
+    const int c_t = wave & 1, a_q = wave >> 1;   // MFMA role: 32 gout channels (two 16-channel tiles), 16 input channels
+    const int rsel = wave >> 2, pw = wave & 3;   // DMA role: row of the step's pair, 8-pixel piece
+    const int H = p.TH, TW = p.TW, gC = p.gC, IH = p.IH;
+    const int R = p.B * nstrips * H;
+    const int u0 = (int)((int64_t)R * split / nsplit), u1 = (int)((int64_t)R * (split + 1) / nsplit);
+
+    // ---- per-lane DMA geometry: lane = (pixel pl of an 8-pixel piece, 16-B position cpos of its 128-B line); the chunk it FETCHES is swizzled ----
+    const int pl = lane >> 3, cpos = lane & 7;
+    const int gch = cpos ^ ((((pl >> 1) & 1) << 2) | ((pw & 1) << 1));  // pixel 8 pw + pl of the LDS row: bit 1 -> 64-B halves, bit 3 -> 32-B quarters
+    const char* const zero_page = reinterpret_cast<const char*>(g_wr_zero);
+    const bool g_chok = co0 + 8 * gch < gC;
+    const int ch = ci0 + 8 * gch;
+    const bool x_chok = ch < p.cin_total;
+    const int c_first = p.src[0].C;
+    const bool second = p.nsrc > 1 && ch >= c_first;
+    const falnet_src_t& S = second ? p.src[1] : p.src[0];
+    const int l_hs = S.H != IH ? 1 : 0, l_ws = S.W != p.IW ? 1 : 0;
+    const int64_t l_sy = S.sy, l_sx = S.sx, l_sb = S.sb;
+    const T* const l_ptr = reinterpret_cast<const T*>(S.ptr) + (second ? ch - c_first : ch);
+
+    auto load_item = [&](Wr8Item& c, int u) {
+        c.u = u;
+        const int bs = u / H;
+        c.y0 = u - bs * H;
+        c.n = min((bs + 1) * H, u1) - u;
+        c.T = (c.n + 3) >> 1;
+        c.b = bs / nstrips;
+        c.x0 = (bs - c.b * nstrips) * WR_TW;
+        c.t = 0;
+    };
+    int nst = 0;
+    for (int u = u0; u < u1;) {
+        const int e = min((u / H + 1) * H, u1);
+        nst += (e - u + 3) >> 1;
+        u = e;
+    }
+    const char* gptr = zero_page;
+    const char* xptr = zero_page;
+    const char* x4ptr = zero_page;
+    unsigned g_inc = 0, x_inc = 0, x4_inc = 0;
+    auto item_pointers = [&](const Wr8Item& c) {
+        const int gx = c.x0 + 8 * pw + pl;
+        const bool g_ok = g_chok && gx < TW;
+        gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H + c.y0 + rsel) * TW + gx) * gC + co0 + 8 * gch) : zero_page;
+        g_inc = g_ok ? (unsigned)(2 * TW * gC * (int)sizeof(T)) : 0u;
+        const int i = c.y0 - 1 + rsel;
+        const int64_t rowoff = (int64_t)c.b * l_sb + (int64_t)(i >> l_hs) * l_sy;
+        const unsigned xi = (unsigned)((l_hs ? l_sy : 2 * l_sy) * (int)sizeof(T));
+        const int xa = c.x0 - 1 + 8 * pw + pl;
+        const bool x_ok = x_chok && xa >= 0 && xa < p.IW;
+        xptr = x_ok ? reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)(xa >> l_ws) * l_sx) : zero_page;
+        x_inc = x_ok ? xi : 0u;
+        const int xb = c.x0 - 1 + 32 + pl;  // (issued by the pw == 0 waves only: pixels 32 .. 39 of the LDS row have bit 3 clear, like their gch)
+        const bool x4_ok = x_chok && pl < 2 && xb < p.IW;
+        x4ptr = x4_ok ? reinterpret_cast<const char*>(l_ptr + rowoff + (int64_t)(xb >> l_ws) * l_sx) : zero_page;
+        x4_inc = x4_ok ? xi : 0u;
+    };
+    auto issue_piece = [&](const Wr8Item& c, int slot, int k) {  // k = 0 gout row, 1 input row, 2 the input row's two halo pixels
+        const unsigned base = lds_base + slot * WR8_SLOT;
+        if (k == 0) {
+            const bool gv = 2 * c.t + rsel < c.n;
+            wr_glds16(gv ? gptr : zero_page, base + rsel * WR_GROW + pw * 1024);
+            gptr += g_inc;
+            return;
+        }
+        const int i = c.y0 - 1 + 2 * c.t + rsel;
+        const bool xv = i >= 0 && i < IH;
+        if (k == 1) {
+            wr_glds16(xv ? xptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + pw * 1024);
+            xptr += x_inc;
+        } else if (pw == 0) {
+            wr_glds16(xv ? x4ptr : zero_page, base + 2 * WR_GROW + rsel * WR_XROW + 4 * 1024);
+            x4ptr += x4_inc;
+        }
+    };
+    auto issue = [&](const Wr8Item& c, int slot) {
+        issue_piece(c, slot, 0);
+        issue_piece(c, slot, 1);
+        issue_piece(c, slot, 2);
+    };
+
+    // ---- fragment read geometry: 16-lane group g16 reads pixels 8 g16 + q (+ 4 in the second read) + pshift of channel block cb16 ----
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int q = i16 >> 2, pc = i16 & 3;
+    auto frag_off = [&](int cb16, int pshift, int second_read) {
+        const int px = 8 * g16 + q + pshift + 4 * second_read;
+        const int chunk = 2 * cb16 + (pc >> 1);
+        const int sw = (((px >> 1) & 1) << 2) | (((px >> 3) & 1) << 1);
+        return px * 128 + ((chunk ^ sw) * 16) + (pc & 1) * 8;
+    };
+    int offA[2][2], offB[3][2];  // [gout tile cc][read], [column offset][read]
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) offA[cc][rd] = frag_off(2 * c_t + cc, 0, rd);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) offB[dx][rd] = 2 * WR_GROW + frag_off(a_q, dx, rd);
+    }
+    auto frag = [&](const char* base, const int (&off)[2]) -> s16x8 {
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base + off[0]));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_v4)(base + off[1]));
+        return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x4_t acc[3][3][2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) acc[dy][dx][cc] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    s16x8 w_a[2], w_b[2];  // gout fragments of the two previous rows (relative rows 2t-2, 2t-1), per 16-channel tile
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w_a[cc][j] = w_b[cc][j] = 0;
+    const bool a_live = ci0 + 16 * a_q < p.cin_total && co0 + 32 * c_t < gC;
+    const bool do_bias = p.bias_grad != nullptr && (tile % ntci) == 0 && a_q == 0;
+    float bsum[2] = {0.f, 0.f};
+
+    Wr8Item ci_, cc_;
+    if (nst > 0) {
+        load_item(ci_, u0);
+        cc_ = ci_;
+        item_pointers(ci_);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < nst) {
+                issue(ci_, d);
+                if (d + 1 < nst && ++ci_.t == ci_.T) {
+                    load_item(ci_, ci_.u + ci_.n);
+                    item_pointers(ci_);
+                }
+            }
+        }
+    }
+    int slot = 0, islot = D;
+    // stagger (as wgrad3x3_rows8_kernel): waves w and w + 4 share a SIMD; waves 4-7 run the MFMAs of step g - 1 right after barrier g and only then
+    // issue their DMA pieces and read the fragments of step g
+    const bool lag = (wave >> 2) == 1;
+    s16x8 n_a[2], n_b[2], xa[3], xb[3];
+    int m_t2 = 0, m_n = 0;
+    bool m_vx0 = false, m_vx1 = false, m_have = false;
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n_a[cc][j] = n_b[cc][j] = 0;
+    auto advance_issue = [&](int g) {
+        if (g + D + 1 < nst && ++ci_.t == ci_.T) {
+            load_item(ci_, ci_.u + ci_.n);
+            item_pointers(ci_);
+        }
+        islot = islot + 1 == NS ? 0 : islot + 1;
+    };
+    auto read_frags = [&](int g) {
+        const char* sb = lds + slot * WR8_SLOT;
+        m_t2 = 2 * cc_.t;
+        m_n = cc_.n;
+        const int i0 = cc_.y0 - 1 + m_t2;
+        m_vx0 = i0 >= 0 && i0 < IH;
+        m_vx1 = i0 + 1 >= 0 && i0 + 1 < IH;
+        m_have = true;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            n_a[cc] = frag(sb, offA[cc]);
+            n_b[cc] = frag(sb + WR_GROW, offA[cc]);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            xa[dx] = frag(sb, offB[dx]);
+            xb[dx] = frag(sb + WR_XROW, offB[dx]);
+        }
+        if (g + 1 < nst && ++cc_.t == cc_.T) load_item(cc_, cc_.u + cc_.n);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    };
+    for (int g = 0; g <= nst; ++g) {
+        const bool do_issue = g + D < nst;
+        if (g < nst) {
+            if (SPB == 1 || (g & (SPB - 1)) == 0) {
+                const int k = max(0, min(D - SPB, nst - g - SPB));
+                if (pw == 0) {
+                    if (k >= 2) wr_vmcnt<(D - SPB >= 2 ? 6 : 0)>();
+                    else if (k == 1) wr_vmcnt<(D - SPB >= 1 ? 3 : 0)>();
+                    else wr_vmcnt<0>();
+                } else {
+                    if (k >= 2) wr_vmcnt<(D - SPB >= 2 ? 4 : 0)>();
+                    else if (k == 1) wr_vmcnt<(D - SPB >= 1 ? 2 : 0)>();
+                    else wr_vmcnt<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (!lag) read_frags(g);
+        }
+        auto piece = [&](int kk) {
+            if (do_issue) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(ci_, islot, kk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        {
+            const int t2 = m_t2;
+            auto vr = [&](int r) { return m_have && (unsigned)r < (unsigned)m_n; };
+            auto mm = [&](int dy, const s16x8 (&A)[2], const s16x8 (&X)[3]) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) acc[dy][dx][cc] = H16<T>::mma16(A[cc], X[dx], acc[dy][dx][cc]);
+            };
+            if (a_live && m_vx0 && vr(t2)) mm(0, n_a, xa);      // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
+            piece(0);
+            if (a_live && m_vx0 && vr(t2 - 1)) mm(1, w_b, xa);
+            if (a_live && m_vx0 && vr(t2 - 2)) mm(2, w_a, xa);
+            piece(1);
+            if (a_live && m_vx1 && vr(t2 + 1)) mm(0, n_b, xb);  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
+            if (a_live && m_vx1 && vr(t2)) mm(1, n_a, xb);
+            piece(2);
+            if (a_live && m_vx1 && vr(t2 - 1)) mm(2, w_b, xb);
+            if (do_issue) advance_issue(g);
+            if (m_have) {
+                if (do_bias) {  // rows outside the item arrive as zeros
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[cc] += Mma16<T>::f32(n_a[cc][j]) + Mma16<T>::f32(n_b[cc][j]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    w_a[cc] = n_a[cc];
+                    w_b[cc] = n_b[cc];
+                }
+                m_have = false;
+            }
+        }
+        if (lag && g < nst) read_frags(g);
+    }
+
+    // ---- every (tap, cout, cin) element of the slab belongs to exactly one wave: tile (cc) of D[co 16 x ci 16], lane (ci = i16, rows 4 g16 + f) ----
+    if (do_bias) {  // lane (i16, g16) summed pixels 8 g16 .. 8 g16 + 7 of every row for channel co0 + 32 c_t + 16 cc + i16
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            float b = bsum[cc];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            const int co = co0 + 32 * c_t + 16 * cc + i16;
+            if (g16 == 0 && co < p.cout) atomicAdd(p.bias_grad + co, b);
+        }
+    }
+    const int ci = ci0 + 16 * a_q + i16;
+    if (ci < p.cin_total) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float* dst = p.partial + (((int64_t)split * 9 + dy * 3 + dx) * w_rows) * p.cin_total;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int co = co0 + 32 * c_t + 16 * cc + 4 * g16 + f;
+                        if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dy][dx][cc][f];
+                    }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Stride-2 form of the eight-wave kernel (encoder convs conv2..conv4, FAL_netB.py:103-107: 3x3, stride 2, pad 1):
 //   dW[co][ky][kx][ci] = sum over output pixels (i, j) of gout[i][j][co] * in[2 i + ky - 1][2 j + kx - 1][ci]
 // Same roles (16-pixel half x 32-channel sub-tiles, one workgroup per CU, accumulators summed through LDS), same ring of row slots
@@ -1094,6 +1397,11 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
         }
         FALNET_RETURN_LAUNCH();
     }
+#endif
+#ifdef FALNET_WR_M16  // A/B build: the 16x16x32 form (wgrad3x3_rows16_kernel)
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<f16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<bf16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    FALNET_RETURN_LAUNCH();
 #endif
 #ifdef FALNET_WR_SPB1  // A/B build: one barrier per step (D = 2), the round-2 form
     if (p.dtype == FALNET_F16) WR_LAUNCH8(f16_t, 2, 0);
