@@ -1398,20 +1398,21 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
         FALNET_RETURN_LAUNCH();
     }
 #endif
-#ifdef FALNET_WR_M16  // A/B build: the 16x16x32 form (wgrad3x3_rows16_kernel)
+#ifdef FALNET_AB  // (experiment builds only) FALNET_WR_FORM=8: the round-2..4 kernel on v_mfma_f32_32x32x16 (two 16-pixel wave groups, LDS reduction);
+    // FALNET_WR_FORM=84: the same with FOUR steps per barrier over an eight-slot ring (neutral on the step: profiles/r05_ab_rows8_spb4.txt)
+    if (form == 8 && falnet_ab_env("FALNET_WR_FORM")) {
+        if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        FALNET_RETURN_LAUNCH();
+    }
+    if (form == 84) {
+        if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        FALNET_RETURN_LAUNCH();
+    }
+#endif
+    // the product kernel: v_mfma_f32_16x16x32 (round 5: -7 % on the launches alone, -0.9 % on the step: profiles/r05_ab_rows16.txt)
     if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<f16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<bf16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    FALNET_RETURN_LAUNCH();
-#endif
-#ifdef FALNET_WR_SPB1  // A/B build: one barrier per step (D = 2), the round-2 form
-    if (p.dtype == FALNET_F16) WR_LAUNCH8(f16_t, 2, 0);
-    else WR_LAUNCH8(bf16_t, 2, 0);
-#elif defined(FALNET_WR_SPB4)  // A/B build: FOUR steps (72 MFMAs per wave) per barrier over an eight-slot ring (144 KiB, every piece of the next four steps drained at the barrier)
-    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 4>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-#else
-    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<f16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows8_kernel<bf16_t, 4, 0, true, true, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-#endif
     FALNET_RETURN_LAUNCH();
 }

@@ -614,7 +614,7 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
         if nsplit >= 8:
             nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
-        variant, sym = 7, f"_Z21wgrad3x3_rows8_kernelI{tn}Li4ELi0ELb1ELb1ELi2EEv14falnet_wgrad_tiiii"
+        variant, sym = 7, f"_Z22wgrad3x3_rows16_kernelI{tn}Li4ELi2EEv14falnet_wgrad_tiiii"
     elif dense:
         co2 = _wgrad_co2(dtype, dense, cin_pad, cout_pad)
         tiles = (cin_pad // 32) * (cout_pad // 32) // (2 if co2 else 1)
