@@ -54,13 +54,13 @@ for name, groups, cout, H, W, up in LAYERS:
         srcs_t.append((torch.randn(B, h, ww, ops.pad_c(g), device=DEV) * float(os.environ.get('BENCH_SCALE', '1'))).to(dtype))  # BENCH_SCALE=0: all-zero activations (clock / power probe)
     out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
     ops.AUTOTUNE = False
-    pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV) if os.environ.get('BENCH_POOL') else None  # BENCH_POOL=1: only the 2x2-pooled map is stored
+    pooled = torch.empty(B, H // 2, W // 2, pc.cout_pad, dtype=dtype, device=DEV) if os.environ.get('BENCH_POOL') else None  # BENCH_POOL=1: only the 2x2-pooled map is stored; 2: the full map AND the pooled one (the synthesised view's VGG pass)
     # BENCH_DGRAD=1: the data-gradient epilogue (residual addend + activation-gradient operand, no activation) instead of bias-free ELU
     dg = os.environ.get('BENCH_DGRAD') == '1' and pooled is None
     addend = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if dg else None
     actout = torch.randn(B, H, W, pc.cout_pad, device=DEV).to(dtype) if dg else None
     call = ops.conv_call(dtype, [ops.nhwc_src(t) for t in srcs_t], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B,
-                         H, W, None if pooled is not None else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled,
+                         H, W, None if (pooled is not None and os.environ.get('BENCH_POOL') != '2') else out, H, W, pc.cout_pad, pc.cout_pad, pool_out=pooled,
                          act=0 if dg else {'elu': L.ACT_ELU, 'relu': L.ACT_RELU, 'none': 0}[os.environ.get('BENCH_ACT', 'elu')], weight_up2=None if dg else pc.wu,
                          addend=addend, actout=actout, actout_kind=L.ACT_ELU if dg else L.ACT_NONE)
     flops = 2.0 * B * H * W * cout * cin * 9
