@@ -56,6 +56,30 @@ class EventTimer:
         return agg
 
 
+def _family_matcher(symbols):
+    """row-name predicate for rocprofv3 CSVs: the row is one of `symbols` (mangled, as the library reports them) -- or the demangled spelling of
+    one of them, which rocprofv3 prints for some template instantiations ("void conv3x3_dma16_kernel<bool _Accum, bool, E, 16, 8, false>(...)"):
+    same template name and the same integer parameters in order."""
+    import re
+    symbols = [symbols] if isinstance(symbols, str) else list(symbols)
+    keys = []
+    for s in symbols:
+        m = re.match(r"_Z\d+([A-Za-z_0-9]+?)I", s)
+        keys.append((m.group(1) if m else s, re.findall(r"Li(\d+)E", s)))
+
+    def match(name):
+        head = name.split("(")[0]
+        if any(head[:100] == s[:100] for s in symbols):
+            return True
+        for base, ints in keys:
+            if base + "<" in name:
+                got = re.findall(r"[<,] ?(\d+)(?=[,>])", name.split(">(")[0] + ">")
+                if got == ints:
+                    return True
+        return False
+    return match
+
+
 def hbm_traffic_from_profiles(kernel_symbol):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_hbm_traffic.json, made by
     tools/profile_round.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction).
@@ -66,11 +90,17 @@ def hbm_traffic_from_profiles(kernel_symbol):
         return None
     table = json.load(open(files[-1]))
     meta = table.pop("_meta", {})
+    match = _family_matcher(kernel_symbol)
+    fetch = write = 0.0
+    n = 0
     for name, v in table.items():
-        if name[:100] == kernel_symbol[:100]:
-            return {"bytes_per_launch": v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"],
-                    "fetch_bytes_corrected": v["fetch_bytes_per_launch_corrected"], "write_bytes": v["write_bytes_per_launch"],
-                    "source": os.path.basename(files[-1]), "collected_at_commit": meta.get("commit", "unknown")}
+        if match(name):
+            fetch += v["fetch_bytes_per_launch_corrected"] * v["launches"]
+            write += v["write_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    if n:
+        return {"bytes_per_launch": (fetch + write) / n, "fetch_bytes_corrected": fetch / n, "write_bytes": write / n,
+                "source": os.path.basename(files[-1]), "collected_at_commit": meta.get("commit", "unknown")}
     return None
 
 
@@ -107,8 +137,9 @@ def hbm_traffic_live(kernel_symbol, args):
             if r.returncode != 0 or not files:
                 return None
             tot, n = 0.0, 0
+            match = _family_matcher(kernel_symbol)
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == counter and row["Kernel_Name"].split("(")[0][:100] == kernel_symbol[:100]:
+                if row["Counter_Name"] == counter and match(row["Kernel_Name"]):
                     tot += float(row["Counter_Value"])
                     n += 1
             if n == 0:
@@ -489,8 +520,17 @@ def main():
                     f.write(f"{us:8.1f} us  #{i:3d}  {flops / 1e9:8.2f} GFLOP {flops / (us * 1e-6) / 1e12 if flops else 0:7.1f} TF  "
                             f"{nbytes / (us * 1e-6) / 1e9 if nbytes else 0:7.0f} GB/s  {name:44s} {tag}\n")
         total_ms = sum(a["ms"] for a in agg.values()) / 3
-        dom_tag = max((t for t in agg if agg[t]["flops"] > 0), key=lambda t: agg[t]["ms"])
-        d = agg[dom_tag]
+        # dominant kernel FAMILY: the instantiations of one kernel template that differ only in boolean flags (fused pool / planar output / ...) are
+        # one family -- same tile, same loop; its members are listed in `roofline.members`
+        import re
+        fam = {}
+        for t, a in agg.items():
+            k = re.sub(r"Lb[01]E", "LbXE", t)
+            f = fam.setdefault(k, {"ms": 0.0, "flops": 0.0, "launches": 0, "members": []})
+            f["ms"] += a["ms"]; f["flops"] += a["flops"]; f["launches"] += a["launches"]; f["members"].append(t)
+        dom_fam = max((k for k in fam if fam[k]["flops"] > 0), key=lambda k: fam[k]["ms"])
+        d = fam[dom_fam]
+        dom_tag = max(d["members"], key=lambda t: agg[t]["ms"])  # (the member with the most time: the symbol the live PMC passes are read for)
         peak = 157.3 if dtype == torch.float32 else 2500.0  # exact-f32 MFMA / dense bf16 = f16 MFMA (MI355X_MICROARCH.md)
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         mfma_ms = sum(a["ms"] for a in agg.values() if a["flops"] > 0) / 3
@@ -498,8 +538,8 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             # live PMC child passes only from a single-process run (world > 1: the other ranks would sit in destroy_process_group)
-            "traffic": (None if (args.no_live_traffic or world > 1) else hbm_traffic_live(dom_tag, args)) or hbm_traffic_from_profiles(dom_tag),
-            "kernel": dom_tag, "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+            "traffic": (None if (args.no_live_traffic or world > 1) else hbm_traffic_live(d["members"], args)) or hbm_traffic_from_profiles(d["members"]),
+            "kernel": dom_fam, "members": sorted(d["members"]), "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
             "kernel_ms_per_step": d["ms"] / 3, "all_kernels_ms_per_step": total_ms,
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,
                                  "algorithmic_gflop_per_step": mfma_fl / 1e9},
