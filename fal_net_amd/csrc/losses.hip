@@ -25,7 +25,7 @@ __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f 
 //                   The scratch (partials + ticket) is per STREAM: `det` = 1 + the slot the launcher assigned to its stream (red_det_slot:
 //                   up to RED_SLOTS streams per process), so reductions on different streams -- a loss on the auxiliary stream, two models
 //                   in one process -- never share a ticket; launches of one stream are ordered by the stream.
-#define RED_SLOTS 16
+#define RED_SLOTS 72  // torch hands out streams from pools of 32 per priority and device: 2 x 32 + the default stream + spares
 __device__ float g_red_partial[RED_SLOTS][RED_BLOCKS];
 __device__ unsigned g_red_ticket[RED_SLOTS] = {};
 __device__ __forceinline__ void red_finish(float* out, float v, int det) {
@@ -47,24 +47,29 @@ __device__ __forceinline__ void red_finish(float* out, float v, int det) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// 0 outside deterministic mode, else 1 + the scratch slot of `stream` (assigned on first use; -1: more than RED_SLOTS streams)
+// 0 outside deterministic mode, else 1 + the scratch slot of `stream`: assigned on first use; when every slot has an owner the LEAST RECENTLY
+// USED one is handed on (a long-lived process that rotates through torch's stream pools must not start failing; the scratch and
+// ticket are __device__ globals, i.e. one set per device already, and a slot is only shared by two streams of one device that are BOTH in a
+// reduction at the same time after more than RED_SLOTS distinct streams have carried one -- far beyond the 65 handles torch can hand out).
 static int red_det_slot(void* stream) {
     if (!falnet_deterministic()) return 0;
     static void* owner[RED_SLOTS] = {};
-    static bool used[RED_SLOTS] = {};
+    static unsigned long long last[RED_SLOTS] = {};
+    static unsigned long long tick = 0;
     static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     pthread_mutex_lock(&mu);
-    int slot = -1;
-    for (int i = 0; i < RED_SLOTS && slot < 0; ++i)
-        if (used[i] && owner[i] == stream) slot = i;
-    for (int i = 0; i < RED_SLOTS && slot < 0; ++i)
-        if (!used[i]) {
-            used[i] = true;
-            owner[i] = stream;
-            slot = i;
-        }
+    int slot = -1, lru = 0;
+    for (int i = 0; i < RED_SLOTS; ++i) {
+        if (last[i] && owner[i] == stream) slot = i;
+        if (last[i] < last[lru]) lru = i;  // (never-used slots have last = 0: taken first)
+    }
+    if (slot < 0) {
+        slot = lru;
+        owner[slot] = stream;
+    }
+    last[slot] = ++tick;
     pthread_mutex_unlock(&mu);
-    return slot < 0 ? -1 : slot + 1;
+    return slot + 1;
 }
 #define FALNET_DET_SLOT(var, stream)                                                                                      \
     const int var = red_det_slot(stream);                                                                                 \
