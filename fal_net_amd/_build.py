@@ -15,6 +15,10 @@ LIB = os.path.join(HERE, "libfalnet_hip.so")
 SOURCES = ["api.cpp", "replay.cpp", "med_head.hip", "med_head2.hip", "losses.hip", "elementwise.hip", "data.hip", "wgrad_rows.hip", "conv_dma.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# Per-file flags.  The MED head kernels are f32 VALU work per pixel and plane: the SLP vectoriser pairs independent scalar
+# f32 operations into v_pk_* with extra moves to form the pairs, which is slower here (forward 88 -> 79 us, backward 157 -> 153 us
+# at 8x192x640x49, same box: profiles/r05_ab_head_noslp.txt).
+FILE_FLAGS = {"med_head.hip": ["-fno-slp-vectorize"], "med_head2.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out, deps):
@@ -24,7 +28,7 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_ab(tag="ab", defines=(), verbose=True):
+def build_ab(tag="ab", defines=(), verbose=True, raw=()):
     """Experiment build: the same sources with -DFALNET_AB (the FALNET_* kernel switches of include/falnet_hip.h are honoured) plus
     extra -D flags -> fal_net_amd/libfalnet_hip_<tag>.so, selected at run time with FALNET_LIB=<path>.  Never the product library."""
     obj_dir = os.path.join(CSRC, "_obj_" + tag)
@@ -33,7 +37,7 @@ def build_ab(tag="ab", defines=(), verbose=True):
     lib = os.path.join(HERE, f"libfalnet_hip_{tag}.so")
 
     def run(src):
-        cmd = [HIPCC] + flags + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", os.path.join(obj_dir, src + ".o")]
+        cmd = [HIPCC] + flags + FILE_FLAGS.get(src, []) + list(raw) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", os.path.join(obj_dir, src + ".o")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -51,7 +55,7 @@ def build(force=False, verbose=True):
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src + ".o")
         if force or _stale(obj, [path] + headers):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
             jobs.append(cmd)
 
     def run(cmd):
@@ -68,10 +72,10 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    if "--ab" in sys.argv:  # python -m fal_net_amd._build --ab [tag] [-DNAME[=V] ...]
+    if "--ab" in sys.argv:  # python -m fal_net_amd._build --ab [tag] [-DNAME[=V] ...] [-f<compiler flag> ...]
         rest = [a for a in sys.argv[sys.argv.index("--ab") + 1:]]
-        tag = next((a for a in rest if not a.startswith("-D")), "ab")
-        print(build_ab(tag, [a[2:] for a in rest if a.startswith("-D")]))
+        tag = next((a for a in rest if not a.startswith("-")), "ab")
+        print(build_ab(tag, [a[2:] for a in rest if a.startswith("-D")], raw=[a for a in rest if a.startswith("-") and not a.startswith("-D")]))
     else:
         build(force="--force" in sys.argv)
         print(LIB)
