@@ -694,38 +694,72 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
         const int gseg = segpos ^ (((l4 >> 2) & 1) << 1);            // (row >> 2) & 1: pieces start at multiples of 16 rows
         w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
     }
-    int64_t a_off[KP];
+    // ---- patch piece geometry.  A lane's patch pixel (pr, pc) is the same in every tile: its element offset is (tile origin, wave-uniform) +
+    // (lane constant per source), and only the in-image test depends on the tile.  Tiles advance by gridDim.x: the step is decomposed ONCE into
+    // (images, tile rows, tile columns) and the cursors carry (b, ty, tx) forward with two compare-and-wrap steps -- no division, no 64-bit
+    // multiply per tile (in-kernel stamps, 64 -> 64 channels at 128 x 256: 2 100 of a tile's 22 700 cycles went into re-deriving these). ----
     const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
-    int64_t sbat[2] = {0, 0};
-    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
-        const int tix = tile % tiles_x;
+    struct TPos { int b, ty, tx; };
+    TPos step_;
+    {
+        const int g = (int)gridDim.x;
+        step_.tx = g % tiles_x;
+        const int q = g / tiles_x;
+        step_.ty = q % tiles_y;
+        step_.b = q / tiles_y;
+    }
+    auto pos_of = [&](int tile) {
+        TPos t;
+        t.tx = tile % tiles_x;
         const int q = tile / tiles_x;
-        ty0 = (q % tiles_y) * TH;
-        tx0 = tix * 32;
-        b = q / tiles_y;
+        t.ty = q % tiles_y;
+        t.b = q / tiles_y;
+        return t;
     };
-    auto tile_offsets = [&](int tile, int s2) {
-        int b, ty0, tx0;
-        tile_coords(tile, b, ty0, tx0);
+    auto pos_next = [&](TPos& t) {
+        t.tx += step_.tx;
+        if (t.tx >= tiles_x) { t.tx -= tiles_x; ++t.ty; }
+        t.ty += step_.ty;
+        if (t.ty >= tiles_y) { t.ty -= tiles_y; ++t.b; }
+        t.b += step_.b;
+    };
+    int pr_[KP], pc_[KP], a_lc[2][KP];  // patch row / column of piece k's pixel; its offset inside source s2 relative to the tile origin
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int pix = 16 * (wave + NWAVES * k) + l4;
+        const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+        pr_[k] = pix < NPIX ? pr : -(1 << 20);  // (a piece beyond the patch never passes the in-image test)
+        pc_[k] = pc;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[(nsrc > 1) ? 1 : 0];
+            const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
+            a_lc[s2][k] = ((pr - 1) >> hs) * (int)S.sy + ((pc - 1) >> ws) * (int)S.sx + (segpos ^ (((pc >> 2) & 1) << 1)) * 8;
+        }
+    }
+    int a_off[KP];      // element offset of piece k inside the sample (valid when bit k of a_ok is set; the zero page otherwise)
+    unsigned a_ok = 0;
+    const T* a_base = sptr[0];  // source pointer + image offset + tile origin of the issue cursor
+    auto tile_offsets = [&](const TPos& t, int s2) {
         const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
-        sbat[s2] = (int64_t)b * S.sb;
         const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
+        const int ty0 = t.ty * TH, tx0 = t.tx * 32;
+        a_base = sptr[s2] + ((int64_t)t.b * S.sb + (int64_t)((ty0 >> hs) * (int)S.sy + (tx0 >> ws) * (int)S.sx));
+        a_ok = 0;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int pix = 16 * (wave + NWAVES * k) + l4;
-            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
-            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
-            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
-            a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ (((pc >> 2) & 1) << 1)) * 8)
-                          : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+            const int vy = ty0 - 1 + pr_[k], vx = tx0 - 1 + pc_[k];
+            a_ok |= (vy >= 0 && vy < IH && vx >= 0 && vx < IW) ? 1u << k : 0u;
+            a_off[k] = a_lc[s2][k];
         }
     };
-    struct Cur { int tile, c, s, c0, kofs; };
+    struct Cur { int tile, c, s, c0, kofs; TPos t; };
     auto advance = [&](Cur& q) {
         if (++q.c == nchunks) {
             q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
             q.tile += gridDim.x;
-            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            pos_next(q.t);
+            if (q.tile < ntiles) tile_offsets(q.t, 0);
             return;
         }
         q.c0 += KCV;
@@ -733,15 +767,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
         if (q.s == 0 && q.c0 >= C0) {
             q.s = 1;
             q.c0 = 0;
-            tile_offsets(q.tile, 1);
+            tile_offsets(q.t, 1);
         }
     };
     auto issue_piece = [&](const Cur& q, int buf, int i) {
         const unsigned dst0 = lds_base + buf * BUF;
         if (i < KP) {
             const int id = wave + NWAVES * i;
-            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
-            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+            const T* src = ((a_ok >> i) & 1) ? a_base + q.c0 + a_off[i] : zero_t;
+            if (id < A_PIECES) cd_glds16(src, dst0 + id * 1024);
         } else {
             const int wid = wave + NWAVES * (i - KP);
             if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
@@ -765,17 +799,44 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt].zero();
-    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0, pos_of((int)blockIdx.x)};
+    TPos ct = qi.t;  // the compute cursor's tile
     if (total > 0) {
-        tile_offsets(qi.tile, 0);
+        tile_offsets(qi.t, 0);
 #pragma unroll
         for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
         advance(qi);
     }
     int ctile = blockIdx.x, cc = 0;
+#ifdef FALNET_CD_STAMPS  // profiling build (tools/cd_stamps.py): s_memtime at the phase boundaries, every wave of workgroup (0, 0) -> p.splitk_ws
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
+    int stamp_i = 0;
+#define CD16_STAMP()                                                                                 \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        unsigned long long t_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (stamp_out && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && stamp_i < 256) stamp_out[wave * 256 + stamp_i] = t_; \
+        ++stamp_i;                                                                                   \
+    } while (0)
+#else
+#define CD16_STAMP() do {} while (0)
+#endif
+#if defined(FALNET_CD_STAMPS) && FALNET_CD_STAMPS == 2  // second stamp set: inside the tile end (advance / slice 0 / slice 1)
+#define CD16_A() do {} while (0)
+#define CD16_B() CD16_STAMP()
+#else
+#define CD16_A() CD16_STAMP()
+#define CD16_B() do {} while (0)
+#endif
     for (int it = 0; it < total; ++it) {
+        CD16_STAMP();  // 0: loop top
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        CD16_A();  // 1: own DMA landed (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
+        CD16_STAMP();  // 2 (B: 1): barrier passed
+        CD16_A();  // 3
         const bool more = it + 1 < total;
         int bo = (it & 1) * BUF;
         asm volatile("" : "+s"(bo));
@@ -837,19 +898,23 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
             if constexpr (MT == 2) __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
         }
+        CD16_STAMP();  // 4 (B: 2): MFMAs issued
         if (more) advance(qi);
+        CD16_B();  // B 3: issue cursor advanced
         if (++cc == nchunks) {
             cc = 0;
-            int b, ty0, tx0;
-            tile_coords(ctile, b, ty0, tx0);
+            const int b = ct.b, ty0 = ct.ty * TH, tx0 = ct.tx * 32;
+            pos_next(ct);
             ctile += gridDim.x;
             const int cstride = p.out_cstride;
             const int x = tx0 + r;
+            // (wave-uniform 64-bit origin of the tile + a 32-bit lane part: no 64-bit vector multiply per slab)
+            const int64_t obase = PLANAR ? ((int64_t)b * p.Cout * p.OH + ty0) * p.OW + tx0 : (((int64_t)b * p.OH + ty0) * p.OW + tx0) * cstride;
             auto pixoff = [&](int mt) -> int64_t {
                 const int y = ty0 + wave * MT + mt;
                 if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                if constexpr (PLANAR) return ((int64_t)b * p.Cout * p.OH + y) * p.OW + x;  // planar f32 [B][Cout][OH][OW]: offset of channel 0
-                else return (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                if constexpr (PLANAR) return obase + ((wave * MT + mt) * p.OW + r);  // planar f32 [B][Cout][OH][OW]: offset of channel 0
+                else return obase + ((wave * MT + mt) * p.OW + r) * cstride;
             };
             auto pooloff = [&](int mt) -> int64_t {
                 const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
@@ -867,9 +932,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
                 }
                 if constexpr (POOL) epilogue_direct<T, MT, 1, decltype(pixoff), decltype(pooloff), -1, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff, pooloff);
                 else epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, (PLANAR ? -1 : FALNET_DMA16_EPI_AHEAD), false, !PLANAR, PLANAR>(p, v, bias, n0 + 32 * nt, lane, pixoff);
+                if (nt == 0) CD16_B();  // B 4: slice 0 done
             }
+        } else {
+            CD16_B();
         }
+        CD16_STAMP();  // 5: (epilogue) done
     }
+#undef CD16_STAMP
+#undef CD16_A
+#undef CD16_B
 }
 
 int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th) {

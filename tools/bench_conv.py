@@ -9,7 +9,7 @@ from fal_net_amd import _lib as L, ops
 
 DEV = "cuda"
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
-B = 8
+B = int(os.environ.get("BENCH_B", "8"))
 LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("conv0_1 32->32 @256x512", [32], 32, 256, 512, None),
     ("deconv1 64->64 @256x512 (up)", [64], 64, 256, 512, (128, 256)),

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from fal_net_amd import _lib as L, ops
 ops.AUTOTUNE = False
-DEV, dtype, B = "cuda", torch.bfloat16, 8
+DEV, dtype, B = "cuda", torch.bfloat16, int(os.environ.get("BENCH_B", "8"))
 cin, cout, H, W = (int(a) for a in sys.argv[1:5])
 w = torch.nn.Parameter(torch.randn(cout, cin, 3, 3, device=DEV) * 0.05)
 pc = ops.PackedConv("t", w, None, [cin], 1)
@@ -16,7 +16,7 @@ x = torch.randn(B, H, W, ops.pad_c(cin), device=DEV).to(dtype)
 out = torch.empty(B, H, W, pc.cout_pad, dtype=dtype, device=DEV)
 call = ops.conv_call(dtype, [ops.nhwc_src(x)], H, W, pc.wf, pc.cin_pad, ops.fwd_taps(3), 9, pc.cout_pad, 1, B, H, W, out, H, W, pc.cout_pad,
                      pc.cout_pad, act=L.ACT_ELU)
-call.desc.variant = 13
+call.desc.variant = int(os.environ.get("CD_VARIANT", "13"))
 stamps = torch.zeros(8 * 256, dtype=torch.int64, device=DEV)
 call.desc.splitk_ws = stamps.data_ptr()
 for _ in range(5):
