@@ -99,38 +99,71 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         const int gseg = segpos ^ ((lane >> 4) & 3);                 // (row >> 2) & 3 = (l4 >> 2) & 3: pieces start at multiples of 16
         w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * p.w_taps + (flip ? 8 - tap : tap)) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
     }
-    int64_t a_off[KP];  // of the issue cursor's (tile, source), from the sample's base: recomputed when either changes (twice per tile at most)
+    // Patch piece geometry (as conv3x3_dma16_kernel): a lane's patch pixel is the same in every tile -- element offset = (tile origin, wave-uniform)
+    // + (lane constant per source) -- and the cursors carry (b, ty, tx) forward by the decomposed grid step: no division and no 64-bit vector
+    // multiply per tile.
     const T* sptr[2] = {reinterpret_cast<const T*>(p.src[0].ptr), reinterpret_cast<const T*>(nsrc > 1 ? p.src[1].ptr : p.src[0].ptr)};
-    int64_t sbat[2] = {0, 0};  // sample offset of the issue cursor's tile, per source
-    auto tile_coords = [&](int tile, int& b, int& ty0, int& tx0) {
-        const int tix = tile % tiles_x;
+    struct TPos { int b, ty, tx; };
+    TPos step_;
+    {
+        const int g = (int)gridDim.x;
+        step_.tx = g % tiles_x;
+        const int q = g / tiles_x;
+        step_.ty = q % tiles_y;
+        step_.b = q / tiles_y;
+    }
+    auto pos_of = [&](int tile) {
+        TPos t;
+        t.tx = tile % tiles_x;
         const int q = tile / tiles_x;
-        ty0 = (q % tiles_y) * TH;
-        tx0 = tix * 32;
-        b = q / tiles_y;
+        t.ty = q % tiles_y;
+        t.b = q / tiles_y;
+        return t;
     };
-    auto tile_offsets = [&](int tile, int s2) {  // patch offsets of the issue cursor's (tile, source)
-        int b, ty0, tx0;
-        tile_coords(tile, b, ty0, tx0);
+    auto pos_next = [&](TPos& t) {
+        t.tx += step_.tx;
+        if (t.tx >= tiles_x) { t.tx -= tiles_x; ++t.ty; }
+        t.ty += step_.ty;
+        if (t.ty >= tiles_y) { t.ty -= tiles_y; ++t.b; }
+        t.b += step_.b;
+    };
+    int pr_[KP], pc_[KP], a_lc[2][KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int pix = 16 * (wave + NWAVES * k) + l4;
+        const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+        pr_[k] = pix < NPIX ? pr : -(1 << 20);
+        pc_[k] = pc;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[(nsrc > 1) ? 1 : 0];
+            const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+            a_lc[s2][k] = ((pr - 1) >> hs) * (int)S.sy + ((pc - 1) >> ws) * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8;
+        }
+    }
+    int a_off[KP];      // element offset of piece k from a_base (valid when bit k of a_ok is set; the zero page otherwise)
+    unsigned a_ok = 0;
+    const T* a_base = sptr[0];  // source pointer + image offset + tile origin of the issue cursor
+    auto tile_offsets = [&](const TPos& t, int s2) {  // patch offsets of the issue cursor's (tile, source)
         const falnet_src_t& S = s2 == 0 ? p.src[0] : p.src[1];
-        sbat[s2] = (int64_t)b * S.sb;
-        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;  // exact 2x nearest upsampling (dispatcher checks)
+        const int hs = S.H != IH ? 1 : 0, ws = S.W != IW ? 1 : 0;
+        const int ty0 = t.ty * TH, tx0 = t.tx * 32;
+        a_base = sptr[s2] + ((int64_t)t.b * S.sb + (int64_t)((ty0 >> hs) * (int)S.sy + (tx0 >> ws) * (int)S.sx));
+        a_ok = 0;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int pix = 16 * (wave + NWAVES * k) + l4;
-            const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
-            const int vy = ty0 - 1 + pr, vx = tx0 - 1 + pc;
-            const bool ok = pix < NPIX && vy >= 0 && vy < IH && vx >= 0 && vx < IW;
-            a_off[k] = ok ? (int64_t)((vy >> hs) * (int)S.sy + (vx >> ws) * (int)S.sx + (segpos ^ ((pix >> 2) & 3)) * 8)
-                          : (int64_t)(zero_t - (reinterpret_cast<const T*>(S.ptr) + sbat[s2]));
+            const int vy = ty0 - 1 + pr_[k], vx = tx0 - 1 + pc_[k];
+            a_ok |= (vy >= 0 && vy < IH && vx >= 0 && vx < IW) ? 1u << k : 0u;
+            a_off[k] = a_lc[s2][k];
         }
     };
-    struct Cur { int tile, c, s, c0, kofs; };      // issue cursor: tile, chunk, source, channel offset, weight-row offset
+    struct Cur { int tile, c, s, c0, kofs; TPos t; };  // issue cursor: tile, chunk, source, channel offset, weight-row offset, tile position
     auto advance = [&](Cur& q) {
         if (++q.c == nchunks) {
             q.c = 0; q.s = 0; q.c0 = 0; q.kofs = 0;
             q.tile += gridDim.x;
-            if (q.tile < ntiles) tile_offsets(q.tile, 0);
+            pos_next(q.t);
+            if (q.tile < ntiles) tile_offsets(q.t, 0);
             return;
         }
         q.c0 += KCV;
@@ -138,7 +171,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         if (q.s == 0 && q.c0 >= C0) {
             q.s = 1;
             q.c0 = 0;
-            tile_offsets(q.tile, 1);
+            tile_offsets(q.t, 1);
         }
     };
     // one piece of the issue cursor's chunk (i = 0 .. KP + KW - 1: patch pieces, then weight pieces); the pieces of chunk it + 1 are
@@ -148,22 +181,22 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         const unsigned dst0 = lds_base + buf * BUF;
         if (i < KP) {
             const int id = wave + NWAVES * i;
-            const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
-            if (id < A_PIECES) cd_glds16(sbase + a_off[i], dst0 + id * 1024);
+            const T* src = ((a_ok >> i) & 1) ? a_base + q.c0 + a_off[i] : zero_t;
+            if (id < A_PIECES) cd_glds16(src, dst0 + id * 1024);
         } else {
             const int wid = wave + NWAVES * (i - KP);
             if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
         }
     };
     auto issue = [&](const Cur& q, int buf) {
-        const T* sbase = (q.s == 0 ? sptr[0] + sbat[0] : sptr[1] + sbat[1]) + q.c0;
         const T* wbase = wptr + q.kofs;
         const unsigned dst0 = lds_base + buf * BUF;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const int id = wave + NWAVES * k;
             if (id < A_PIECES) {  // wave-uniform
-                cd_glds16(sbase + a_off[k], dst0 + id * 1024);
+                const T* src = ((a_ok >> k) & 1) ? a_base + q.c0 + a_off[k] : zero_t;
+                cd_glds16(src, dst0 + id * 1024);
             }
         }
 #pragma unroll
@@ -194,9 +227,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[nt][mt][0][j] = 0.f;
-    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0};
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0, pos_of((int)blockIdx.x)};
+    TPos ct = qi.t;  // the compute cursor's tile
     if (total > 0) {
-        tile_offsets(qi.tile, 0);
+        tile_offsets(qi.t, 0);
         issue(qi, 0);
         advance(qi);
     }
@@ -300,16 +334,19 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         CD_STAMP();  // 4: MFMAs issued
         if (++cc == nchunks) {  // tile finished: epilogue straight from the accumulators, then the next tile starts from zero
             cc = 0;
-            int b, ty0, tx0;
-            tile_coords(ctile, b, ty0, tx0);
+            const int b = ct.b, ty0 = ct.ty * TH, tx0 = ct.tx * 32;
+            pos_next(ct);
             ctile += gridDim.x;
             const int cstride = p.out_cstride;
             const int x = tx0 + r;
             const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
+            // (wave-uniform 64-bit origin of the tile + a 32-bit lane part: no 64-bit vector multiply per slab)
+            const int64_t obase = planar_out ? ((int64_t)b * p.Cout * p.OH + ty0) * p.OW + tx0 : (((int64_t)b * p.OH + ty0) * p.OW + tx0) * cstride;
+            const int lstride = planar_out ? 1 : cstride;
             auto pixoff = [&](int mt) -> int64_t {
                 const int y = ty0 + wave * MT + mt;
                 if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
-                return planar_out ? ((int64_t)b * p.Cout * p.OH + y) * p.OW + x : (((int64_t)b * p.OH + y) * p.OW + x) * cstride;
+                return obase + ((wave * MT + mt) * p.OW + r) * lstride;
             };
             auto pooloff = [&](int mt) -> int64_t {
                 const int py = (ty0 + wave * MT + mt) >> 1, px = x >> 1, PH = p.OH >> 1, PW = p.OW >> 1;
