@@ -154,6 +154,33 @@ def hbm_traffic_live(kernel_symbol, args):
             "source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this bench run (FETCH_SIZE x2, gfx950)"}
 
 
+def sustained_mfma(dtype, dev):
+    """What the board sustains on the matrix pipe, measured here: falnet_mfma_probe (register-resident v_mfma_f32_16x16x32 loop, two waves per SIMD on
+    every CU, no LDS / memory traffic) after ~0.25 s of back-to-back launches, on random operands (real switching activity: the board's 1 400 W cap
+    sets the clock) and on zeros (the clock-bound rate).  Context for `roofline.frac`, whose `peak` stays the guide's dense figure."""
+    from fal_net_amd import _lib as L
+    dt = dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+    out = torch.zeros(4, device=dev)
+    iters = 1500
+    flops = 2048 * 4 * iters * 16 * 16384.0
+    res = {}
+    for name, scale in (("random", 1.0), ("zeros", 0.0)):
+        ab = (torch.randn(64 * 8 * 64 * 8, device=dev) * scale).to(dt)
+        def launch():
+            L.check(L.lib().falnet_mfma_probe(L.ptr(ab), L.ptr(out), iters, L.dtype_code(dt), L.stream_ptr()), "mfma_probe")
+        for _ in range(90):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = round(flops * 40 / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    return {"tflops_random_operands": res["random"], "tflops_zero_operands": res["zeros"], "unit": "TFLOP/s",
+            "how": "falnet_mfma_probe: register-resident v_mfma_f32_16x16x32 loop, 2 waves/SIMD on all CUs, 40 launches timed behind 90 (0.25 s) of the same"}
+
+
 def host_cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -544,6 +571,10 @@ def main():
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,
                                  "algorithmic_gflop_per_step": mfma_fl / 1e9},
         }
+        if dtype != torch.float32:
+            sm = sustained_mfma(dtype, dev)
+            result["roofline"]["sustained_mfma"] = sm
+            result["roofline"]["frac_of_sustained"] = round(ach / sm["tflops_random_operands"], 4)
         heads = {t: a for t, a in agg.items() if t.startswith("falnet_med_head")}
         if heads:
             hb = sum(a["bytes"] for a in heads.values()) / 3

@@ -167,6 +167,7 @@ SIGNATURES = {
     "falnet_fill_f32": [_P, _L, _F, _P],
     "falnet_copy_bytes": [_P, _P, _L, _P],
     "falnet_spin": [_I, _P],
+    "falnet_mfma_probe": [_P, _P, _I, _I, _P],
 }
 _RESTYPES = {"falnet_last_error": C.c_char_p, "falnet_wgrad_workspace_bytes": C.c_int64}
 
@@ -174,7 +175,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 500
+EXPECTED_VERSION = 501
 
 
 def lib():

@@ -540,3 +540,46 @@ extern "C" int falnet_spin(int microseconds, void* stream) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
     FALNET_RETURN_LAUNCH();
 }
+
+// ---- what the board sustains on the matrix pipe (include/falnet_hip.h: falnet_mfma_probe) -------------------------------------------------
+// A register-resident v_mfma_f32_16x16x32 loop: every wave keeps four A and four B fragments (16 x 32 values of `ab` each, the caller's data:
+// random for the ceiling under real switching activity, zeros for the clock-bound one) and sixteen independent accumulators, and issues
+// `iters` x 16 MFMAs back to back -- no LDS, no memory traffic inside the loop.  bench.py times it after ~0.2 s of back-to-back launches (the
+// power controller's settling time) and reports the rate beside the dense peak: the dominant convolution's 128 / 256-channel launches run at the
+// board's 1 400 W cap (profiles/r05_power_probe.txt), where no kernel reaches the 2.5 PFLOP/s of the data sheet.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(const T* __restrict__ ab, float* __restrict__ out, int iters) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6)) & 63;
+    s16x8_t a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = *reinterpret_cast<const s16x8_t*>(ab + ((size_t)(wave * 8 + k) * 64 + lane) * 8);
+        b[k] = *reinterpret_cast<const s16x8_t*>(ab + ((size_t)(wave * 8 + 4 + k) * 64 + lane) * 8);
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = H16<T>::mma16(a[i], b[j], acc[i][j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 123.456f) out[0] = sum;  // (keeps the loop alive; never true on finite data)
+}
+extern "C" int falnet_mfma_probe(const void* ab, float* out, int iters, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_CHECK_ARG(ab && out && iters > 0 && (dtype == FALNET_BF16 || dtype == FALNET_F16), "mfma_probe: 16-bit operands (64 x 8 x 64 x 8 values), iters > 0");
+    // 2 048 workgroups of four waves: eight per CU over the launch, two waves per SIMD resident (launch bounds), as the convolution kernels run
+    if (dtype == FALNET_BF16) hipLaunchKernelGGL(mfma_probe_kernel<bf16_t>, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ab, out, iters);
+    else hipLaunchKernelGGL(mfma_probe_kernel<f16_t>, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const f16_t*)ab, out, iters);
+    FALNET_RETURN_LAUNCH();
+}
+

@@ -470,6 +470,10 @@ int falnet_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
  * (fal_net_amd/plan.py: stream_selftest) -- two of them on two streams take ONE period when the streams sit on different hardware queues and TWO
  * when HIP has mapped both onto the same queue.  Not part of any step. */
 int falnet_spin(int microseconds, void* stream);
+/* The matrix-pipe rate the board SUSTAINS: 2 048 workgroups x 4 waves, each issuing iters x 16 register-resident v_mfma_f32_16x16x32 on the
+ * caller's operands `ab` (64 x 8 x 64 x 8 16-bit values = 512 KiB; random data for the ceiling under real switching activity); FLOPs of one launch =
+ * 2048 * 4 * iters * 16 * 16384.  bench.py's `roofline.sustained_mfma` (measurement only: no step launches it); `out` is never written on finite data. */
+int falnet_mfma_probe(const void* ab, float* out, int iters, int dtype, void* stream);
 
 #ifdef __cplusplus
 }
