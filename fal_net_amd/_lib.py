@@ -77,7 +77,7 @@ class PackDesc(C.Structure):
 
 class PackUp2Desc(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wu", C.c_void_p), ("cout", C.c_int32), ("cin", C.c_int32), ("cin_pad", C.c_int32), ("cout_pad", C.c_int32),
-                ("block_begin", C.c_int32)]
+                ("block_begin", C.c_int32), ("reserved", C.c_int32), ("wdd", C.c_void_p)]
 
 
 class Cmd(C.Structure):  # falnet_cmd_t
@@ -175,7 +175,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 501
+EXPECTED_VERSION = 502
 
 
 def lib():

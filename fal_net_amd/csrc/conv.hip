@@ -2738,6 +2738,27 @@ __global__ __launch_bounds__(256) void pack_up2_batched_kernel(const falnet_pack
                     if (ky >= ky0 && ky <= ky1 && kx >= kx0 && kx <= kx1) v += w[ky * 3 + kx];
             wu[((int64_t)co * 16 + pair) * d.cin_pad + ci] = from_f32<T>(v);
         }
+        if (d.wdd) {
+            // data-gradient form on the low-resolution grid (conv_dma.hip: conv2x2_up2d_dma16_kernel): wdd[ci][2 du + dv][e 2 Cp + f Cp + co], the
+            // coefficient of upstream pixel (2 (i + du) - 1 + e, 2 (j + dv) - 1 + f) in input position (i, j): per axis t = 2 d + parity selects the
+            // 3x3 taps {2}, {1, 2}, {0, 1}, {0}
+            T* wdd = reinterpret_cast<T*>(d.wdd);
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+                for (int ef = 0; ef < 4; ++ef) {
+                    const int ty = 2 * (tap >> 1) + (ef >> 1), tx = 2 * (tap & 1) + (ef & 1);
+                    const int ky0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), ky1 = ty == 0 ? 2 : (ty == 1 ? 2 : (ty == 2 ? 1 : 0));
+                    const int kx0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), kx1 = tx == 0 ? 2 : (tx == 1 ? 2 : (tx == 2 ? 1 : 0));
+                    float v = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            if (ky >= ky0 && ky <= ky1 && kx >= kx0 && kx <= kx1) v += w[ky * 3 + kx];
+                    wdd[((int64_t)ci * 4 + tap) * (4 * d.cout_pad) + ef * d.cout_pad + co] = from_f32<T>(v);
+                }
+        }
     }
 }
 
@@ -2876,6 +2897,8 @@ int falnet_conv_dma2_launch(const falnet_conv_t& p, int flip, hipStream_t st, in
 int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, int th);  // variants 13 / 17 / 20 on v_mfma_f32_16x16x32 (variants 23 / 24 / 25)
 bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // deconv forward in sub-pixel form (variant 18)
 int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
+bool falnet_conv_up2d_applicable(const falnet_conv_t& p);                   // deconv data gradient on the low-resolution grid (variant 26)
+int falnet_conv_up2d_launch(const falnet_conv_t& p, hipStream_t st);
 bool falnet_conv_deep_applicable(const falnet_conv_t& p);                   // maps of <= 128 positions: one-shot LDS-DMA, K slices, last-arriver epilogue (variant 19)
 int falnet_conv_deep_launch(const falnet_conv_t& p, hipStream_t st);
 int falnet_conv_deep_mtiles(const falnet_conv_t& p);
@@ -2920,7 +2943,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || (variant >= 21 && variant <= 25), "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || (variant >= 21 && variant <= 26), "conv2d: unknown variant %d", variant);
     if (variant == 19) {  // levels 5-6: K-sliced one-shot LDS-DMA kernel with the epilogue in the last slice (conv_dma.hip: conv3x3_deep_kernel)
         if (!falnet_conv_deep_applicable(p)) {
             falnet_set_error("conv2d: variant 19 needs a 16-bit nine-tap stride-1/2 launch on maps of at most 128 positions (128 %% (TH TW) == 0), dense NHWC output, "
@@ -2942,6 +2965,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.swap = 0;
         c.patch = 4;
         c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
+        return 0;
+    }
+    if (variant == 26) {  // deconv data gradient on the low-resolution grid: 2x2 taps over pair pixels of the upstream gradient (conv_dma.hip: conv2x2_up2d_dma16_kernel)
+        if (!(falnet_conv_up2d_applicable(p) && p.ntaps == 4 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.TH == p.OH && p.TW == p.OW)) {
+            falnet_set_error("conv2d: variant 26 needs a 16-bit NHWC launch over ONE source at exactly twice the output map (>= 16 x 32), w_taps = ntaps = 4, cin_total = 4 C, no pool / split-K");
+            return -2;
+        }
+        c.flip = 0;
+        c.swap = 0;
+        c.patch = 9;
+        c.bn = 64; c.kcb = 32; c.tps = 4; c.adb = 1; c.th = 16; c.nwaves = 8;
         return 0;
     }
     if (variant == 18) {  // deconv forward in sub-pixel form (conv_dma.hip: conv3x3_up2_dma_kernel)
@@ -3065,7 +3099,9 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 8)
+    if (c.patch == 9)
+        snprintf(buf, len, "_Z25conv2x2_up2d_dma16_kernelI%sEv13falnet_conv_tiii", t);
+    else if (c.patch == 8)
         snprintf(buf, len, "_Z20conv3x3_dma16_kernelI%sLb%dELi%dELi%dELb%dEEv13falnet_conv_tiiii", t, pp->pool_out ? 1 : 0, c.th, c.nwaves, pp->out_layout == FALNET_OUT_PLANAR_F32 ? 1 : 0);
     else if (c.patch == 7)
         snprintf(buf, len, "_Z19conv3x3_dma2_kernelI%sLb%dELi%dEEv13falnet_conv_tiiiii", t, pp->pool_out ? 1 : 0, c.nwaves);
@@ -3119,6 +3155,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 9) return falnet_conv_up2d_launch(p, st);
     if (c.patch == 8) return falnet_conv_dma16_launch(p, c.flip, st, c.th);
     if (c.patch == 7) return falnet_conv_dma2_launch(p, c.flip, st, c.th);
     if (c.patch == 6) return falnet_conv_deep_launch(p, st);

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
         issue(qi, 0);
         advance(qi);
     }
-    int ctile = blockIdx.x, cc = 0;  // compute cursor
+    int cc = 0;  // chunk of the compute cursor's tile
 #ifdef FALNET_CD_STAMPS
     // profiling build (tools/cd_stamps.py): s_memtime at the phase boundaries of the first 48 chunks, every wave of workgroup (0, 0) -> p.splitk_ws
     unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv3x3_dma_kernel(const falnet_c
             cc = 0;
             const int b = ct.b, ty0 = ct.ty * TH, tx0 = ct.tx * 32;
             pos_next(ct);
-            ctile += gridDim.x;
             const int cstride = p.out_cstride;
             const int x = tx0 + r;
             const bool planar_out = p.out_layout == FALNET_OUT_PLANAR_F32;
@@ -844,7 +843,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
         for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
         advance(qi);
     }
-    int ctile = blockIdx.x, cc = 0;
+    int cc = 0;
 #ifdef FALNET_CD_STAMPS  // profiling build (tools/cd_stamps.py): s_memtime at the phase boundaries, every wave of workgroup (0, 0) -> p.splitk_ws
     unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(p.splitk_ws);
     int stamp_i = 0;
@@ -942,7 +941,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 2 : 1) void conv3x3_dma1
             cc = 0;
             const int b = ct.b, ty0 = ct.ty * TH, tx0 = ct.tx * 32;
             pos_next(ct);
-            ctile += gridDim.x;
             const int cstride = p.out_cstride;
             const int x = tx0 + r;
             // (wave-uniform 64-bit origin of the tile + a 32-bit lane part: no 64-bit vector multiply per slab)
@@ -1002,6 +1000,268 @@ int falnet_conv_dma16_launch(const falnet_conv_t& p, int flip, hipStream_t st, i
     FALNET_DISPATCH_16(p.dtype, DMA16_L);
 #undef DMA16_L
 #undef DMA16_K
+    FALNET_RETURN_LAUNCH();
+}
+
+// ============================================================================================================================
+// Data gradient of a `deconv` layer (nearest 2x upsampling + 3x3 convolution, models/FAL_netB.py:52-58) ON THE LOW-RESOLUTION GRID
+// (falnet_conv2d variant 26, round 5).
+//
+// y[Y, X] = sum_k W[k] up(x)[Y + kh - 1, X + kw - 1], up(x)[r, c] = x[r >> 1, c >> 1].  The high-resolution form (3x3 data gradient at 2H x 2W,
+// 2x2 sums fused into its epilogue: 36 MACs per low-resolution position and channel pair) adds taps that meet the SAME upstream pixel: per
+// axis, input position i receives  W[2] g[2i-1] + (W[1] + W[2]) g[2i] + (W[0] + W[1]) g[2i+1] + W[0] g[2i+2]  -- a 4x4 / stride-2 convolution of the
+// upstream gradient, 16 MACs (2.25x fewer).  Grouped by PAIRS of upstream rows / columns (pair u = rows 2u-1, 2u; columns alike) it is a dense
+// 2x2-tap stride-1 convolution over "pair pixels" of 4 C channels: K index = e 2C + f C + c for row parity e, column parity f (falnet_pack_up2_batched
+// writes the summed weights wdd[ci][2 du + dv][K]).  The kernel is conv3x3_dma16_kernel's machinery with four tap steps per 32-channel chunk:
+//   * a chunk belongs to one (e, f): its patch piece of pair pixel (u, v) is the 64 B at upstream pixel (2u - 1 + e, 2v - 1 + f) -- the LDS-DMA
+//     gathers the strided view directly, pixels outside the upstream map (row -1 of pair 0, row 2H of pair H) read the zero page;
+//   * patch (16 + 1) x (32 + 1) pair pixels (CD_PW columns kept for the segment swizzle), weights 4 x 64 rows: 53 KB per buffer;
+//   * per chunk and wave 4 steps x 16 MFMAs on six + six pixel fragments and four weight fragments per step; the epilogue is the plain NHWC one
+//     (residual addend, activation gradient of the layer's input).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv2x2_up2d_dma16_kernel(const falnet_conv_t p, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int TH = 16, NWAVES = 8, MT = 2, BN = 64, NT = 2, KCV = 32;
+    constexpr int NPIX = (TH + 1) * CD_PW;
+    constexpr int A_PIECES = (NPIX + 15) / 16, B_PIECES = 4 * BN / 16, NPIECES = A_PIECES + B_PIECES;
+    constexpr int A_BYTES = A_PIECES * 1024, BUF = NPIECES * 1024;
+    constexpr int ROWB = CD_PW * 64;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float lds_bias[BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(unsigned long)(cd_lptr_t)lds;
+    const int r = lane & 31;
+    const int lp = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * BN;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cd_zero);
+    stage_bias_lds(p, n0, BN, lds_bias);
+
+    const falnet_src_t& S = p.src[0];          // the upstream gradient at 2 OH x 2 OW
+    const int GH = S.H, GW = S.W, CP = S.C;     // its map and (padded) channel count
+    const int cpc = CP / KCV;                   // chunks per (e, f)
+    const int nchunks = 4 * cpc;
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nchunks;
+
+    constexpr int KP = (A_PIECES + NWAVES - 1) / NWAVES, KW = (B_PIECES + NWAVES - 1) / NWAVES;
+    static_assert(KP + KW <= 8, "two DMA issue slots per step");
+    const int l4 = lane >> 2, segpos = lane & 3;
+    const T* const wptr = reinterpret_cast<const T*>(p.weight);
+    const T* const zero_t = reinterpret_cast<const T*>(zero_page);
+    const T* const sptr = reinterpret_cast<const T*>(S.ptr);
+    int64_t w_off[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int wid = wave + NWAVES * k;
+        const int tap = wid >> 2, co = n0 + ((wid & 3) << 4) + l4;
+        const int gseg = segpos ^ (((l4 >> 2) & 1) << 1);
+        w_off[k] = (wid < B_PIECES && co < p.w_rows) ? (int64_t)(co * 4 + tap) * p.cin_total + gseg * 8 : (int64_t)(zero_t - wptr);
+    }
+    struct TPos { int b, ty, tx; };
+    TPos step_;
+    {
+        const int g = (int)gridDim.x;
+        step_.tx = g % tiles_x;
+        const int q = g / tiles_x;
+        step_.ty = q % tiles_y;
+        step_.b = q / tiles_y;
+    }
+    auto pos_of = [&](int tile) {
+        TPos t;
+        t.tx = tile % tiles_x;
+        const int q = tile / tiles_x;
+        t.ty = q % tiles_y;
+        t.b = q / tiles_y;
+        return t;
+    };
+    auto pos_next = [&](TPos& t) {
+        t.tx += step_.tx;
+        if (t.tx >= tiles_x) { t.tx -= tiles_x; ++t.ty; }
+        t.ty += step_.ty;
+        if (t.ty >= tiles_y) { t.ty -= tiles_y; ++t.b; }
+        t.b += step_.b;
+    };
+    int pr_[KP], pc_[KP], a_off[KP];  // pair-pixel row / column of piece k inside the patch; its element offset from the (tile, e, f) origin
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int pix = 16 * (wave + NWAVES * k) + l4;
+        const int pr = pix / CD_PW, pc = pix - pr * CD_PW;
+        pr_[k] = pix < NPIX ? pr : (1 << 20);  // (a piece beyond the patch never passes the in-map test)
+        pc_[k] = pc;
+        a_off[k] = 2 * pr * (int)S.sy + 2 * pc * (int)S.sx + (segpos ^ (((pc >> 2) & 1) << 1)) * 8;
+    }
+    unsigned a_ok = 0;
+    const T* a_base = sptr;
+    auto tile_offsets = [&](const TPos& t, int e, int f) {  // origin = upstream pixel (2 ty0 - 1 + e, 2 tx0 - 1 + f) of image b (only ever dereferenced with a piece that passed the test)
+        const int y0 = 2 * t.ty * TH - 1 + e, x0 = 2 * t.tx * 32 - 1 + f;
+        a_base = sptr + ((int64_t)t.b * S.sb + (int64_t)y0 * (int)S.sy + (int64_t)x0 * (int)S.sx);
+        a_ok = 0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int vy = y0 + 2 * pr_[k], vx = x0 + 2 * pc_[k];
+            a_ok |= (vy >= 0 && vy < GH && vx >= 0 && vx < GW) ? 1u << k : 0u;
+        }
+    };
+    struct Cur { int tile, c, cin, ef, kofs; TPos t; };  // chunk of the tile, chunk inside its (e, f), (e, f) index, weight K offset
+    auto advance = [&](Cur& q) {
+        q.kofs += KCV;
+        ++q.c;
+        if (++q.cin == cpc) {
+            q.cin = 0;
+            if (++q.ef == 4) {
+                q.ef = 0; q.c = 0; q.kofs = 0;
+                q.tile += gridDim.x;
+                pos_next(q.t);
+                if (q.tile >= ntiles) return;
+            }
+            tile_offsets(q.t, q.ef >> 1, q.ef & 1);
+        }
+    };
+    auto issue_piece = [&](const Cur& q, int buf, int i) {
+        const unsigned dst0 = lds_base + buf * BUF;
+        if (i < KP) {
+            const int id = wave + NWAVES * i;
+            const T* src = ((a_ok >> i) & 1) ? a_base + q.cin * KCV + a_off[i] : zero_t;
+            if (id < A_PIECES) cd_glds16(src, dst0 + id * 1024);
+        } else {
+            const int wid = wave + NWAVES * (i - KP);
+            if (wid < B_PIECES) cd_glds16(wptr + q.kofs + w_off[i - KP], dst0 + A_BYTES + wid * 1024);
+        }
+    };
+
+    int a_lane[2][2];
+#pragma unroll
+    for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int col = dv + 16 * pt + lp;
+            a_lane[dv][pt] = ((wave * MT) * CD_PW + col) * 64 + ((lg ^ (((col >> 2) & 1) << 1)) << 4);
+        }
+    const int wrow = m16_row_channel(lp);
+    const int b_lane = A_BYTES + wrow * 64 + ((lg ^ (((wrow >> 2) & 1) << 1)) << 4);
+
+    Acc16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt].zero();
+    Cur qi = {(int)blockIdx.x, 0, 0, 0, 0, pos_of((int)blockIdx.x)};
+    TPos ct = qi.t;
+    if (total > 0) {
+        tile_offsets(qi.t, 0, 0);
+#pragma unroll
+        for (int i = 0; i < KP + KW; ++i) issue_piece(qi, 0, i);
+        advance(qi);
+    }
+    int cc = 0;
+    for (int it = 0; it < total; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = it + 1 < total;
+        int bo = (it & 1) * BUF;
+        asm volatile("" : "+s"(bo));
+        const char* const Bf = lds;
+        int aa[2][2];
+#pragma unroll
+        for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) aa[dv][pt] = a_lane[dv][pt] + bo;
+        const int bb = b_lane + bo;
+        // step st = 2 dv + du: tap (du, dv) = weight tile 2 du + dv; patch row rs of column group dv serves output row mt under du = rs - mt
+        s16x8_t fa[2][MT + 1][2], fb[2][NT][2];
+        auto a_read = [&](int dv, int rs, int pt) { return *reinterpret_cast<const s16x8_t*>(Bf + aa[dv][pt] + rs * ROWB); };
+        auto b_read = [&](int st, int set) {
+            const int t = (st & 1) * 2 + (st >> 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ct2 = 0; ct2 < 2; ++ct2) fb[set][nt][ct2] = *reinterpret_cast<const s16x8_t*>(Bf + bb + (t * BN + nt * 32 + ct2 * 16) * 64);
+        };
+#pragma unroll
+        for (int rs = 0; rs < MT; ++rs)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) fa[0][rs][pt] = a_read(0, rs, pt);
+        b_read(0, 0);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int dv = st >> 1, du = st & 1;
+            if (st + 1 < 4) b_read(st + 1, (st + 1) & 1);
+            if (du == 0) { fa[dv][MT][0] = a_read(dv, MT, 0); fa[dv][MT][1] = a_read(dv, MT, 1); }
+            if (du == 1 && dv == 0) {
+#pragma unroll
+                for (int rs = 0; rs < MT; ++rs)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) fa[1][rs][pt] = a_read(1, rs, pt);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int i = 2 * st + half;
+                if (i < KP + KW && more) issue_piece(qi, (it + 1) & 1, i);  // (wave-uniform)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int ct2 = 0; ct2 < 2; ++ct2)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt)
+                            acc[half][nt].t[ct2][pt] = H16<T>::mma16(fb[st & 1][nt][ct2], fa[dv][half + du][pt], acc[half][nt].t[ct2][pt]);
+            }
+            if (st == 3) __builtin_amdgcn_sched_group_barrier(0x100, 0, 0);
+            else if (st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        if (more) advance(qi);
+        if (++cc == nchunks) {
+            cc = 0;
+            const int b = ct.b, ty0 = ct.ty * TH, tx0 = ct.tx * 32;
+            pos_next(ct);
+            const int cstride = p.out_cstride;
+            const int x = tx0 + r;
+            const int64_t obase = (((int64_t)b * p.OH + ty0) * p.OW + tx0) * cstride;
+            auto pixoff = [&](int mt) -> int64_t {
+                const int y = ty0 + wave * MT + mt;
+                if (!(y < p.OH && x < p.OW)) return (int64_t)-1;
+                return obase + ((wave * MT + mt) * p.OW + r) * cstride;
+            };
+            const int h = lane >> 5;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float bias[1][16];
+                load_bias16_lds(lds_bias, 32 * nt, h, bias);
+                f32x16 v[MT][1];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][nt].to32(v[mt][0]);
+                    acc[mt][nt].zero();
+                }
+                epilogue_direct<T, MT, 1, decltype(pixoff), NoPool, FALNET_DMA16_EPI_AHEAD, false, true>(p, v, bias, n0 + 32 * nt, lane, pixoff);
+            }
+        }
+    }
+}
+
+// variant 26: one upstream-gradient source at exactly twice the output map, 2x2-tap weights [w_rows][4][4 C] (falnet_pack_up2_batched: wdd)
+bool falnet_conv_up2d_applicable(const falnet_conv_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.nsrc != 1 || p.w_taps != 4 || p.out_layout != FALNET_OUT_NHWC || p.pool_out || p.ksplit > 1 || !p.out || p.weight_up2) return false;
+    const falnet_src_t& S = p.src[0];
+    if (S.C % 32 || S.C <= 0 || p.cin_total != 4 * S.C) return false;
+    if (S.H != 2 * p.OH || S.W != 2 * p.OW || p.OH < 16 || p.OW < 32) return false;
+    if ((int64_t)S.H * S.sy >= (1ll << 31) || (int64_t)p.w_rows * 4 * p.cin_total >= (1ll << 31) || (S.C + 64) * 2 > CD_ZERO_BYTES) return false;
+    return true;
+}
+
+int falnet_conv_up2d_launch(const falnet_conv_t& p, hipStream_t st) {
+    const int tiles_x = (p.OW + 31) / 32, tiles_y = (p.OH + 15) / 16;
+    const int ntiles = p.B * tiles_x * tiles_y;
+    const int ny = (p.Cout + 63) / 64;
+    int gx = 256 / ny;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv2x2_up2d_dma16_kernel<f16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv2x2_up2d_dma16_kernel<bf16_t>), grid, dim3(512), 0, st, p, tiles_x, tiles_y, ntiles);
     FALNET_RETURN_LAUNCH();
 }
 

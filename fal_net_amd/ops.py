@@ -27,6 +27,7 @@ AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 # timing launches, whose winner can differ from run to run --, no split-K (f32 atomics), one writer per element in the slab reduce,
 # bias gradients through the two-pass ordered form; the library side is falnet_set_deterministic (fal_net_amd/_lib.py sets it).
 DETERMINISTIC = L.DETERMINISTIC
+UP2D = L.ab("FALNET_UP2D", "1") == "1"  # deconv data gradients on the low-resolution grid (falnet_conv2d variant 26) among the plan's candidates
 
 
 # ---- persistent autotune choices --------------------------------------------------------------------------------------
@@ -204,6 +205,7 @@ class PackedConv:
         self.cout_pad = pad_c(self.cout)
         self.wf = self.wd = None
         self.wu = None      # sub-pixel weights [cout_pad][16][cin_pad] of a `deconv` layer (set `up2 = True` before alloc): falnet_conv2d variant 18
+        self.wdd = None     # the same layer's data-gradient weights on the low-resolution grid [cin_pad][4][4 cout_pad]: falnet_conv2d variant 26
         self.up2 = False
         self._packed_version = None
         self._dtype = None
@@ -213,6 +215,7 @@ class PackedConv:
             self.wf = torch.zeros(self.cout_pad, self.taps, self.cin_pad, dtype=dtype, device=device)
             self.wd = torch.zeros(self.cin_pad, self.taps, self.cout_pad, dtype=dtype, device=device)
             self.wu = torch.zeros(self.cout_pad, 16, self.cin_pad, dtype=dtype, device=device) if (self.up2 and dtype in H16 and self.taps == 9) else None
+            self.wdd = torch.zeros(self.cin_pad, 4, 4 * self.cout_pad, dtype=dtype, device=device) if (self.wu is not None and UP2D) else None
             self._dtype = dtype
             self._packed_version = None
 
@@ -314,6 +317,7 @@ def pack_up2_call(pcs, dtype, device):
     for i, pc in enumerate(pcs):
         d = descs[i]
         d.w, d.wu, d.cout, d.cin, d.cin_pad, d.cout_pad, d.block_begin = pc.weight.data_ptr(), pc.wu.data_ptr(), pc.cout, pc.cin, pc.cin_pad, pc.cout_pad, blk
+        d.wdd = 0 if pc.wdd is None else pc.wdd.data_ptr()
         blk += (pc.cout_pad // 32) * (pc.cin_pad // 32)
     dev = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(device)
     n, total, code = len(pcs), blk, L.dtype_code(dtype)
@@ -359,9 +363,11 @@ def _fill_taps(d, taps):
 def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stride_in, B, TH, TW, out, OH, OW,
               Cout, out_cstride, out_layout=L.OUT_NHWC, out_step=(1, 1, 0, 0), bias=None, addend=None,
               act=L.ACT_NONE, actout=None, actout_kind=L.ACT_NONE, weight_offset_elems=0, name="conv", flops=0,
-              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE, weight_up2=None):
+              autotune=True, ws_owner=None, pool_out=None, pool_mode=0, pool_actout=None, pool_actout_kind=L.ACT_NONE, weight_up2=None,
+              variant=None):
     """Build one falnet_conv2d launch; returns a zero-argument callable.  `pool_out`: fused 2x2 max pool of the output
-    (halo-patch kernels only; `out` may then be None when only the pooled map is needed)."""
+    (halo-patch kernels only; `out` may then be None when only the pooled map is needed).  `variant`: this kernel and no other (no autotune;
+    ValueError when it does not apply)."""
     lib = L.lib()
     d = L.Conv()
     d.nsrc = len(srcs)
@@ -397,7 +403,11 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
         d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel() * 4
     ref = C.byref(d)
     keep = (d, srcs, weight, out, bias, addend, actout, ws, pool_out, pool_actout, weight_up2, scratch)
-    if AUTOTUNE and autotune and dev_t.is_cuda:
+    if variant is not None:
+        d.variant = variant
+        if lib.falnet_conv2d_kernel_name(ref, C.create_string_buffer(160), 160) != 0:
+            raise ValueError(f"falnet_conv2d variant {variant} does not apply to this launch: {lib.falnet_last_error().decode(errors='replace')}")
+    elif AUTOTUNE and autotune and dev_t.is_cuda:
         key = conv_signature(d)
         hit = cache_get(key)
         if hit is not None:
@@ -423,6 +433,23 @@ def conv_call(dtype, srcs, IH, IW, weight, cin_total, taps, w_taps, w_rows, stri
     call = _timed(tag, flops, 0, launch, f"{name} v{d.variant} k{d.ksplit}")
     call.desc, call.ref = d, ref
     return call
+
+
+UP2D_TAPS = [(0, 0, 0), (0, 1, 1), (1, 0, 2), (1, 1, 3)]  # (du, dv, weight tile) of falnet_conv2d variant 26: pairs u = i, i + 1 of upstream rows / columns
+
+
+def deconv_dgrad_call(dtype, gout, pc, B, gin, actout, name="", flops=0, ws_owner=None):
+    """Data gradient of a `deconv` layer (nearest 2x upsampling + 3x3 convolution, FAL_netB.py:52-58) on the low-resolution grid:
+    gin[B, H, W, cin_pad] = (4x4 / stride-2 convolution of gout[B, 2H, 2W, cout_pad] with the summed taps pc.wdd) * elu'(actout) -- falnet_conv2d
+    variant 26, 16 instead of 36 tap-MACs per position.  ValueError when the kernel does not apply (maps below 16 x 32, f32)."""
+    if pc.wdd is None:
+        raise ValueError("no low-resolution data-gradient weights for this layer")
+    GH, GW = gout.shape[1], gout.shape[2]
+    OH, OW = GH // 2, GW // 2
+    assert (2 * OH, 2 * OW) == (GH, GW) and gout.shape[3] == pc.cout_pad and gin.shape[1:3] == (OH, OW)
+    return conv_call(dtype, [nhwc_src(gout)], GH, GW, pc.wdd, 4 * pc.cout_pad, UP2D_TAPS, 4, pc.cin_pad, 1, B, OH, OW, gin, OH, OW, pc.cin_pad, gin.shape[3],
+                     actout=actout, actout_kind=L.ACT_ELU if actout is not None else L.ACT_NONE, name="dgrad(low-res) " + name, flops=flops,
+                     ws_owner=ws_owner, variant=26)
 
 
 _SPLITK_WS = {}

@@ -19,8 +19,9 @@ from . import ops
 from .arch import ARCHS
 from .ops import pad_c
 
-_TAIL_MAIN = ""  # default of FALNET_TAIL_MAIN: extra weight gradients for the main stream's tail beside level 0's (re-tuned after the later kernel
-# changes made the MAIN stream the longer chain again: "conv1,conv1_1.conv1" was +0.7 % once, now -0.6 %)
+_TAIL_MAIN = "conv1_1.conv1"  # default of FALNET_TAIL_MAIN: extra weight gradients for the main stream's tail beside level 0's.  Re-tuned whenever a kernel
+# change moves work between the chains: "" while the main stream was the longer one; with the deconv data gradients on the low-resolution grid (main
+# stream -69 us) the side streams are, and one level-1 weight gradient on the main stream is worth 0.7 % (profiles/r05_ab_up2d.txt)
 _TAIL_LEVELS = int(L.ab("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
@@ -605,13 +606,23 @@ class FalnetPlan:
                         self.bwd_body.append(ops.simple_call("falnet_upsample_bwd", L.ptr(g_up), L.ptr(tgt), L.ptr(below), B, hh,
                                                              ww, bh, bw, below_ch, code))
                         plain, self.bwd_body = self.bwd_body[at:], self.bwd_body[:at]
-                    if fused is not None and plain is not None:
-                        seqs = [fused, plain]
+                    # the same gradient on the LOW-resolution grid: the taps that meet one upstream pixel summed beforehand (falnet_conv2d variant 26,
+                    # 16 instead of 36 tap-MACs per position; maps of at least 16 x 32, 16-bit types)
+                    lowres = None
+                    if (2 * bh, 2 * bw) == (hh, ww) and pcd.wdd is not None:
+                        try:
+                            lowres = [ops.deconv_dgrad_call(self.dtype, g_dpre, pcd, B, tgt, below, name=dname, ws_owner=("falnet", id(self)),
+                                                            flops=2 * B * hh * ww * pcd.cout * pcd.cin * 9)]
+                        except ValueError:
+                            pass
+                    seqs = [q for q in (fused, plain, lowres) if q is not None]
+                    if len(seqs) > 1:
                         runs = [lambda q=q: [c() for c in q] for q in seqs]
-                        pick = ops.best_of(*runs, key=f"upsum|t{code}|B{B}|{hh}x{ww}|{pcd.cin_pad}>{pcd.cout_pad}")
+                        tags = "".join("f" if q is fused else ("p" if q is plain else "l") for q in seqs)
+                        pick = ops.best_of(*runs, key=f"upsum3|{tags}|t{code}|B{B}|{hh}x{ww}|{pcd.cin_pad}>{pcd.cout_pad}")
                         self.bwd_body.extend(seqs[runs.index(pick)])
                     else:
-                        self.bwd_body.extend(fused if fused is not None else plain)
+                        self.bwd_body.extend(seqs[0])
                 if lvl < 6:
                     g_ipre[lvl + 1] = tgt
             # gc[6] now holds g_z6 (pre-activation grad of the last residual block output)

@@ -137,6 +137,10 @@ typedef struct {
                                   staged bytes and 40 % fewer fragment reads per MFMA than 13;
                                   23 = 13 on v_mfma_f32_16x16x32 (a 32x32 tile as 2 x 2 MFMAs of K = 32): the MFMA shape the chip holds a higher clock on
                                   (conv_dma.hip: conv3x3_dma16_kernel); 24 / 25 = 17 / 20 in the same way (NHWC outputs, no fused pool);
+                                  26 = data gradient of a `deconv` layer (nearest 2x upsampling + 3x3 convolution, FAL_netB.py:52-58) on the LOW-resolution
+                                  grid: ONE source = the upstream gradient at exactly twice the output map, weight = falnet_pack_up2_t::wdd
+                                  ([w_rows][4][4 C], w_taps = ntaps = 4, cin_total = 4 C) -- a 2x2-tap convolution over pairs of upstream rows /
+                                  columns, 16 instead of 36 tap-MACs per input position (conv_dma.hip: conv2x2_up2d_dma16_kernel);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,
@@ -260,6 +264,10 @@ int falnet_adam_tick(float* state, const float* scaler, void* stream);
 typedef struct {
     const float* w; void* wu;
     int32_t cout, cin, cin_pad, cout_pad, block_begin;
+    int32_t reserved;
+    void* wdd;  /* NULL, or [cin_pad][4][4 cout_pad]: the layer's data-gradient weights on the low-resolution grid (falnet_conv2d variant 26):
+                 * wdd[ci][2 du + dv][e 2 cout_pad + f cout_pad + co] = sum of the 3x3 taps that carry upstream pixel (2 (i + du) - 1 + e,
+                 * 2 (j + dv) - 1 + f) into input position (i, j); per axis t = 2 d + parity selects taps {2}, {1, 2}, {0, 1}, {0} */
 } falnet_pack_up2_t;
 int falnet_pack_up2_batched(const falnet_pack_up2_t* descs_dev, int n, int total_blocks, int dtype, void* stream);
 /* accumulate == 0: entries with groups == 1 OVERWRITE their gradient (plain stores), entries with groups > 1 add into it

@@ -509,6 +509,78 @@ def test_conv_subpixel_deconv_forward(B, cin, cout, h, w, act, with_bias, dtype)
     assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cin,cout,h,w,with_act", [
+    (2, 64, 64, 16, 32, True),     # one tile exactly
+    (1, 128, 64, 24, 80, True),    # ragged tiles both ways (second tile row of 8, third tile column of 16)
+    (3, 256, 128, 16, 33, False),  # a single ragged column, 4 output-channel blocks, 16 chunks
+    (2, 96, 49, 17, 40, True),     # gradient channels not a multiple of 32 (49 -> 64: zero weight columns), input channels 96 (two blocks, ragged)
+    (8, 64, 64, 128, 256, True),   # deconv1 at the benchmark's size
+])
+def test_conv_deconv_dgrad_lowres(B, cin, cout, h, w, with_act, dtype):
+    """falnet_conv2d variant 26 (conv2x2_up2d_dma16_kernel + falnet_pack_up2_batched's wdd): the data gradient of a `deconv` layer (FAL_netB.py:52-58,
+    nearest x2 then 3x3 conv) computed ON THE LOW-RESOLUTION GRID -- the 3x3 taps that meet one upstream pixel summed beforehand: a 4x4 / stride-2
+    convolution of the upstream gradient, 16 instead of 36 tap-MACs per position -- against autograd through F.interpolate + F.conv2d AND against the
+    product's other form (3x3 data gradient at 2H x 2W with the 2x2 sums in its epilogue) on the same operands."""
+    g = torch.Generator().manual_seed(B * 977 + cin + 3 * cout + h)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (0.5 / (cout ** 0.5))
+    gout = torch.randn(B, cout, 2 * h, 2 * w, generator=g)
+    low = torch.randn(B, cin, h, w, generator=g)
+    low = torch.where(low > 0, low, torch.expm1(low))  # the layer's input: an ELU output
+    gr = gout.to(dtype).float()
+    x = torch.zeros(B, cin, h, w, requires_grad=True)
+    (F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, None, padding=1) * gr).sum().backward()
+    act_t = to_nhwc(low, dtype)
+    lowr = to_nchw(act_t, cin)
+    ref = x.grad * (torch.where(lowr > 0, torch.ones_like(lowr), lowr + 1) if with_act else 1.0)
+    wp = torch.nn.Parameter(wt.to(DEV))
+    pc = ops.PackedConv("deconvT", wp, None, [cin], 1)
+    pc.up2 = True
+    pc.alloc(dtype, torch.device(DEV))
+    assert pc.wdd is not None and tuple(pc.wdd.shape) == (pc.cin_pad, 4, 4 * pc.cout_pad)
+    pc.pack_call()()
+    ops.pack_up2_call([pc], dtype, torch.device(DEV))()
+    # the packed weights: wdd[ci][2 du + dv][e 2 Cp + f Cp + co], per axis t = 2 d + parity selects the 3x3 taps {2}, {1, 2}, {0, 1}, {0}
+    sel = {0: [2], 1: [1, 2], 2: [0, 1], 3: [0]}
+    wdd_ref = torch.zeros(pc.cin_pad, 4, 4 * pc.cout_pad)
+    for du in range(2):
+        for dv in range(2):
+            for e in range(2):
+                for f in range(2):
+                    acc = sum(wt[:, :, ky, kx] for ky in sel[2 * du + e] for kx in sel[2 * dv + f])  # [cout][cin]
+                    k0 = e * 2 * pc.cout_pad + f * pc.cout_pad
+                    wdd_ref[:cin, 2 * du + dv, k0:k0 + cout] = acc.t()
+    assert torch.equal(pc.wdd.float().cpu(), wdd_ref.to(dtype).float())
+    g_t = to_nhwc(gout, dtype)
+    gin = torch.full((B, h, w, pc.cin_pad), float("nan"), dtype=dtype, device=DEV)
+    call = ops.deconv_dgrad_call(dtype, g_t, pc, B, gin, act_t if with_act else None, name="t")
+    assert call.desc.variant == 26 and "up2d" in call.tag
+    call()
+    torch.cuda.synchronize()
+    assert torch.isfinite(gin.float()).all()
+    if pc.cin_pad > cin:  # padded output channels: zero weight rows -> zeros (times elu' of a zero activation = 1)
+        assert float(gin[..., cin:].float().abs().max()) == 0.0
+    got = to_nchw(gin, cin)
+    assert rel(got, ref) < TOL[dtype], rel(got, ref)
+    # the other form on the same operands: 3x3 data gradient over the 2H x 2W map, 2x2 block sums x elu' in the epilogue
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        pooled = torch.full((B, h, w, pc.cin_pad), float("nan"), dtype=dtype, device=DEV)
+        hi = ops.conv_call(dtype, [ops.nhwc_src(g_t)], 2 * h, 2 * w, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9, pc.cin_pad, 1, B, 2 * h, 2 * w, None,
+                           2 * h, 2 * w, pc.cin_pad, pc.cin_pad, pool_out=pooled, pool_mode=1, pool_actout=act_t if with_act else None,
+                           pool_actout_kind=L.ACT_ELU if with_act else L.ACT_NONE)
+    finally:
+        ops.AUTOTUNE = old
+    hi()
+    torch.cuda.synchronize()
+    assert rel(got, to_nchw(pooled, cin)) < 2 * TOL[dtype]
+    # refused, not silently replaced, when the map is below one tile or the weights are the 3x3 ones
+    small = torch.zeros(B, 16, 32, pc.cout_pad, dtype=dtype, device=DEV)
+    with pytest.raises(ValueError):
+        ops.deconv_dgrad_call(dtype, small, pc, B, torch.zeros(B, 8, 16, pc.cin_pad, dtype=dtype, device=DEV), None)
+
+
 DEEP_CASES = [  # B, groups, Cout, H, W (input), stride, upsampled first source, bias, act, residual, activation-gradient operand
     (8, [512], 512, 8, 16, 1, False, True, L.ACT_ELU, False, False),    # conv5_1.conv1 at the bench size: one image per tile
     (8, [512], 512, 4, 8, 1, False, True, L.ACT_NONE, True, True),      # conv6_1.conv2: four images per tile, residual + activation gradient
