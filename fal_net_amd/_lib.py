@@ -60,7 +60,7 @@ class Wgrad(C.Structure):
                 ("tap_dy", C.c_int32 * 9), ("tap_dx", C.c_int32 * 9), ("isy", C.c_int32), ("isx", C.c_int32),
                 ("B", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("cin_total", C.c_int32),
                 ("nsplit", C.c_int32), ("partial", C.c_void_p), ("dtype", C.c_int32), ("variant", C.c_int32), ("bias_grad", C.c_void_p),
-                ("cout", C.c_int32)]
+                ("cout", C.c_int32), ("up2", C.c_int32)]
 
 
 class ReduceDesc(C.Structure):
@@ -175,7 +175,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 502
+EXPECTED_VERSION = 503
 
 
 def lib():

@@ -3356,6 +3356,7 @@ static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
     const int w_rows = round32(p.gC);
     const bool h16 = p.dtype == FALNET_BF16 || p.dtype == FALNET_F16;
     const bool canon = canonical_taps9(p);
+    if (p.up2 && p.variant != 7) { falnet_set_error("wgrad: up2 (a deconv layer's gradient on the low-resolution grid) is a mode of variant 7 only"); return WGK_BAD; }
     if (p.variant == 6) {  // first layer: planar f32 3-channel source (src[0].ptr = [B][3][IH][IW] f32), 16-bit gout, Cout 32
         const bool ok = h16 && canon && p.isy == 1 && p.isx == 1 && p.TH == p.IH && p.TW == p.IW && p.gC == 32 && w_rows == 32 && p.cin_total == 32 && p.nsrc == 1;
         if (!ok) { falnet_set_error("wgrad: variant 6 is the Cin=3 / Cout=32 first layer in bf16 / f16 (dense 3x3, cin_total 32)"); return WGK_BAD; }
@@ -3372,7 +3373,7 @@ static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
         return WGK_ROWS_S2;
     }
     if (p.variant == 7) {
-        if (!falnet_wgrad_rows_applicable(p)) { falnet_set_error("wgrad: variant 7 needs a 16-bit dense 3x3 stride-1 launch with sources at the launch size or half of it"); return WGK_BAD; }
+        if (!falnet_wgrad_rows_applicable(p)) { falnet_set_error("wgrad: variant 7 needs a 16-bit dense 3x3 stride-1 launch with sources at the launch size or half of it (up2: ONE source at the launch size, nsplit a multiple of 4)"); return WGK_BAD; }
         return WGK_ROWS;
     }
     // dense 3x3 stride-1 -> halo-patch kernel (one slab per workgroup; nsplit = pixel-range splits)

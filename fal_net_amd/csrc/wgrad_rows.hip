@@ -705,7 +705,16 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8_kernel(const fa
 //   * operand = [16 channels x 32 pixels]: 16-lane group g reads pixels 8g .. 8g+7 (two ds_read_b64_tr_b16 of four pixel rows each), so a 32-lane
 //     half reads two blocks 8 pixels apart in the same columns: besides the 64-B half exchange on pixel bit 1 the 32-B quarters are exchanged on
 //     pixel bit 3 (source-side, as everything the DMA writes): conflict-free for every column offset and both reads (exhaustive check).
-template <typename T, int D, int SPB>
+//
+// UP2 (falnet_wgrad_t::up2, round 5): the weight gradient of a `deconv` layer (nearest 2x upsampling + 3x3 convolution, FAL_netB.py:52-58) on the
+// LOW-resolution grid.  up(x)[2y + py + ky - 1] is x[y + ((py + ky - 1) >> 1)]: for output parity py the taps ky that read the same x row fall
+// together, so  dW[ky][kx] = sum over the four parities (py, px) of S[py, px][ky', kx']  with
+//   S[py, px][ky', kx'] = sum_{y, x} g[2y + py, 2x + px] x[y + ky' - 1, x + kx' - 1],  ky' in {py, py + 1}, kx' in {px, px + 1}
+// (py = 0: ky 0 <- ky' 0, ky 1 and 2 <- ky' 1;  py = 1: ky 0 and 1 <- ky' 1, ky 2 <- ky' 2) -- 16 instead of 36 tap products per low-resolution
+// position.  A split is (parity class, pixel range): its workgroups stream the class's quarter of g (pixel stride 2 gC, row stride 2 rows: the
+// LDS-DMA names every source pixel anyway) against x at its own size, issue 4 of the 9 tap products, and write the slab of the FULL 3x3 gradient's
+// share of that class -- every slab element once -- so the batched slab reduce sums classes and pixel ranges alike.
+template <typename T, int D, int SPB, bool UP2>
 __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
     constexpr int NS = D + SPB;
     static_assert(D >= 1 && D <= 4 && (SPB == 1 || SPB == 2) && D >= SPB, "prefetch distance / steps per barrier");
@@ -731,7 +740,9 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const f
     const int rsel = wave >> 2, pw = wave & 3;   // DMA role: row of the step's pair, 8-pixel piece
     const int H = p.TH, TW = p.TW, gC = p.gC, IH = p.IH;
     const int R = p.B * nstrips * H;
-    const int u0 = (int)((int64_t)R * split / nsplit), u1 = (int)((int64_t)R * (split + 1) / nsplit);
+    const int py = UP2 ? (split >> 1) & 1 : 0, px = UP2 ? split & 1 : 0;  // parity class of this split (UP2: splits = (pixel range, class))
+    const int sub = UP2 ? split >> 2 : split, nsub = UP2 ? nsplit >> 2 : nsplit;
+    const int u0 = (int)((int64_t)R * sub / nsub), u1 = (int)((int64_t)R * (sub + 1) / nsub);
 
     // ---- per-lane DMA geometry: lane = (pixel pl of an 8-pixel piece, 16-B position cpos of its 128-B line); the chunk it FETCHES is swizzled ----
     const int pl = lane >> 3, cpos = lane & 7;
@@ -770,8 +781,14 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const f
     auto item_pointers = [&](const Wr8Item& c) {
         const int gx = c.x0 + 8 * pw + pl;
         const bool g_ok = g_chok && gx < TW;
-        gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H + c.y0 + rsel) * TW + gx) * gC + co0 + 8 * gch) : zero_page;
-        g_inc = g_ok ? (unsigned)(2 * TW * gC * (int)sizeof(T)) : 0u;
+        if constexpr (UP2) {  // row 2 (y0 + rsel) + py, pixel 2 gx + px of the upstream gradient at 2H x 2W
+            gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) +
+                                                        ((((int64_t)c.b * 2 * H + 2 * (c.y0 + rsel) + py) * (2 * TW)) + 2 * gx + px) * gC + co0 + 8 * gch) : zero_page;
+            g_inc = g_ok ? (unsigned)(8 * TW * gC * (int)sizeof(T)) : 0u;
+        } else {
+            gptr = g_ok ? reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.gout) + (((int64_t)c.b * H + c.y0 + rsel) * TW + gx) * gC + co0 + 8 * gch) : zero_page;
+            g_inc = g_ok ? (unsigned)(2 * TW * gC * (int)sizeof(T)) : 0u;
+        }
         const int i = c.y0 - 1 + rsel;
         const int64_t rowoff = (int64_t)c.b * l_sb + (int64_t)(i >> l_hs) * l_sy;
         const unsigned xi = (unsigned)((l_hs ? l_sy : 2 * l_sy) * (int)sizeof(T));
@@ -931,21 +948,24 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const f
         {
             const int t2 = m_t2;
             auto vr = [&](int r) { return m_have && (unsigned)r < (unsigned)m_n; };
+            auto tap_on = [&](int par, int k) { return !UP2 || k == par || k == par + 1; };  // UP2: the class's two tap rows / columns
             auto mm = [&](int dy, const s16x8 (&A)[2], const s16x8 (&X)[3]) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (!tap_on(px, dx)) continue;  // (workgroup-uniform)
 #pragma unroll
                     for (int cc = 0; cc < 2; ++cc) acc[dy][dx][cc] = H16<T>::mma16(A[cc], X[dx], acc[dy][dx][cc]);
+                }
             };
-            if (a_live && m_vx0 && vr(t2)) mm(0, n_a, xa);      // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
+            if (a_live && m_vx0 && vr(t2) && tap_on(py, 0)) mm(0, n_a, xa);      // input row j = 2t meets gout rows 2t (ky 0), 2t-1 (ky 1), 2t-2 (ky 2)
             piece(0);
-            if (a_live && m_vx0 && vr(t2 - 1)) mm(1, w_b, xa);
-            if (a_live && m_vx0 && vr(t2 - 2)) mm(2, w_a, xa);
+            if (a_live && m_vx0 && vr(t2 - 1) && tap_on(py, 1)) mm(1, w_b, xa);
+            if (a_live && m_vx0 && vr(t2 - 2) && tap_on(py, 2)) mm(2, w_a, xa);
             piece(1);
-            if (a_live && m_vx1 && vr(t2 + 1)) mm(0, n_b, xb);  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
-            if (a_live && m_vx1 && vr(t2)) mm(1, n_a, xb);
+            if (a_live && m_vx1 && vr(t2 + 1) && tap_on(py, 0)) mm(0, n_b, xb);  // input row j = 2t+1 meets gout rows 2t+1, 2t, 2t-1
+            if (a_live && m_vx1 && vr(t2) && tap_on(py, 1)) mm(1, n_a, xb);
             piece(2);
-            if (a_live && m_vx1 && vr(t2 - 1)) mm(2, w_b, xb);
+            if (a_live && m_vx1 && vr(t2 - 1) && tap_on(py, 2)) mm(2, w_b, xb);
             if (do_issue) advance_issue(g);
             if (m_have) {
                 if (do_bias) {  // rows outside the item arrive as zeros
@@ -978,19 +998,27 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const f
     }
     const int ci = ci0 + 16 * a_q + i16;
     if (ci < p.cin_total) {
+        // UP2: tap k of the 3x3 gradient takes the class's product k' (par = 0: 0 <- 0, 1 and 2 <- 1; par = 1: 0 and 1 <- 1, 2 <- 2)
+        auto feeds = [&](int par, int kp, int k) { return !UP2 ? kp == k : (par == 0 ? (kp == 0 ? k == 0 : (kp == 1 && k >= 1)) : (kp == 1 ? k <= 1 : (kp == 2 && k == 2))); };
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                float* dst = p.partial + (((int64_t)split * 9 + dy * 3 + dx) * w_rows) * p.cin_total;
+            for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        const int co = co0 + 32 * c_t + 16 * cc + 4 * g16 + f;
-                        if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dy][dx][cc][f];
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (!UP2 && (ky != dy || kx != dx)) continue;
+                        if (!(feeds(py, dy, ky) && feeds(px, dx, kx))) continue;  // (workgroup-uniform)
+                        float* dst = p.partial + (((int64_t)split * 9 + ky * 3 + kx) * w_rows) * p.cin_total;
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) {
+                                const int co = co0 + 32 * c_t + 16 * cc + 4 * g16 + f;
+                                if (co < w_rows) dst[(int64_t)co * p.cin_total + ci] = acc[dy][dx][cc][f];
+                            }
                     }
-            }
     }
 }
 
@@ -1358,6 +1386,8 @@ bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p) {
     }
     if (ctot != p.cin_total) return false;
     if ((int64_t)p.B * ((p.TW + WR_TW - 1) / WR_TW) * p.TH >= (1ll << 30)) return false;
+    // up2: gout is the upstream gradient at [B][2 TH][2 TW][gC], ONE source at the launch size, splits in whole groups of the four parity classes
+    if (p.up2 && (p.nsrc != 1 || p.src[0].H != p.IH || p.src[0].W != p.IW || p.nsplit < 4 || (p.nsplit & 3) || (int64_t)8 * p.TW * p.gC * 2 >= (1ll << 31))) return false;
     return true;
 }
 
@@ -1412,7 +1442,12 @@ int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st) {
     }
 #endif
     // the product kernel: v_mfma_f32_16x16x32 (round 5: -7 % on the launches alone, -0.9 % on the step: profiles/r05_ab_rows16.txt)
-    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<f16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<bf16_t, 4, 2>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    if (p.up2) {  // a `deconv` layer's weight gradient on the low-resolution grid: splits = (pixel range, parity class)
+        if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<f16_t, 4, 2, true>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<bf16_t, 4, 2, true>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+        FALNET_RETURN_LAUNCH();
+    }
+    if (p.dtype == FALNET_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<f16_t, 4, 2, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_rows16_kernel<bf16_t, 4, 2, false>), grid, dim3(WR8_THREADS), 0, st, p, w_rows, ntci, ntiles, nstrips);
     FALNET_RETURN_LAUNCH();
 }

@@ -27,6 +27,8 @@ AUTOTUNE = os.environ.get("FALNET_AUTOTUNE", "1") != "0"
 # timing launches, whose winner can differ from run to run --, no split-K (f32 atomics), one writer per element in the slab reduce,
 # bias gradients through the two-pass ordered form; the library side is falnet_set_deterministic (fal_net_amd/_lib.py sets it).
 DETERMINISTIC = L.DETERMINISTIC
+UP2W = L.ab("FALNET_UP2W", "0") == "1"  # deconv weight gradients on the low-resolution grid (falnet_wgrad_t::up2): correct and tested, NOT faster -- the
+# row-streaming kernel's step is bound by its DMA / barrier cadence, not by its MFMAs (profiles/r05_ab_up2w.txt) -- so off by default
 UP2D = L.ab("FALNET_UP2D", "1") == "1"  # deconv data gradients on the low-resolution grid (falnet_conv2d variant 26) among the plan's candidates
 
 
@@ -611,7 +613,7 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
     return best
 
 
-def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_pad, max_slabs, target_wgs=1536):
+def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_pad, max_slabs, target_wgs=1536, up2=False):
     """(variant, nsplit, kernel symbol) of one weight-gradient launch -- the host-side mirror of conv.hip's kernel choice
     (falnet_wgrad re-checks the variant and fails loudly; whether the bias gradient is fused is ASKED from the library,
     falnet_wgrad_fuses_bias, never re-derived here)."""
@@ -637,11 +639,18 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         sym = f"_Z18wgrad3x3_s2_kernelI{tn}Li{2 if cout_pad % 64 == 0 else 1}EEv14falnet_wgrad_tiiii"
     elif _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
-        units = B * ((TW + 31) // 32) * TH
+        units = B * ((TW + 31) // 32) * TH * (4 if up2 else 1)  # up2: every parity class walks the whole low-resolution grid
         nsplit = max(1, min(_WGRAD_ROWS_WGS // tiles, units // _WGRAD_ROWS_MIN_ROWS))
         if nsplit >= 8:
             nsplit -= nsplit % 8  # multiples of 8: the channel tiles of one pixel range then share an XCD
-        variant, sym = 7, f"_Z22wgrad3x3_rows16_kernelI{tn}Li4ELi2EEv14falnet_wgrad_tiiii"
+        if up2:
+            nsplit = max(4, nsplit - nsplit % 4)  # whole groups of the four parity classes
+            max_slabs -= max_slabs % 4
+            if max_slabs < 4:
+                raise ValueError("up2 weight gradient: the slab budget holds fewer than four slabs")
+        variant, sym = 7, f"_Z22wgrad3x3_rows16_kernelI{tn}Li4ELi2ELb{int(up2)}EEv14falnet_wgrad_tiiii"
+    elif up2:
+        raise ValueError("up2 weight gradient: the row-streaming kernel does not apply")
     elif dense:
         co2 = _wgrad_co2(dtype, dense, cin_pad, cout_pad)
         tiles = (cin_pad // 32) * (cout_pad // 32) // (2 if co2 else 1)
@@ -680,18 +689,19 @@ def _fuse_bias(lib, d, grad_b):
 
 
 def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, ws, target_wgs=1536,
-                name="wgrad", flops=0):
+                name="wgrad", flops=0, up2=False):
     """Weight (+bias) gradient of one conv: split-K partial slabs in `ws`, then a reduce into the
-    OIHW f32 views `grad_w` / `grad_b`.  Returns a callable taking (accumulate)."""
+    OIHW f32 views `grad_w` / `grad_b`.  Returns a callable taking (accumulate).  up2: as WgradBatch.add."""
     lib = L.lib()
     d = L.Wgrad()
     _fill_wgrad(d, dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc)
     gC = gout.shape[-1]
-    M = B * TH * TW
+    M = B * TH * TW * (4 if up2 else 1)
     slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
     d.variant, nsplit, sym = _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, pc.cin_pad, pad_c(gC), ws.numel() * 4 // slab,
-                                         target_wgs)
+                                         target_wgs, up2=up2)
     d.nsplit = nsplit
+    d.up2 = int(up2)
     d.partial = ws.data_ptr()
     assert lib.falnet_wgrad_workspace_bytes(C.byref(d)) <= ws.numel() * 4, "wgrad workspace too small"
     ref = C.byref(d)
@@ -785,15 +795,19 @@ class WgradBatch:
         self.ws = None
         self.accumulate = 1  # set per backward by the plan: 0 = the step's gradient buffer was zeroed, single-writer entries may overwrite
 
-    def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0, bucket=0):
+    def add(self, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_w, grad_b, name="wgrad", flops=0, bucket=0, up2=False):
+        """up2: the weight gradient of a `deconv` layer on the LOW-resolution grid (falnet_wgrad_t::up2): `gout` at [B][2 TH][2 TW][gC], the one
+        source at TH x TW = IH x IW; ValueError when the row-streaming kernel does not apply."""
         lib = L.lib()
         d = L.Wgrad()
         _fill_wgrad(d, self.dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc)
         gC = gout.shape[-1]
-        M = B * TH * TW
+        M = B * TH * TW * (4 if up2 else 1)
         slab = len(taps) * pad_c(gC) * pc.cin_pad * 4
-        d.variant, nsplit, sym = _wgrad_plan(self.dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, pc.cin_pad, pad_c(gC), max(1, self.SLAB_CAP // slab))
+        d.variant, nsplit, sym = _wgrad_plan(self.dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, pc.cin_pad, pad_c(gC), max(1, self.SLAB_CAP // slab),
+                                             up2=up2)
         d.nsplit = nsplit
+        d.up2 = int(up2)
         ref = C.byref(d)
         keep = (d, srcs, gout, grad_w, grad_b)
 

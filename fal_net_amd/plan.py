@@ -249,11 +249,29 @@ class FalnetPlan:
             else:
                 self.bwd_body.append(chosen)
 
-    def _wgrad(self, pc, srcs, IH, IW, gout, name="", on_main=False):
+    def _wgrad(self, pc, srcs, IH, IW, gout, name="", on_main=False, up2=False):
+        """up2: a `deconv` layer (its one source sits at exactly half of gout's map): the gradient is taken on the LOW-resolution grid where the
+        row-streaming kernel applies (falnet_wgrad_t::up2: 16 instead of 36 tap products per position), else on gout's grid as every other layer's."""
         OH, OW = gout.shape[1], gout.shape[2]
         self._buckets_seen = getattr(self, "_buckets_seen", set()) | {self._bucket}
         gw = self.model._grad_view(pc.weight)
         gb = self.model._grad_view(pc.bias) if pc.bias is not None else None
+        def route(call):
+            if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
+                self._main_tail = getattr(self, "_main_tail", [])
+                self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)
+            elif OH * OW <= self._deep_max_px or (self._deep_alt and self._alt_toggle()):
+                self._deep_call(call)
+            else:
+                self._side_call(call)
+        if up2 and len(srcs) == 1 and pc.stride == 1 and pc.taps == 9 and self.dtype in ops.H16 and ops.UP2W:
+            try:
+                lh, lw = OH // 2, OW // 2
+                route(self.wbatch.add(srcs, lh, lw, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], 1, self.B, lh, lw, pc, gw, gb,
+                                      name="wgrad(low-res) " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps, bucket=self._bucket, up2=True))
+                return
+            except ValueError:
+                pass
         if (len(srcs) == 2 and pc.groups_pad == [64, 32] and pc.stride == 1 and pc.taps == 9 and self.dtype in ops.H16
                 and L.ab("FALNET_SPLIT_WGRAD_96", "1") == "1"):
             # 64 + 32 input channels (the logits conv over concat(deconv1, conv0_1)): the row-streaming kernel works on 64 x 64 channel
@@ -293,13 +311,7 @@ class FalnetPlan:
             call = self.wbatch.add(srcs, IH, IW, gout, [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(pc.ksize)], pc.stride, self.B, OH, OW,
                                    pc, gw, gb, name="wgrad " + name, flops=2 * self.B * OH * OW * pc.cout * pc.cin * pc.taps,
                                    bucket=self._bucket)
-        if on_main:  # tail balancing: the main stream has nothing left to do once its last data gradient is out
-            self._main_tail = getattr(self, "_main_tail", [])
-            self._main_tail.append(call)  # queued behind the LAST data gradient (flushed at the end of the encoder loop)
-        elif OH * OW <= self._deep_max_px or (self._deep_alt and self._alt_toggle()):
-            self._deep_call(call)
-        else:
-            self._side_call(call)
+        route(call)
 
     def _alt_toggle(self):
         self._alt_n += 1
@@ -581,7 +593,7 @@ class FalnetPlan:
                 g_dpre = self._act(f"g_d{lvl}", hh, ww, dch)
                 self._dgrad(pci, 0, gi, g_dpre, hh, ww, actout=d[lvl], name=iname + "[deconv]")
                 self._dgrad(pci, 1, gi, gc[lvl - 1], hh, ww, name=iname + "[skip]")  # first writer of g_c{lvl-1}
-                self._wgrad(pcd, [ops.nhwc_src(below)], hh, ww, g_dpre, name=dname)
+                self._wgrad(pcd, [ops.nhwc_src(below)], hh, ww, g_dpre, name=dname, up2=(2 * below.shape[1], 2 * below.shape[2]) == (hh, ww))
                 below_ch = below.shape[3]
                 if (bh, bw) == (hh, ww):  # degenerate: no resize
                     tgt = gc[6] if lvl == 6 else self._act(f"g_i{lvl + 1}", bh, bw, below_ch)

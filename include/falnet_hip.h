@@ -211,6 +211,11 @@ typedef struct {
                                   falnet_wgrad returns -3 when it is set for a launch whose kernel cannot */
     int32_t cout;              /* real output channels (<= gC): bound of the fused bias gradient (bias_grad holds `cout` floats);
                                   0 = gC */
+    int32_t up2;               /* variant 7 only, else 0.  != 0: the weight gradient of a `deconv` layer (nearest 2x upsampling + 3x3 convolution,
+                                  FAL_netB.py:52-58) on the LOW-resolution grid: `gout` is the upstream gradient at [B][2 TH][2 TW][gC], the one source
+                                  the layer's input at TH x TW (= IH x IW); nsplit = 4 x pixel ranges (split = 4 range + 2 py + px): a split multiplies
+                                  the gout pixels of its parity class with the 2 x 2 input offsets they meet (16 instead of 36 tap products per
+                                  position) and writes its share of the full 3x3 slab, so the slab reduce is unchanged */
 } falnet_wgrad_t;
 /* 1 when the kernel falnet_wgrad selects for this descriptor sums the bias gradient itself (bias_grad honoured), else 0 */
 int falnet_wgrad_fuses_bias(const falnet_wgrad_t* p);

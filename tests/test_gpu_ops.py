@@ -1187,6 +1187,52 @@ def test_wgrad_rows(case, dtype):
             assert rel(gb, b.grad) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cin,cout,h,w,bias", [
+    (2, 64, 64, 9, 33, True),      # ragged strip, odd row count
+    (1, 128, 64, 16, 40, True),    # two input-channel tiles
+    (2, 256, 128, 12, 32, False),  # 4 x 2 channel tiles
+    (1, 96, 49, 10, 70, True),     # gradient channels 49 -> 64, input channels 96: second block half empty
+    (8, 64, 64, 24, 64, True),     # many units: 8-aligned split counts take the XCD-grouped block mapping
+])
+def test_wgrad_rows_deconv_lowres(B, cin, cout, h, w, bias, dtype):
+    """falnet_wgrad_t::up2 (wgrad3x3_rows16_kernel<..., true>): the weight gradient of a `deconv` layer (FAL_netB.py:52-58, nearest x2 then 3x3 conv)
+    on the LOW-resolution grid -- per parity class of the upstream gradient the four tap products that class meets, written as that class's share
+    of the full 3x3 slab -- against autograd through F.interpolate + F.conv2d on the rounded operands, for several split counts (whole groups of
+    the four classes; ranges that cut columns at arbitrary rows), AND against the high-resolution form of the same kernel."""
+    g = torch.Generator().manual_seed(h * w + cout + 7 * cin)
+    x = torch.randn(B, cin, h, w, generator=g)
+    go = torch.randn(B, cout, 2 * h, 2 * w, generator=g)
+    xr, gr = x.to(dtype).float(), go.to(dtype).float()
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    bt = torch.zeros(cout, requires_grad=True)
+    (F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), wt, bt, padding=1) * gr).sum().backward()
+    pc = packed(wt.detach(), bt.detach() if bias else None, [cin], 1, torch.bfloat16)
+    x_t, g_t = _nhwc_torch(x, dtype), _nhwc_torch(go, dtype)
+    ws = torch.empty(16 << 20, device=DEV)
+    taps = [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)]
+    max_slabs = ws.numel() * 4 // (9 * ops.pad_c(cout) * pc.cin_pad * 4)
+    for nsplit in (4, 8, 12, 40, 64):
+        gw = torch.full(wt.shape, float("nan"), device=DEV)
+        gb = torch.full((cout,), float("nan"), device=DEV) if bias else None
+        call = ops.wgrad_calls(dtype, [ops.nhwc_src(x_t)], h, w, g_t, taps, 1, B, h, w, pc, gw, gb, ws, up2=True)
+        assert call.desc.variant == 7 and call.desc.up2 == 1 and call.desc.nsplit % 4 == 0
+        call.desc.nsplit = min(nsplit, max_slabs - max_slabs % 4)
+        call(0)
+        assert rel(gw, wt.grad) < 2e-5, (nsplit, rel(gw, wt.grad))
+        if bias:
+            assert rel(gb, bt.grad) < 2e-5
+    # the same layer through the high-resolution form (source upsampled on the fly by the same kernel)
+    gw2 = torch.full(wt.shape, float("nan"), device=DEV)
+    hi = ops.wgrad_calls(dtype, [ops.nhwc_src(x_t)], 2 * h, 2 * w, g_t, taps, 1, B, 2 * h, 2 * w, pc, gw2, None, ws)
+    assert hi.desc.variant == 7 and hi.desc.up2 == 0
+    hi(0)
+    assert rel(gw, gw2) < 2e-5
+    # a split count that is not a whole number of class groups is refused
+    call.desc.nsplit = 6
+    assert L.lib().falnet_wgrad(C.byref(call.desc), L.stream_ptr()) != 0
+
+
 def test_launch_from_a_fresh_thread_and_side_stream():
     """SURVEY 8b threading contract: launches are issued from autograd's worker thread too.  Every entry point makes the device of
     the stream it is given current on the calling thread (hipStreamGetDevice + hipSetDevice), so a brand-new thread works."""

@@ -9,7 +9,7 @@ from fal_net_amd import _lib as L, ops
 
 DEV, B = "cuda", 8
 dtype = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.bfloat16
-LAYERS = [  # name, groups, Cout, H, W, upsample_from
+LAYERS = [  # name, groups, Cout, H, W, upsample_from  (BENCH_LAYERS: comma-separated substrings)
     ("deconv1 64->64 @256x512 (up)", [64], 64, 256, 512, (128, 256)),
     ("logits 64+32->49 @256x512", [64, 32], 49, 256, 512, None),
     ("conv1_1 64->64 @128x256", [64], 64, 128, 256, None),
@@ -24,6 +24,8 @@ LAYERS = [  # name, groups, Cout, H, W, upsample_from
     ("conv4_1 256->256 @16x32", [256], 256, 16, 32, None),
     ("iconv5 128+256->256 @16x32", [128, 256], 256, 16, 32, None),
 ]
+if os.environ.get("BENCH_LAYERS"):
+    LAYERS = [l for l in LAYERS if any(k in l[0] for k in os.environ["BENCH_LAYERS"].split(","))]
 cold = os.environ.get("COLD") == "1"
 flush = torch.empty(768 << 20, dtype=torch.uint8, device=DEV) if cold else None
 splits = [int(x) for x in os.environ.get("ROWS_WGS", "512").split(",")]
@@ -48,6 +50,11 @@ for name, groups, cout, H, W, up in LAYERS:
         ops._WGRAD_ROWS_WGS = wgs
         c = ops.wgrad_calls(dtype, srcs, H, W, gout, taps, 1, B, H, W, pc, gw, None, ws)
         cands.append((f"rows{wgs} n{c.desc.nsplit}", c))
+    if up and (2 * up[0], 2 * up[1]) == (H, W) and len(groups) == 1:  # the deconv layer's gradient on the low-resolution grid (falnet_wgrad_t::up2)
+        for wgs in splits:
+            ops._WGRAD_ROWS_WGS = wgs
+            c = ops.wgrad_calls(dtype, srcs, up[0], up[1], gout, taps, 1, B, up[0], up[1], pc, gw, None, ws, up2=True)
+            cands.append((f"lowres{wgs} n{c.desc.nsplit}", c))
     flops = 2.0 * B * H * W * cout * cin * 9
     times = {k: [] for k, _ in cands}
     ref = None
