@@ -1233,6 +1233,20 @@ def test_wgrad_rows_deconv_lowres(B, cin, cout, h, w, bias, dtype):
     assert L.lib().falnet_wgrad(C.byref(call.desc), L.stream_ptr()) != 0
 
 
+def test_mfma_probe_runs_and_rejects_bad_arguments():
+    """falnet_mfma_probe (bench.py: roofline.sustained_mfma): a measurement kernel -- it must launch on both 16-bit types, leave `out` alone on finite
+    data and refuse f32 / null operands / a non-positive iteration count."""
+    out = torch.full((4,), 7.0, device=DEV)
+    for dt in (torch.bfloat16, torch.float16):
+        ab = torch.randn(64 * 8 * 64 * 8, device=DEV).to(dt)
+        assert L.lib().falnet_mfma_probe(L.ptr(ab), L.ptr(out), 4, L.dtype_code(dt), L.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), torch.full((4,), 7.0))
+    assert L.lib().falnet_mfma_probe(L.ptr(ab), L.ptr(out), 0, L.dtype_code(torch.bfloat16), L.stream_ptr()) != 0
+    assert L.lib().falnet_mfma_probe(L.ptr(ab), L.ptr(out), 4, L.dtype_code(torch.float32), L.stream_ptr()) != 0
+    assert L.lib().falnet_mfma_probe(L.ptr(None), L.ptr(out), 4, L.dtype_code(torch.bfloat16), L.stream_ptr()) != 0
+
+
 def test_launch_from_a_fresh_thread_and_side_stream():
     """SURVEY 8b threading contract: launches are issued from autograd's worker thread too.  Every entry point makes the device of
     the stream it is given current on the calling thread (hipStreamGetDevice + hipSetDevice), so a brand-new thread works."""
