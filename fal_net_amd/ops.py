@@ -734,7 +734,8 @@ def wgrad_calls(dtype, srcs, IH, IW, gout, taps, stride_in, B, TH, TW, pc, grad_
 
 
 _FUSED_BIAS = L.ab("FALNET_FUSED_BIAS", "1") == "1"  # bias gradients inside the halo weight-gradient kernels
-_WGRAD_WGS = int(L.ab("FALNET_WGRAD_WGS", "512"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles)
+_WGRAD_WGS = int(L.ab("FALNET_WGRAD_WGS", "256"))  # workgroups per dense weight-gradient launch (split-K factor = this / channel tiles): one per CU.  512 was the
+# setting of rounds 2-4; with the round-5 kernels 256 is 0.4 % faster on the step on two boxes and halves these layers' slab bytes (profiles/r05_ab_wgrad_wgs.txt)
 
 
 _WGRAD_ROWS_WGS = int(L.ab("FALNET_WGRAD_ROWS_WGS", "128"))  # workgroups (one per CU, eight waves) per row-streaming weight-gradient launch: half the chip,
