@@ -373,6 +373,35 @@ def allreduce_report(model, step, args, world, rank, dev, ms_per_step):
             "isolated_vs_ring_bound": (ring_ms / iso["whole_buffer"]) if iso["whole_buffer"] > 0 else None}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>` as a child process and return its exit code.  Lines are relayed as they come; a JSON result line
+    is held back and printed LAST (the driver reads the last line of stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool: RCCL needs it across processes
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks as child processes: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -400,15 +429,29 @@ def main():
     if args.dtype is None:
         args.dtype = "f16" if args.workload == "highres" else "bf16"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed as is: this process becomes the launcher.  It has not touched the GPU (no HIP call above this line) and
+        # never will: the N ranks are CHILD processes of torch.distributed.run (never an exec), their output is relayed, rank 0's JSON line stays last.
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or leave WORLD_SIZE unset and let bench.py start them)")
     # FALNET_DIST_BACKEND=gloo (tests): the N > 1 path of this script on a box with fewer GPUs than ranks -- ranks then share devices
     # (RCCL itself refuses two ranks on one device and stays the backend of every real run)
     backend = os.environ.get("FALNET_DIST_BACKEND", "nccl")
+    if os.environ.get("FALNET_BENCH_DRYRUN") == "1":
+        # launch-path check (tests, CPU box): rendezvous + one collective over gloo, no GPU call, no measurement -- the line says so
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run of the launch path (no measurement)", "value": None, "dry_run": True, "n_gpus": world, "ranks_seen": int(t.item())}), flush=True)
+        return 0
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -596,4 +639,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

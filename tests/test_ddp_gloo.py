@@ -141,3 +141,32 @@ def test_real_model_broadcast_and_bucketed_allreduce(tmp_path):
     assert r0["n_async"] == 4 and r0["n_acc"] == 0 and r0["scale"] == 0.5
     n = r0["g"].numel()
     assert torch.equal(r0["g"], torch.arange(n, dtype=torch.float32) % 97 * 3)  # every element summed over both ranks exactly once
+
+
+def test_bench_gpus2_self_launches_its_ranks():
+    """`python3 bench.py --gpus 2` typed as is (no torchrun, WORLD_SIZE unset): the script must start its two ranks as child processes of
+    torch.distributed.run instead of exiting 1 at argument handling.  FALNET_BENCH_DRYRUN=1 stops each rank after the
+    rendezvous and one gloo collective, before any GPU call, so this runs on the CPU box; the GPU form is tests/test_gpu_step.py:
+    test_bench_two_ranks_reports_allreduce[self]."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FALNET_DIST_BACKEND="gloo", FALNET_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    d = json.loads(last)  # the JSON line is the LAST line of stdout
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["ranks_seen"] == 2
+
+
+def test_bench_gpus_mismatch_is_refused():
+    """WORLD_SIZE set by a launcher but different from --gpus: refused with a message (not silently benchmarked at another size)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", FALNET_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

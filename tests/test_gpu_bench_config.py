@@ -57,13 +57,13 @@ def _f32_stage1():
     return _F32["s1"]
 
 
-def _f32_det(shape, tmp_path_factory):
+def _f32_det(shape, tmp_path_factory, stage2=False):
     """The f32 HIP step of `shape` from a fresh process in deterministic mode (tests/_f32_det_step.py): no atomics-order noise on the f32 side."""
-    key = ("det",) + tuple(shape)
+    key = ("det2" if stage2 else "det",) + tuple(shape)
     if key not in _F32:
         out = str(tmp_path_factory.mktemp("f32det") / "step.pt")
-        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_f32_det_step.py")] + [str(v) for v in shape] + [out],
-                           capture_output=True, text=True, timeout=1800)
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_f32_det_step.py")] + [str(v) for v in shape] + [out] +
+                           (["stage2"] if stage2 else []), capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         _F32[key] = torch.load(out)
     return _F32[key]
@@ -167,23 +167,26 @@ def _stage2(dtype):
     for q in fix.parameters():
         q.requires_grad_(False)
     out = train.stage2_step(m, fix, train.FlatAdam(m, lr=5e-5), left.to(DEV), right.to(DEV), mx.to(DEV))
+    inv = 1.0 / float(out["scaler"].state[0]) if out.get("scaler") is not None else 1.0  # f16: the raw gradients carry the loss scale
     res = {k: float(out[k]) for k in ("loss", "rec", "sm", "mirror")}
-    res.update(ldisp=out["ldisp"].detach().clone().cpu(), rdisp=out["rdisp"].detach().clone().cpu(), flat_grad=m.flat_gradients().clone())  # (cosine: scale-free)
+    res.update(ldisp=out["ldisp"].detach().clone().cpu(), rdisp=out["rdisp"].detach().clone().cpu(), flat_grad=m.flat_gradients().clone() * inv,
+               grads={k: p.grad.detach().float().cpu() * inv for k, p in m.named_parameters() if p.grad is not None})
     del m, fix
     LF.set_compute_dtype(torch.float32)
     return res
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_stage2_b8_16bit_vs_f32_hip(dt):
-    """Stage-2 (BASELINE configs[3]) at B=8/GPU: the 16-bit steps against the f32 HIP step (itself pinned to the oracle at
-    256x512 B=2 by tests/test_gpu_step.py::test_stage2_step_256x512_vs_oracle and to the reference by golden G3)."""
-    if "s2" not in _F32:
-        _F32["s2"] = _stage2(torch.float32)
-    ref, got = _F32["s2"], _stage2(dt)
+def test_stage2_b8_16bit_vs_f32_hip(dt, tmp_path_factory):
+    """Stage-2 (BASELINE configs[3]) at B=8/GPU, held to Stage-1's standard: the 16-bit steps against the DETERMINISTIC f32 HIP
+    Stage-2 step of the same inputs (itself pinned to the oracle at 256x512 B=2 by tests/test_gpu_step.py::test_stage2_step_256x512_vs_oracle and
+    to the reference by golden G3), per parameter tensor -- gradient norm within 3 % (bf16) / 0.5 % (f16), cosine >= 0.999 -- so a dropped K slice
+    in one Stage-2-only launch (the 2B-batch plans, falnet_mask_mix, the mirror loss's adjoint) cannot hide in a flat cosine; `rec`, `sm`, `mirror`
+    and the total are all asserted.  Reference: Train_Stage2_K.py:267-331."""
+    ref, got = _f32_det((B, H, W, N), tmp_path_factory, stage2=True), _stage2(dt)
     dev = {k: abs(got[k] - ref[k]) / abs(ref[k]) for k in ("loss", "rec", "sm", "mirror")}
-    cos = float(torch.nn.functional.cosine_similarity(got["flat_grad"].double(), ref["flat_grad"].double(), dim=0))
-    print(f"Stage-2 B=8 {dt} vs f32 HIP: {dev}, ldisp {rel(got['ldisp'], ref['ldisp']):.2e}, grad cosine {cos:.5f}")
-    assert torch.isfinite(got["flat_grad"]).all()
-    assert dev["loss"] < 3e-2 and dev["rec"] < 3e-2 and cos > 0.97
-    assert rel(got["ldisp"], ref["ldisp"]) < (1.5e-1 if dt == torch.bfloat16 else 3e-2)
+    print(f"Stage-2 B=8 {dt} vs deterministic f32 HIP: {dev}, rdisp {rel(got['rdisp'], ref['rdisp']):.2e}")
+    _compare_16bit(ref, got, dt, "Stage-2 B=8", loss_tol=3e-2, disp_tol=1.5e-1 if dt == torch.bfloat16 else 3e-2)
+    tol = 3e-2 if dt == torch.bfloat16 else 1e-2
+    assert dev["rec"] < tol and dev["sm"] < tol and dev["mirror"] < tol, dev
+    assert rel(got["rdisp"], ref["rdisp"]) < (1.5e-1 if dt == torch.bfloat16 else 3e-2)

@@ -577,21 +577,27 @@ def test_data_parallel_two_ranks_one_gpu(dtype_name, tmp_path):
     assert res["w_maxabs"] <= 4.2e-4  # two Adam steps of lr = 1e-4: at most +-lr per step on sign-unstable elements
 
 
-def test_bench_two_ranks_reports_allreduce():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on the one GPU of a test box over gloo
+@pytest.mark.parametrize("launch", ["torchrun", "self"])
+def test_bench_two_ranks_reports_allreduce(launch):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) AND typed as is (`python3 bench.py --gpus 2`,
+    WORLD_SIZE unset: the script starts its ranks as child processes itself), on the one GPU of a test box over gloo
     (FALNET_DIST_BACKEND): the line must carry n_gpus = 2, the whole-job rate, and the `allreduce` block -- both ranks seen, parameters still
     identical across ranks after the timed steps, isolated times per bucket, the step time without the collective and the exposed part."""
     import json
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    env = dict(os.environ, FALNET_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "128",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FALNET_DIST_BACKEND"] = "gloo"
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541"] \
+        if launch == "torchrun" else [sys.executable]
+    cmd = head + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "128",
            "--no-cpu-baseline", "--no-roofline", "--dtype", "f32"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    if launch == "self":
+        assert r.stdout.strip().splitlines()[-1] == line  # the relayed JSON is the LAST line of stdout
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     a = d["allreduce"]
