@@ -9,8 +9,9 @@ plans is fal_net_amd/models/FAL_netB.py; the kernels are fal_net_amd/csrc/.  Wha
   * `run_forward` / `run_backward`: eager issue for the first two passes, then recorded launch sequences replayed through `falnet_replay`
     (csrc/replay.cpp).  With a gradient-bucket hook (N > 1) the recorded backward is CUT at the bucket boundaries: the hook -- an asynchronous
     `torch.distributed.all_reduce` of that range of the flat gradient buffer -- is called from Python between two replayed segments;
-  * `stream_selftest`: two spin kernels on every pair of the plan's streams must overlap; HIP maps streams onto GPU_MAX_HW_QUEUES hardware
-    queues by creation order, and two busy streams of the step on ONE queue serialise it (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt).
+  * `StepStreams`: the side / third / auxiliary streams of a DEVICE (shared by all plans) and their self-test: two spin kernels on every pair of
+    the step's streams must overlap; HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues by creation order, and two busy streams of the step
+    on ONE queue serialise it (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt).
 """
 import torch
 
@@ -25,16 +26,10 @@ _TAIL_MAIN = "conv1_1.conv1"  # default of FALNET_TAIL_MAIN: extra weight gradie
 _TAIL_LEVELS = int(L.ab("FALNET_TAIL_LEVELS", "2"))  # encoder levels (from level 0) in the LAST gradient bucket
 
 
-_AUX_STREAMS = {}
-
-
 def aux_stream(device):
     """The auxiliary stream of a device (the label image's VGG pass beside the network forward, train.vgg_label_async): one per device, kept
-    here so that the stream self-test of a plan sees every stream the step keeps busy."""
-    key = (device.type, device.index)
-    if key not in _AUX_STREAMS:
-        _AUX_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _AUX_STREAMS[key]
+    beside the other streams of the step (StepStreams) so that the stream self-test sees every stream the step keeps busy."""
+    return StepStreams.for_device(device).aux
 
 
 def _spin_pair_ms(a, b, us=200):
@@ -99,6 +94,143 @@ def _spin_all_ms(streams, fn=None, us=200, rounds=3):
     return max(e0.elapsed_time(e) for e in ends)
 
 
+class StepStreams:
+    """The HIP streams a step keeps busy on ONE device besides the caller's -- side (full-resolution weight gradients, slab reduces, bucket
+    hooks), third (weight gradients below full resolution), auxiliary (the label image's VGG pass) -- shared by EVERY plan and model on that
+    device (Stage 2's teacher and student, several crop shapes), and their hardware-queue self-test, run once per (caller's stream, hook
+    state) and device, not per plan.
+
+    HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order; two BUSY streams of the step on one queue serialise it
+    (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt) and nothing in the API says which queue a stream got.  So measure it: on every
+    pair of (main, side, third, auxiliary) two 200-us spin kernels must take ~200 us, not ~400; an offending side / third / auxiliary stream
+    is replaced by a fresh one until the pair overlaps.  With a process group (`hooked`) the collective's own stream is in the picture too:
+    an all-reduce issued beside a spin on each stream must not wait for the spin.  That part issues collectives, so it is ALIGNED ACROSS
+    RANKS: it runs at an explicit collective point (train.enable_overlapped_allreduce, which every rank calls at the same place), every round
+    starts behind a barrier, and the measured times are MAX-reduced over the ranks before anything is decided -- every rank replaces the same
+    streams and takes the same third-stream decision, whatever skew it saw locally.  `generation` counts stream replacements:
+    a plan whose recorded launch sequences were made under another generation drops them (they hold raw stream handles)."""
+
+    _BY_DEVICE = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.side = torch.cuda.Stream(device=device)
+        self.third = torch.cuda.Stream(device=device)
+        self.aux = torch.cuda.Stream(device=device)
+        self.generation = 0
+        self.tested = set()       # (handle of the caller's stream, hooked) states already measured under the current generation
+        self.result = None        # last self-test record (bench.py prints it)
+        self.hooked_tested = False
+        self.third_with_hook = L.ab("FALNET_DEEP_WITH_HOOK", "1") == "1"  # third stream beside a bucket hook -- when the self-test found it a queue of its own
+
+    @classmethod
+    def for_device(cls, device):
+        device = torch.device(device)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in cls._BY_DEVICE:
+            cls._BY_DEVICE[key] = cls(torch.device(*key))
+        return cls._BY_DEVICE[key]
+
+    def ensure_tested(self, main, hooked):
+        """Run the self-test for this (caller's stream, hook state) unless it already ran under the current set of streams.  Flipping between
+        states (gradient accumulation in a data-parallel run: hooked, not hooked, hooked, ...) costs nothing after the first visit of each."""
+        if L.ab("FALNET_STREAM_SELFTEST", "1") != "1":
+            return
+        if (main.cuda_stream, bool(hooked)) in self.tested:
+            return
+        # the collective part runs once per device (normally at train.enable_overlapped_allreduce); a later visit from another caller's stream, or
+        # after a local replacement, repeats only the LOCAL pair part -- no rank ever issues a probe collective its peers do not
+        again = bool(hooked) and self.hooked_tested
+        self.selftest(main, hooked and not again)
+        if again:
+            self.tested.add((main.cuda_stream, True))
+
+    def selftest(self, main, hooked, tries=12):
+        dev = self.device
+        import os
+        dist = torch.distributed
+        with_group = bool(hooked) and dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if with_group else 1
+        roles = [("main", lambda: main, None), ("side", lambda: self.side, lambda s: setattr(self, "side", s)),
+                 ("third", lambda: self.third, lambda s: setattr(self, "third", s)), ("aux", lambda: self.aux, lambda s: setattr(self, "aux", s))]
+        coll = None
+        if with_group:
+            buf = torch.zeros(1 << 18, device=dev)
+
+            def coll():
+                dist.all_reduce(buf, async_op=True).wait()
+        log, accepted, replaced = [], [], 0
+        torch.cuda.synchronize(dev)
+        for name, get, put in roles:  # local part: no collectives, any rank may loop as long as it needs
+            n, worst = 0, 0.0
+            while True:
+                s = get()
+                worst = max([_spin_pair_ms(o, s) for _, o in accepted] + [0.0])
+                if worst < 0.3 or put is None or n >= tries:
+                    break
+                put(torch.cuda.Stream(device=dev))
+                n += 1
+                replaced += 1
+            log.append({"stream": name, "handle": hex(get().cuda_stream), "replaced": n, "worst_pair_ms": round(worst, 3)})
+            accepted.append((name, get()))
+        collective = None
+        if coll is not None:
+            # Every rank issues the SAME collectives whatever it measures: three fixed rounds, each behind a barrier, the per-stream times
+            # MAX-reduced over the ranks before the (then identical) replacement decisions; the replacement loops themselves are local.
+            coll()  # (first call: communicator / stream set-up outside the measurement)
+            torch.cuda.synchronize(dev)
+            for _ in range(3):
+                if world > 1:
+                    dist.barrier()
+                collective = {}
+                for i, (name, s) in enumerate(accepted):
+                    collective[name] = _spin_vs_call_ms(s, accepted[(i + 1) % len(accepted)][1], coll)
+                if world > 1:
+                    t = torch.tensor([collective[name] for name, _ in accepted], device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    collective = {name: float(v) for (name, _), v in zip(accepted, t.tolist())}
+                collective = {k: round(v, 3) for k, v in collective.items()}
+                for i, (name, s) in enumerate(accepted):
+                    if collective[name] <= 0.25 or name == "main":
+                        continue
+                    put = [r[2] for r in roles if r[0] == name][0]  # the collective's stream shares this stream's queue: move OUR stream
+                    for _t in range(tries):
+                        put(torch.cuda.Stream(device=dev))
+                        replaced += 1
+                        s = [r[1] for r in roles if r[0] == name][0]()
+                        if max(_spin_pair_ms(o, s) for nm, o in accepted if nm != name) < 0.3:
+                            break
+                    accepted[i] = (name, s)
+            for e in log:
+                e["handle"] = hex(dict(accepted)[e["stream"]].cuda_stream)
+            self.third_with_hook = self.third_with_hook and collective.get("third", 0.0) <= 0.25 and collective.get("main", 0.0) <= 0.25
+            self.hooked_tested = True
+        torch.cuda.synchronize(dev)
+        if coll is not None and world > 1:
+            dist.barrier()
+        all_ms = _spin_all_ms([s for _, s in accepted], coll)  # every stream of the step busy at once (three rounds of 200 us), the collective among them
+        torch.cuda.synchronize(dev)
+        hwq = os.environ.get("GPU_MAX_HW_QUEUES")
+        self.result = {"pairs_overlap": all(e["worst_pair_ms"] < 0.3 for e in log), "streams": log, "collective_beside_spin_ms": collective,
+                       "all_streams_3x200us_ms": round(all_ms, 3), "streams_replaced": replaced,
+                       "third_stream_with_hook": bool(self.third_with_hook) if hooked else None, "hw_queues": hwq, "world": world,
+                       "decisions_max_reduced_over_ranks": bool(with_group and world > 1)}
+        if hooked and hwq is not None and hwq.isdigit() and int(hwq) > 5:
+            # the pair / collective probes do NOT see the many-queue cliff (profiles/r05_ab_dist_queues.txt: 9.07 ms at 8 queues with a green
+            # self-test, 5.77 at 5; world-1 RCCL group): say so in the record and on stderr
+            self.result["hw_queues_note"] = (f"GPU_MAX_HW_QUEUES={hwq} with a gradient-bucket hook: measured 1.6x slower than 5 queues on a world-1 RCCL "
+                                             "group (9.07 vs 5.77 ms, profiles/r05_ab_dist_queues.txt); this self-test does not detect it")
+            import warnings
+            warnings.warn(self.result["hw_queues_note"])
+        if replaced:
+            self.generation += 1
+            self.tested.clear()
+        self.tested.add((main.cuda_stream, bool(hooked)))
+        if hooked:
+            self.tested.add((main.cuda_stream, False))  # (the pair part is the same measurement)
+        return self.result
+
+
 class _WgradPart:
     """One input-channel group of a two-source convolution presented to ops.WgradBatch as a layer of its own: `cin` stays the row stride
     of the full OIHW gradient, the group's channels are the packed columns [0, c_pad) -> real columns [0, c_real) of the gradient VIEW
@@ -126,7 +258,9 @@ class FalnetPlan:
         self.N = model.no_levels
         self.generation = 0
         self.use_side_stream = True
-        self._side = self._side_stream = None
+        self._streams = StepStreams.for_device(device)  # side / third / auxiliary streams: per DEVICE, shared by every plan
+        self._streams_gen = self._streams.generation
+        self._side_stream = None
         self._side_pending, self._side_events, self._side_ev_next = [], [], 0
         self._side_batch = max(1, int(L.ab("FALNET_SIDE_BATCH", "2")))
         # third stream of backward: every weight gradient below full resolution (levels 1-6).  The deep ones (levels 4-6) are 12-30 us
@@ -135,14 +269,11 @@ class FalnetPlan:
         # keeping only the full-resolution layers (logits, deconv1, level 0) and this stream everything else, two weight-gradient chains
         # of 128 workgroups each run beside the data gradients: same-box A/B -1.7 % on the step (profiles/r04_ab_wgrad_streams.txt:
         # levels 4-6 only -0.7 %, levels 3-6 -1.0 %, levels 1-6 -1.7 %, everything on this stream or alternating launches: worse).
-        self._deep = self._deep_stream = None
+        self._deep_stream = None
         self._deep_pending, self._deep_events, self._deep_ev_next, self._deep_dirty = [], [], 0, False
         self._sync_events, self._sync_ev_next = [], 0
         self._bwd_segments, self._bwd_eager_runs = {}, {}
         self._fwd_segments, self._fwd_eager_runs = {}, {}
-        self.selftest = None          # result of stream_selftest (bench.py prints it): None = not run yet
-        self._selftest_hooked = None  # whether the last self-test included the collective's stream
-        self._deep_with_hook = L.ab("FALNET_DEEP_WITH_HOOK", "1") == "1"  # third stream beside a bucket hook -- when the self-test found it a queue of its own
         self._main_stream = None
         self._deep_batch = max(1, int(L.ab("FALNET_DEEP_BATCH", "3")))
         self._deep_alt = L.ab("FALNET_DEEP_ALT", "0") == "1"  # experiment: every second larger weight gradient on the third stream as well
@@ -796,8 +927,13 @@ class FalnetPlan:
         # falnet_replay call -- the same launches on the same three streams.  Not with a gradient-bucket hook installed (torch.distributed
         # collectives are issued from Python between the buckets) and not inside bench.py's instrumented pass.
         hooked = getattr(self.model, "bucket_hook", None) is not None and not self._accumulate
-        if use_side and self._selftest_hooked != hooked and L.ab("FALNET_STREAM_SELFTEST", "1") == "1":
-            self.stream_selftest(main, hooked)  # (may re-create the side / third stream: recorded sequences are dropped)
+        if use_side:
+            # once per (caller's stream, hook state) and device; the hooked form normally ran already at train.enable_overlapped_allreduce
+            # (an explicit collective point: its probes are collectives) -- here only for a hook installed by hand
+            self._streams.ensure_tested(main, hooked)
+        if self._streams_gen != self._streams.generation:  # a stream was re-created (by any plan's test): recorded sequences hold the old handles
+            self.invalidate_segments()
+            self._streams_gen = self._streams.generation
         key = (g_disp is not None, g_pan is not None, bool(self._accumulate), hooked)
         can = use_side and ops.replay_ok() and (not hooked or L.ab("FALNET_REPLAY_HOOKED", "1") == "1")
         seg = self._bwd_segments.get(key) if can else None
@@ -840,18 +976,14 @@ class FalnetPlan:
             self._side_ev_next = self._deep_ev_next = self._sync_ev_next = 0
             self._deep_dirty = False
             if use_side:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                self._side_stream = self._side
+                self._side_stream = self._streams.side
                 self._stream_wait(self._side_stream, main)  # the previous step's Adam / repack must not be overtaken
                 # with a gradient-bucket hook (N > 1: torch.distributed collectives fired from the side stream) the third stream is OFF: on a
                 # world-size-1 RCCL group the step measured 8.4 ms with it against 5.5 ms without (exposed communication 3.0 vs 0.0 ms with 8 or 16
                 # hardware queues, none with 4: profiles/r04_ab_dist_third_stream.txt) -- the collective's stream, the side stream it waits on
                 # and the third stream the side stream waits on serialise against the main stream's data gradients
-                if self._deep_max_px > 0 and (not key[3] or self._deep_with_hook):
-                    if self._deep is None:
-                        self._deep = torch.cuda.Stream(device=self.device)
-                    self._deep_stream = self._deep
+                if self._deep_max_px > 0 and (not key[3] or self._streams.third_with_hook):
+                    self._deep_stream = self._streams.third
                     self._stream_wait(self._deep_stream, main)
                 else:
                     self._deep_stream = None
@@ -880,77 +1012,13 @@ class FalnetPlan:
         self._fwd_eager_runs.clear()
         self._reset_handover_state()
 
-    def stream_selftest(self, main, hooked, tries=12):
-        """HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order; two BUSY streams of the step on one queue serialise it
-        (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt) and nothing in the API says which queue a stream got.  So measure it: on every
-        pair of (main, side, third, auxiliary) two 200-us spin kernels must take ~200 us, not ~400; an offending side / third / auxiliary stream
-        is replaced by a fresh one from torch's pool until the pair overlaps.  With a bucket hook (`hooked`) the collective's own stream is in
-        the picture too: an all-reduce issued beside a spin on each of the plan's streams must not wait for the spin.  In-process, no re-exec;
-        ~10 ms once per plan and hook state.  The result goes to `self.selftest` (bench.py's allreduce_report prints it)."""
-        dev = self.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        if self._deep is None and self._deep_max_px > 0:
-            self._deep = torch.cuda.Stream(device=dev)
-        roles = [("main", lambda: main, None), ("side", lambda: self._side, lambda s: setattr(self, "_side", s))]
-        if self._deep is not None:
-            roles.append(("third", lambda: self._deep, lambda s: setattr(self, "_deep", s)))
-        roles.append(("aux", lambda: aux_stream(dev), lambda s: _AUX_STREAMS.__setitem__((dev.type, dev.index), s)))
-        coll = None
-        if hooked and torch.distributed.is_available() and torch.distributed.is_initialized():
-            buf = torch.zeros(1 << 18, device=dev)
+    @property
+    def selftest(self):
+        """Record of the device's stream self-test (StepStreams.selftest); None = not run yet."""
+        return self._streams.result
 
-            def coll():
-                torch.distributed.all_reduce(buf, async_op=True).wait()
-        log, accepted, replaced = [], [], 0
-        torch.cuda.synchronize(dev)
-        for name, get, put in roles:
-            n, worst = 0, 0.0
-            while True:
-                s = get()
-                worst = max([_spin_pair_ms(o, s) for _, o in accepted] + [0.0])
-                if worst < 0.3 or put is None or n >= tries:
-                    break
-                put(torch.cuda.Stream(device=dev))
-                n += 1
-                replaced += 1
-            log.append({"stream": name, "handle": hex(get().cuda_stream), "replaced": n, "worst_pair_ms": round(worst, 3)})
-            accepted.append((name, get()))
-        collective = None
-        if coll is not None:
-            # Every rank issues the SAME number of collectives whatever it measures (three rounds of one probe per stream): a rank that
-            # re-tried on its own would leave the others waiting in a collective it never joins.
-            coll()  # (first call: communicator / stream set-up outside the measurement)
-            torch.cuda.synchronize(dev)
-            for _ in range(3):
-                collective = {}
-                for i, (name, s) in enumerate(accepted):
-                    collective[name] = round(_spin_vs_call_ms(s, accepted[(i + 1) % len(accepted)][1], coll), 3)
-                for i, (name, s) in enumerate(accepted):
-                    if collective[name] <= 0.25 or name == "main":
-                        continue
-                    put = [r[2] for r in roles if r[0] == name][0]  # the collective's stream shares this stream's queue: move OUR stream
-                    for _t in range(tries):
-                        put(torch.cuda.Stream(device=dev))
-                        replaced += 1
-                        s = [r[1] for r in roles if r[0] == name][0]()
-                        if max(_spin_pair_ms(o, s) for nm, o in accepted if nm != name) < 0.3:
-                            break
-                    accepted[i] = (name, s)
-            for e in log:
-                e["handle"] = hex(dict(accepted)[e["stream"]].cuda_stream)
-            self._deep_with_hook = self._deep_with_hook and collective.get("third", 0.0) <= 0.25 and collective.get("main", 0.0) <= 0.25
-        torch.cuda.synchronize(dev)
-        all_ms = _spin_all_ms([s for _, s in accepted], coll)  # every stream of the step busy at once (three rounds of 200 us), the collective among them
-        torch.cuda.synchronize(dev)
-        self.selftest = {"pairs_overlap": all(e["worst_pair_ms"] < 0.3 for e in log), "streams": log, "collective_beside_spin_ms": collective,
-                         "all_streams_3x200us_ms": round(all_ms, 3),
-                         "streams_replaced": replaced, "third_stream_with_hook": bool(self._deep_with_hook) if hooked else None,
-                         "hw_queues": __import__("os").environ.get("GPU_MAX_HW_QUEUES")}
-        self._selftest_hooked = hooked
-        if replaced:
-            self.invalidate_segments()
-        return self.selftest
+    def stream_selftest(self, main, hooked):
+        return self._streams.selftest(main, hooked)
 
     def _stream_wait(self, waiter, waited):
         """waiter.wait_stream(waited) as an explicit event pair (recordable)."""

@@ -193,6 +193,16 @@ def enable_overlapped_allreduce(model):
             return
         model._pending_reduces.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True))
     model.bucket_hook = hook
+    # The hooked form of the stream self-test issues collectives: run it HERE, where every rank stands at the same point of its program (the
+    # first step of a data-parallel run), not lazily inside some plan's first backward.  Gloo groups on CPU tensors have no
+    # device stream to test.
+    p0 = model.flat_gradients()
+    if p0 is not None and p0.is_cuda and L.ab("FALNET_STREAM_SELFTEST", "1") == "1":
+        from .plan import StepStreams
+        st = StepStreams.for_device(p0.device)
+        if not st.hooked_tested:
+            with torch.cuda.device(p0.device):
+                st.selftest(torch.cuda.current_stream(p0.device), hooked=True)
 
 
 _SKIP_ALLREDUCE = False  # bench.py only: time the same steps without the collective (exposed communication = the difference)
@@ -218,7 +228,7 @@ def allreduce_gradients(model):
 
 
 def _aux_stream(device):
-    from .plan import aux_stream  # (one per device, kept beside the plans' streams: plan.stream_selftest checks it too)
+    from .plan import aux_stream  # (one per device: plan.StepStreams, whose self-test checks it too)
     return aux_stream(device)
 
 

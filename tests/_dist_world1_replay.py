@@ -8,6 +8,7 @@ import json
 import os
 import sys
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")  # main + side + third + aux + the collective's stream: as the entry scripts set it (before HIP initialises)
 os.environ["FALNET_FORCE_DIST"] = "1"
 os.environ["FALNET_DETERMINISTIC"] = "1"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -52,7 +53,7 @@ def run(replay, steps=6):
     plan = next(iter(m._plans.values()))
     segs = [type(s).__name__ for s in plan._bwd_segments.values()]
     cuts = [sum(1 for p in s.parts if not isinstance(p, L.Segment)) for s in plan._bwd_segments.values() if isinstance(s, L.SegmentChain)]
-    return {"steps": out, "fired": fired, "segments": segs, "cuts": cuts, "selftest": plan.selftest, "hooked_selftest": plan._selftest_hooked}
+    return {"steps": out, "fired": fired, "segments": segs, "cuts": cuts, "selftest": plan.selftest, "hooked_selftest": plan._streams.hooked_tested}
 
 
 def main():
