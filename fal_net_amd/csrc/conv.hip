@@ -3338,11 +3338,13 @@ extern "C" int64_t falnet_wgrad_workspace_bytes(const falnet_wgrad_t* p) {
 }
 
 // kernel selection of falnet_wgrad -- ONE place, also behind falnet_wgrad_fuses_bias (the host must not re-derive it)
-enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_S2, WGK_C3, WGK_ROWS, WGK_ROWS_S2 };
+enum WgradKernel { WGK_BAD = -1, WGK_TAP = 0, WGK_PATCH11, WGK_PATCH12, WGK_PATCH21, WGK_S2, WGK_C3, WGK_ROWS, WGK_ROWS_S2, WGK_WAVE };
 bool falnet_wgrad_rows_applicable(const falnet_wgrad_t& p);           // wgrad_rows.hip
 int falnet_wgrad_rows_launch(const falnet_wgrad_t& p, hipStream_t st);
 bool falnet_wgrad_rows_s2_applicable(const falnet_wgrad_t& p);        // wgrad_rows.hip: row-streaming form of the stride-2 weight gradient (variant 8)
 int falnet_wgrad_rows_s2_launch(const falnet_wgrad_t& p, hipStream_t st);
+bool falnet_wgrad_wave_applicable(const falnet_wgrad_t& p);           // wgrad_wave.hip: wave-streaming kernel for 32-channel inputs (variant 9)
+int falnet_wgrad_wave_launch(const falnet_wgrad_t& p, hipStream_t st);
 
 static bool canonical_taps9(const falnet_wgrad_t& p) {
     if (p.ntaps != 9) return false;
@@ -3371,6 +3373,10 @@ static WgradKernel choose_wgrad_kernel(const falnet_wgrad_t& p) {
     if (p.variant == 8) {
         if (!falnet_wgrad_rows_s2_applicable(p)) { falnet_set_error("wgrad: variant 8 needs a 16-bit 3x3 stride-2 pad-1 launch with ONE source at the input size"); return WGK_BAD; }
         return WGK_ROWS_S2;
+    }
+    if (p.variant == 9) {
+        if (!falnet_wgrad_wave_applicable(p)) { falnet_set_error("wgrad: variant 9 needs a 16-bit dense 3x3 stride-1 launch over ONE 32-channel NHWC source at the launch size, gC 32 or 64, TW >= 32"); return WGK_BAD; }
+        return WGK_WAVE;
     }
     if (p.variant == 7) {
         if (!falnet_wgrad_rows_applicable(p)) { falnet_set_error("wgrad: variant 7 needs a 16-bit dense 3x3 stride-1 launch with sources at the launch size or half of it (up2: ONE source at the launch size, nsplit a multiple of 4)"); return WGK_BAD; }
@@ -3441,6 +3447,8 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
         return falnet_wgrad_rows_launch(p, st);
     case WGK_ROWS_S2:
         return falnet_wgrad_rows_s2_launch(p, st);
+    case WGK_WAVE:
+        return falnet_wgrad_wave_launch(p, st);
     case WGK_C3:
 #define WG_C3(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_c3_kernel<T>), dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
         FALNET_DISPATCH_16(p.dtype, WG_C3);

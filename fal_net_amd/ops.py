@@ -637,6 +637,13 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         tiles = (cin_pad // 32) * (cout_pad // (64 if cout_pad % 64 == 0 else 32))
         variant, nsplit = 5, max(1, min((_WGRAD_WGS + tiles - 1) // tiles, npatch))
         sym = f"_Z18wgrad3x3_s2_kernelI{tn}Li{2 if cout_pad % 64 == 0 else 1}EEv14falnet_wgrad_tiiii"
+    elif _wgrad_wave(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad) and not up2:
+        # wave-streaming kernel (32-channel input): one workgroup = 8 waves = 8 / (cout_pad / 32) pixel ranges, one slab per workgroup; every
+        # range gets at least _WGRAD_WAVE_MIN_ROWS strip rows (two of its steps are halo rows)
+        npw = 8 // (cout_pad // 32)
+        units = B * ((TW + 31) // 32) * TH
+        nsplit = max(1, min(_WGRAD_WAVE_WGS, units // (npw * _WGRAD_WAVE_MIN_ROWS)))
+        variant, sym = 9, f"_Z22wgrad3x3_wave32_kernelI{tn}Li{cout_pad // 32}EEv14falnet_wgrad_ti"
     elif _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
         units = B * ((TW + 31) // 32) * TH * (4 if up2 else 1)  # up2: every parity class walks the whole low-resolution grid
@@ -743,6 +750,21 @@ _WGRAD_ROWS_WGS = int(L.ab("FALNET_WGRAD_ROWS_WGS", "128"))  # workgroups (one p
 _REDUCE_PER_LAYER = L.ab("FALNET_REDUCE_PER_LAYER", "0") == "1"
 _REDUCE_BLOCKS = int(L.ab("FALNET_REDUCE_BLOCKS", "64"))  # blocks per layer of the batched slab reduce (split over slab groups)
 _WGRAD_ROWS_MIN_ROWS = int(L.ab("FALNET_WGRAD_ROWS_MIN_ROWS", "8"))  # image rows per split-K range, at least
+
+
+_WGRAD_WAVE_WGS = int(L.ab("FALNET_WGRAD_WAVE_WGS", "256"))  # workgroups of a wave-streaming weight-gradient launch (HBM-bound: the whole chip)
+_WGRAD_WAVE_MIN_ROWS = int(L.ab("FALNET_WGRAD_WAVE_MIN_ROWS", "8"))
+
+
+def _wgrad_wave(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
+    """Wave-streaming weight-gradient kernel (falnet_wgrad variant 9, csrc/wgrad_wave.hip): 16-bit dense 3x3 stride-1 layers over ONE
+    32-channel NHWC source at the launch size with 32 or 64 (padded) output channels -- conv0_1's two convolutions, the skip group of the
+    logits convolution."""
+    if not (dense and dtype in (torch.bfloat16, torch.float16) and TW >= 32 and cin_pad == 32 and cout_pad in (32, 64)):
+        return False
+    if len(srcs) != 1 or srcs[0].C != 32 or srcs[0].H != IH or srcs[0].W != IW:
+        return False
+    return L.ab("FALNET_WGRAD_WAVE", "1") == "1"
 
 
 def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):

@@ -71,7 +71,7 @@ def _spin_vs_call_ms(x, probe, fn, us=300):
 
 def _spin_all_ms(streams, fn=None, us=200, rounds=3):
     """Wall time (ms) of `rounds` rounds of one `us` spin on EVERY stream of `streams` at once (behind a common gate), fn() -- a collective --
-    issued from the second stream in every round: ~rounds x us when the hardware runs all of them side by side."""
+    issued from the LAST stream (the auxiliary one) in every round: ~rounds x us when the hardware runs all of them side by side."""
     lib = L.lib()
     a = streams[0]
     gate, e0 = torch.cuda.Event(), torch.cuda.Event(enable_timing=True)
@@ -84,7 +84,7 @@ def _spin_all_ms(streams, fn=None, us=200, rounds=3):
     for _ in range(rounds):
         for i, s in enumerate(streams):
             L.check(lib.falnet_spin(us, s.cuda_stream), "spin")
-            if fn is not None and i == 1:
+            if fn is not None and i == len(streams) - 1:  # (the auxiliary stream: where the step's bucket all-reduces run)
                 with torch.cuda.stream(s):
                     fn()
     for s, e in zip(streams, ends):
@@ -103,11 +103,14 @@ class StepStreams:
     HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order; two BUSY streams of the step on one queue serialise it
     (5.5 -> 8.4 ms, profiles/r04_ab_dist_third_stream.txt) and nothing in the API says which queue a stream got.  So measure it: on every
     pair of (main, side, third, auxiliary) two 200-us spin kernels must take ~200 us, not ~400; an offending side / third / auxiliary stream
-    is replaced by a fresh one until the pair overlaps.  With a process group (`hooked`) the collective's own stream is in the picture too:
-    an all-reduce issued beside a spin on each stream must not wait for the spin.  That part issues collectives, so it is ALIGNED ACROSS
-    RANKS: it runs at an explicit collective point (train.enable_overlapped_allreduce, which every rank calls at the same place), every round
-    starts behind a barrier, and the measured times are MAX-reduced over the ranks before anything is decided -- every rank replaces the same
-    streams and takes the same third-stream decision, whatever skew it saw locally.  `generation` counts stream replacements:
+    is replaced by a fresh one until the pair overlaps.  The chip's compute pipes run FOUR queues side by side; a fifth busy queue
+    time-slices with one of them (profiles/r05_ab_dist_queues.txt: a world-1 RCCL group's own stream made the step 5.5 -> 5.8 ms at 5 queues,
+    9.1 at 8).  So the data-parallel step has no fifth stream: its bucket all-reduces are SYNC collectives issued on the auxiliary stream,
+    idle during backward (train.enable_overlapped_allreduce; torch >= 2.8 runs a sync NCCL / RCCL collective on the caller's stream).  With a
+    process group (`hooked`) the self-test probes exactly that: the collective on the auxiliary stream beside a spin on each other stream
+    must not wait for the spin.  That part issues collectives, so it is ALIGNED ACROSS RANKS: it runs at an explicit collective point
+    (train.enable_overlapped_allreduce, which every rank calls at the same place), every round starts behind a barrier, the times are
+    MAX-reduced over the ranks, and nothing is decided on them.  `generation` counts stream replacements:
     a plan whose recorded launch sequences were made under another generation drops them (they hold raw stream handles)."""
 
     _BY_DEVICE = {}
@@ -157,8 +160,8 @@ class StepStreams:
         if with_group:
             buf = torch.zeros(1 << 18, device=dev)
 
-            def coll():
-                dist.all_reduce(buf, async_op=True).wait()
+            def coll():  # (on the caller's CURRENT stream: a sync collective of the NCCL / RCCL backend, torch >= 2.8)
+                dist.all_reduce(buf, async_op=False)
         log, accepted, replaced = [], [], 0
         torch.cuda.synchronize(dev)
         for name, get, put in roles:  # local part: no collectives, any rank may loop as long as it needs
@@ -175,35 +178,24 @@ class StepStreams:
             accepted.append((name, get()))
         collective = None
         if coll is not None:
-            # Every rank issues the SAME collectives whatever it measures: three fixed rounds, each behind a barrier, the per-stream times
-            # MAX-reduced over the ranks before the (then identical) replacement decisions; the replacement loops themselves are local.
-            coll()  # (first call: communicator / stream set-up outside the measurement)
+            # The bucket all-reduces run as SYNC collectives on the auxiliary stream (train.enable_overlapped_allreduce): no stream of the
+            # backend's own beside the step's four.  Probe exactly that: a spin on each other stream, the collective on aux beside it must not
+            # wait for the spin.  Every rank issues the SAME collectives whatever it measures -- three fixed rounds, each behind a barrier, the
+            # times MAX-reduced over the ranks -- and NO stream is replaced on these numbers (the pair test above has already placed aux).
+            aux_s = dict(accepted)["aux"]
+            with torch.cuda.stream(aux_s):
+                coll()  # (first call: communicator set-up outside the measurement)
             torch.cuda.synchronize(dev)
+            others = [(n, s_) for n, s_ in accepted if n != "aux"]
             for _ in range(3):
                 if world > 1:
                     dist.barrier()
-                collective = {}
-                for i, (name, s) in enumerate(accepted):
-                    collective[name] = _spin_vs_call_ms(s, accepted[(i + 1) % len(accepted)][1], coll)
+                collective = {name: _spin_vs_call_ms(s_, aux_s, coll) for name, s_ in others}
                 if world > 1:
-                    t = torch.tensor([collective[name] for name, _ in accepted], device=dev)
+                    t = torch.tensor([collective[name] for name, _ in others], device=dev)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    collective = {name: float(v) for (name, _), v in zip(accepted, t.tolist())}
+                    collective = {name: float(v) for (name, _), v in zip(others, t.tolist())}
                 collective = {k: round(v, 3) for k, v in collective.items()}
-                for i, (name, s) in enumerate(accepted):
-                    if collective[name] <= 0.25 or name == "main":
-                        continue
-                    put = [r[2] for r in roles if r[0] == name][0]  # the collective's stream shares this stream's queue: move OUR stream
-                    for _t in range(tries):
-                        put(torch.cuda.Stream(device=dev))
-                        replaced += 1
-                        s = [r[1] for r in roles if r[0] == name][0]()
-                        if max(_spin_pair_ms(o, s) for nm, o in accepted if nm != name) < 0.3:
-                            break
-                    accepted[i] = (name, s)
-            for e in log:
-                e["handle"] = hex(dict(accepted)[e["stream"]].cuda_stream)
-            self.third_with_hook = self.third_with_hook and collective.get("third", 0.0) <= 0.25 and collective.get("main", 0.0) <= 0.25
             self.hooked_tested = True
         torch.cuda.synchronize(dev)
         if coll is not None and world > 1:

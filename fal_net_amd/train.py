@@ -187,9 +187,30 @@ def enable_overlapped_allreduce(model):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DIST):
         return
     model._pending_reduces = []
+    model._comm_event = None
+    on_device = model.flat_gradients() is not None and model.flat_gradients().is_cuda
+    sync_on_stream = on_device and dist.get_backend() == "nccl" and _COMM_ON_AUX
 
     def hook(bucket, flat_slice):
         if _SKIP_ALLREDUCE:
+            return
+        if sync_on_stream:
+            # The collective runs ON one of the step's own streams: torch >= 2.8 issues a SYNC collective (async_op=False) of the NCCL / RCCL
+            # backend on the caller's current stream, and the auxiliary stream (the label image's VGG pass in forward) is idle throughout
+            # backward.  No fifth busy hardware queue: the compute pipes of the chip run four queues side by side, a fifth time-slices with one
+            # of them (profiles/r05_ab_dist_queues.txt: the more queues the slower; r06_ab_dist.txt: world-1 exposure 0.31 -> see there).
+            # Order: slab reduce of the bucket (caller's stream) -> event -> aux: all_reduce -> event -> the optimiser's stream (allreduce_gradients).
+            from .plan import aux_stream
+            aux = aux_stream(flat_slice.device)
+            cur = torch.cuda.current_stream(flat_slice.device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            aux.wait_event(ev)
+            with torch.cuda.stream(aux):
+                dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=False)
+                done = torch.cuda.Event()
+                done.record(aux)
+            model._comm_event = done  # (stream order on aux: the last bucket's event covers the earlier ones)
             return
         model._pending_reduces.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True))
     model.bucket_hook = hook
@@ -205,6 +226,7 @@ def enable_overlapped_allreduce(model):
                 st.selftest(torch.cuda.current_stream(p0.device), hooked=True)
 
 
+_COMM_ON_AUX = L.ab("FALNET_COMM_ON_AUX", "1") == "1"  # bucket all-reduces as sync collectives on the auxiliary stream (0: async on the backend's own stream)
 _SKIP_ALLREDUCE = False  # bench.py only: time the same steps without the collective (exposed communication = the difference)
 
 
@@ -217,6 +239,11 @@ def allreduce_gradients(model):
     if _SKIP_ALLREDUCE:
         if pending:
             pending.clear()
+        return 1.0 / dist.get_world_size()
+    done = getattr(model, "_comm_event", None)
+    if done is not None:  # buckets reduced on the auxiliary stream: the optimiser's stream waits for the last of them
+        torch.cuda.current_stream().wait_event(done)
+        model._comm_event = None
         return 1.0 / dist.get_world_size()
     if pending:
         for w in pending:
