@@ -3345,6 +3345,8 @@ bool falnet_wgrad_rows_s2_applicable(const falnet_wgrad_t& p);        // wgrad_r
 int falnet_wgrad_rows_s2_launch(const falnet_wgrad_t& p, hipStream_t st);
 bool falnet_wgrad_wave_applicable(const falnet_wgrad_t& p);           // wgrad_wave.hip: wave-streaming kernel for 32-channel inputs (variant 9)
 int falnet_wgrad_wave_launch(const falnet_wgrad_t& p, hipStream_t st);
+bool falnet_wgrad_c3wave_applicable(const falnet_wgrad_t& p);         // wgrad_wave.hip: the first layer's gradient in the wave-streaming form (variant 6, IW % 4 == 0)
+int falnet_wgrad_c3wave_launch(const falnet_wgrad_t& p, hipStream_t st);
 
 static bool canonical_taps9(const falnet_wgrad_t& p) {
     if (p.ntaps != 9) return false;
@@ -3416,7 +3418,7 @@ static int check_wgrad_desc(const falnet_wgrad_t& p) {
 
 static bool wgrad_kernel_fuses_bias(WgradKernel k) {
     if (falnet_deterministic()) return false;  // the fused form adds with f32 atomics from every workgroup
-    return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS || k == WGK_ROWS_S2;
+    return k == WGK_PATCH11 || k == WGK_PATCH12 || k == WGK_PATCH21 || k == WGK_S2 || k == WGK_C3 || k == WGK_ROWS || k == WGK_ROWS_S2 || k == WGK_WAVE;
 }
 
 extern "C" int falnet_wgrad_fuses_bias(const falnet_wgrad_t* pp) {
@@ -3450,6 +3452,7 @@ extern "C" int falnet_wgrad(const falnet_wgrad_t* pp, void* stream) {
     case WGK_WAVE:
         return falnet_wgrad_wave_launch(p, st);
     case WGK_C3:
+        if (falnet_wgrad_c3wave_applicable(p)) return falnet_wgrad_c3wave_launch(p, st);
 #define WG_C3(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad3x3_c3_kernel<T>), dim3(1, 1, p.nsplit), dim3(WC3_THREADS), 0, st, p, w_rows, tiles_x, tiles_y, pps)
         FALNET_DISPATCH_16(p.dtype, WG_C3);
         break;

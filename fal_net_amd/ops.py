@@ -626,6 +626,14 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
     if c3:
         assert h16 and dense and cout_pad == 32 and cin_pad == 32, "variant 6: 16-bit first layer, Cout 32"
         variant, nsplit, sym = 6, max(1, min(_WGRAD_WGS, npatch)), f"_Z18wgrad3x3_c3_kernelI{tn}Ev14falnet_wgrad_tiiii"
+        if IW % 4 == 0 and TW >= 32 and not DETERMINISTIC:  # the wave-streaming form (csrc/wgrad_wave.hip: falnet_wgrad_c3wave_applicable)
+            nsplit = max(1, min(_WGRAD_WAVE_WGS, B * ((TW + 31) // 32) * TH // (8 * _WGRAD_WAVE_MIN_ROWS)))
+            sym = f"_Z22wgrad3x3_c3wave_kernelI{tn}Ev14falnet_wgrad_ti"
+    elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs) and _wgrad_wave_s2(srcs, IH, IW, TW, cin_pad, cout_pad):
+        # wave-streaming kernel, stride-2 form (conv1's image source): a workgroup = ONE pixel range x 4 parity planes x 2 output-channel halves
+        units = B * ((TW + 31) // 32) * TH
+        nsplit = max(1, min(_WGRAD_WAVE_WGS, units // _WGRAD_WAVE_MIN_ROWS))
+        variant, sym = 9, f"_Z22wgrad3x3_wave32_kernelI{tn}Li2ELb1EEv14falnet_wgrad_ti"
     elif _wgrad_s2(dtype, taps, stride_in, TH, TW, IH, IW, srcs) and _wgrad_rows_s2(srcs, IH, IW, TW, cin_pad, cout_pad):
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
         units = B * ((TW + 31) // 32) * TH
@@ -643,7 +651,7 @@ def _wgrad_plan(dtype, srcs, taps, stride_in, B, TH, TW, IH, IW, cin_pad, cout_p
         npw = 8 // (cout_pad // 32)
         units = B * ((TW + 31) // 32) * TH
         nsplit = max(1, min(_WGRAD_WAVE_WGS, units // (npw * _WGRAD_WAVE_MIN_ROWS)))
-        variant, sym = 9, f"_Z22wgrad3x3_wave32_kernelI{tn}Li{cout_pad // 32}EEv14falnet_wgrad_ti"
+        variant, sym = 9, f"_Z22wgrad3x3_wave32_kernelI{tn}Li{cout_pad // 32}ELb0EEv14falnet_wgrad_ti"
     elif _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
         tiles = ((cin_pad + 63) // 64) * ((cout_pad + 63) // 64)
         units = B * ((TW + 31) // 32) * TH * (4 if up2 else 1)  # up2: every parity class walks the whole low-resolution grid
@@ -765,6 +773,13 @@ def _wgrad_wave(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):
     if len(srcs) != 1 or srcs[0].C != 32 or srcs[0].H != IH or srcs[0].W != IW:
         return False
     return L.ab("FALNET_WGRAD_WAVE", "1") == "1"
+
+
+def _wgrad_wave_s2(srcs, IH, IW, TW, cin_pad, cout_pad):
+    """The stride-2 form of the wave-streaming kernel (falnet_wgrad variant 9 with isy = 2): ONE 32-channel NHWC source at the input size, 64 output
+    channels -- conv1's image source (its constant `flow` channel goes through falnet_wgrad_const_plane)."""
+    return (len(srcs) == 1 and srcs[0].C == 32 and srcs[0].H == IH and srcs[0].W == IW and srcs[0].sx != 0 and cin_pad == 32 and cout_pad == 64
+            and TW >= 32 and L.ab("FALNET_WGRAD_WAVE", "1") == "1" and L.ab("FALNET_WGRAD_WAVE_S2", "1") == "1")
 
 
 def _wgrad_rows(dtype, dense, srcs, IH, IW, TW, cin_pad, cout_pad):

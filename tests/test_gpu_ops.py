@@ -819,11 +819,12 @@ def test_stride2_dgrad_dma_four_classes(B, cin, cout, H, W, dtype):
         bad()
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (1, 75, 250)])
-def test_wgrad_first_layer_planar(B, H, W):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (1, 37, 70), (1, 75, 250), (2, 37, 68), (8, 24, 96), (1, 5, 32), (1, 64, 512)])
+def test_wgrad_first_layer_planar(B, H, W, dtype):
     """falnet_wgrad variant 6: conv0's weight (+ fused bias) gradient straight from the planar f32 image (no NHWC copy), through
-    the batched path the plans use (slab reduce un-pads the 3 real input channels)."""
-    dtype = torch.bfloat16
+    the batched path the plans use (slab reduce un-pads the 3 real input channels).  Widths that are a multiple of 4 take the wave-streaming
+    form (csrc/wgrad_wave.hip: wgrad3x3_c3wave_kernel -- ragged last strip, ranges that cut columns, empty ranges), the others the halo-patch form."""
     g = torch.Generator().manual_seed(H * W)
     x = torch.randn(B, 3, H, W, generator=g)
     w = (torch.randn(32, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
@@ -839,8 +840,9 @@ def test_wgrad_first_layer_planar(B, H, W):
     call()
     for c in fin[0]:
         c()
-    assert rel(gw, w.grad) < BF16_TOL
-    assert rel(gb, b.grad) < BF16_TOL
+    tol = BF16_TOL if dtype == torch.bfloat16 else 2e-3
+    assert rel(gw, w.grad) < tol
+    assert rel(gb, b.grad) < tol
 
 
 def test_upsample_bwd_and_pool():
@@ -1231,6 +1233,84 @@ def test_wgrad_rows_deconv_lowres(B, cin, cout, h, w, bias, dtype):
     # a split count that is not a whole number of class groups is refused
     call.desc.nsplit = 6
     assert L.lib().falnet_wgrad(C.byref(call.desc), L.stream_ptr()) != 0
+
+
+WAVE_CASES = [
+    # B, Cout, H, W, bias
+    (2, 32, 9, 33, False),     # ragged second strip (one valid column), odd row count
+    (1, 49, 12, 40, True),     # gC 64: two output-channel halves per workgroup (the logits convolution's skip group), fused bias gradient
+    (2, 32, 37, 64, False),    # ranges that cut columns at arbitrary rows
+    (8, 32, 24, 96, False),    # many units
+    (1, 64, 5, 32, True),      # fewer rows than waves: empty ranges
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", WAVE_CASES)
+def test_wgrad_wave32(case, dtype):
+    """falnet_wgrad variant 9 (wave-streaming kernel for 32-channel inputs, csrc/wgrad_wave.hip: conv0_1's two convolutions FAL_netB.py:38-47,100 and
+    the skip group of the logits convolution :127) against autograd of F.conv2d on the operands rounded to the compute dtype, for several workgroup
+    counts (ranges that start / end mid-column, empty ranges); a source that is not 32 channels wide is refused."""
+    B, Cout, H, W, bias = case
+    g = torch.Generator().manual_seed(H * W + Cout)
+    x = torch.randn(B, 32, H, W, generator=g)
+    go = torch.randn(B, Cout, H, W, generator=g)
+    xr, gr = x.to(dtype).float(), go.to(dtype).float()
+    w = torch.zeros(Cout, 32, 3, 3, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    (F.conv2d(xr, w, b, padding=1) * gr).sum().backward()
+    pc = packed(w.detach(), b.detach() if bias else None, [32], 1, torch.bfloat16)
+    x_t, g_t = _nhwc_torch(x, dtype), _nhwc_torch(go, dtype)
+    ws = torch.empty(16 << 20, device=DEV)
+    taps = [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)]
+    for nsplit in (1, 3, 8, 40, 256):
+        gw = torch.full(w.shape, float("nan"), device=DEV)
+        gb = torch.full((Cout,), float("nan"), device=DEV) if bias else None
+        call = ops.wgrad_calls(dtype, [ops.nhwc_src(x_t)], H, W, g_t, taps, 1, B, H, W, pc, gw, gb, ws)
+        assert call.desc.variant == 9, call.desc.variant
+        call.desc.nsplit = min(nsplit, ws.numel() * 4 // (9 * ops.pad_c(Cout) * 32 * 4))
+        call(0)
+        assert rel(gw, w.grad) < 2e-5, (nsplit, rel(gw, w.grad))
+        if bias:
+            assert rel(gb, b.grad) < 2e-5
+    bad = L.Wgrad.from_buffer_copy(call.desc)
+    bad.cin_total = 64
+    assert L.lib().falnet_wgrad(C.byref(bad), L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Cout,IH,IW", [
+    (2, 64, 24, 80),    # TW 40: ragged second strip
+    (1, 64, 37, 65),    # odd input size: the parity planes differ in size, the last output row / column meets one tap row / column only
+    (8, 49, 32, 128),   # many units; gC 64 with 49 real channels
+    (1, 64, 6, 64),     # fewer rows than workgroups: empty ranges
+])
+def test_wgrad_wave32_stride2(B, Cout, IH, IW, dtype):
+    """falnet_wgrad variant 9, stride-2 form (conv1's image source, FAL_netB.py:101: 3x3 / stride 2 / pad 1 over a 32-channel input): four parity-plane
+    waves per pixel range, each writing its own taps of the slab -- against autograd of F.conv2d(stride=2) on the rounded operands, for several
+    workgroup counts."""
+    TH, TW = (IH + 1) // 2, (IW + 1) // 2
+    g = torch.Generator().manual_seed(IH * IW + Cout)
+    x = torch.randn(B, 32, IH, IW, generator=g)
+    go = torch.randn(B, Cout, TH, TW, generator=g)
+    xr, gr = x.to(dtype).float(), go.to(dtype).float()
+    w = torch.zeros(Cout, 32, 3, 3, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    (F.conv2d(xr, w, b, stride=2, padding=1) * gr).sum().backward()
+    pc = packed(w.detach(), b.detach(), [32], 2, torch.bfloat16)
+    x_t, g_t = _nhwc_torch(x, dtype), _nhwc_torch(go, dtype)
+    ws = torch.empty(16 << 20, device=DEV)
+    taps = [(dy, dx, 0) for dy, dx, _ in ops.fwd_taps(3)]
+    for nsplit in (1, 3, 8, 40, 256):
+        gw = torch.full(w.shape, float("nan"), device=DEV)
+        gb = torch.full((Cout,), float("nan"), device=DEV)
+        call = ops.wgrad_calls(dtype, [ops.nhwc_src(x_t)], IH, IW, g_t, taps, 2, B, TH, TW, pc, gw, gb, ws)
+        assert call.desc.variant == 9 and call.desc.isy == 2, (call.desc.variant, call.desc.isy)
+        assert call.desc.bias_grad  # (the bias gradient is summed by the kernel: plane (0, 0)'s waves)
+        call.desc.nsplit = nsplit
+        call(0)
+        assert rel(gw, w.grad) < 2e-5, (nsplit, rel(gw, w.grad))
+        assert rel(gb, b.grad) < 2e-5
 
 
 def test_mfma_probe_runs_and_rejects_bad_arguments():
