@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libfalnet_hip.so")
-SOURCES = ["api.cpp", "replay.cpp", "med_head.hip", "med_head2.hip", "losses.hip", "elementwise.hip", "data.hip", "wgrad_rows.hip", "wgrad_wave.hip", "conv_dma.hip", "conv.hip"]
+SOURCES = ["api.cpp", "replay.cpp", "med_head.hip", "med_head2.hip", "losses.hip", "elementwise.hip", "data.hip", "wgrad_rows.hip", "wgrad_wave.hip", "conv_wave.hip", "conv_dma.hip", "conv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # Per-file flags.  The MED head kernels are f32 VALU work per pixel and plane: the SLP vectoriser pairs independent scalar

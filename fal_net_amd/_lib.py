@@ -175,7 +175,7 @@ _lib = None
 _TLS = threading.local()  # per-thread launch state: the pinned stream (stream_scope) and the active Recorder
 # falnet_version() of the library this binding was written against (api.cpp; bumped with every struct / entry-point change): a stale
 # FALNET_LIB build with the same symbols but another descriptor layout must not load
-EXPECTED_VERSION = 503
+EXPECTED_VERSION = 600
 
 
 def lib():

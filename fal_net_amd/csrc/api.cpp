@@ -16,7 +16,7 @@ void falnet_set_error(const char* fmt, ...) {
 // major * 100 + layout revision of the descriptor structs of include/falnet_hip.h (falnet_conv_t, falnet_wgrad_t, falnet_reduce_t ...):
 // bumped whenever a struct gains / moves a field or an entry point changes meaning; the ctypes binding and the autotune cache
 // header check it.  300: round 3 (falnet_conv_t.variant 17/18, falnet_wgrad_t deterministic flag, falnet_adam_step_dev finite guard).
-extern "C" int falnet_version(void) { return 503; }
+extern "C" int falnet_version(void) { return 600; }
 extern "C" const char* falnet_last_error(void) { return g_err; }
 
 // Deterministic mode (process-wide): see include/falnet_hip.h.  Read by the launchers of conv.hip / losses.hip.

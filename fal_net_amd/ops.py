@@ -53,7 +53,7 @@ if os.environ.get("FALNET_AB") == "1" and any(os.environ.get(k, v) != v for k, v
     _CACHE_PATH = "0"
 _CACHE = None
 _CACHE_DIRTY = False
-_TUNE_SOURCES = ("conv.hip", "conv_dma.hip", "conv_epilogue.h", "common.h")  # what a cached conv choice depends on
+_TUNE_SOURCES = ("conv.hip", "conv_dma.hip", "conv_wave.hip", "conv_epilogue.h", "common.h")  # what a cached conv choice depends on
 
 
 def cache_meta():
@@ -574,6 +574,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
             cands += [(23, 1)]  # variant 13's tile on v_mfma_f32_16x16x32
             if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")):
                 cands += [(24, 1), (25, 1)]  # ... variants 17 / 20 (4x32 / 8x32 tiles)
+        if d.cin_total == 32 and w_rows == 32 and L.ab("FALNET_CONV_WAVE", "1") == "1":
+            cands += [(27, 1)]  # wave-streaming kernel: 32 -> 32 channels at full resolution (HBM-bound layers)
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

@@ -141,6 +141,9 @@ typedef struct {
                                   grid: ONE source = the upstream gradient at exactly twice the output map, weight = falnet_pack_up2_t::wdd
                                   ([w_rows][4][4 C], w_taps = ntaps = 4, cin_total = 4 C) -- a 2x2-tap convolution over pairs of upstream rows /
                                   columns, 16 instead of 36 tap-MACs per input position (conv_dma.hip: conv2x2_up2d_dma16_kernel);
+                                  27 = wave-streaming kernel for 32 -> (<= 32) channel layers (conv_wave.hip: conv3x3_wave32_kernel): ONE 32-channel
+                                  source at the launch size, 32-row packed weight, NHWC output, no pool / split-K; every wave streams its own
+                                  32-pixel strip rows through a private LDS-DMA ring (no workgroup barrier), weights resident in registers;
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,
@@ -204,7 +207,11 @@ typedef struct {
                                   channels, cin_total 32 (slab layout),
                                   7 row-streaming kernel (bf16 / f16, dense 3x3 stride 1, sources at the launch size or exactly
                                   half of it): 64 x 64 channels per workgroup, LDS-DMA row ring, gout fragments in a rolling
-                                  register window; nsplit = ranges of (sample, 32-pixel column strip, row) units */
+                                  register window; nsplit = ranges of (sample, 32-pixel column strip, row) units,
+                                  9 wave-streaming kernel (csrc/wgrad_wave.hip; bf16 / f16, dense 3x3, ONE 32-channel NHWC source at the input size):
+                                  stride 1 with gC 32 or 64, or stride 2 (TH = ceil(IH / 2), TW = ceil(IW / 2)) with gC 64; nsplit = workgroups =
+                                  slabs, every wave streams its own (sample, strip, row) range (stride 2: its own parity plane of one range).
+                                  Variant 6 takes the same wave-streaming form when IW % 4 == 0 (not in deterministic mode) */
     float* bias_grad;          /* optional, halo kernels (dense 3x3 stride 1, variant 5): db[co] += sum over positions of gout[.,co]
                                   (f32 atomics, [gC]) from the gout tiles the kernel stages anyway -- replaces a falnet_bias_grad
                                   pass over the same tensor.  Only the kernels falnet_wgrad_fuses_bias() reports fuse it;

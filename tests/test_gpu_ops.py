@@ -293,6 +293,82 @@ def test_conv_dma2_variant21(B, groups, up, cout, H, W, mode, dtype):
                 assert float((a - b2).abs().max()) <= 2.0 ** (-6 if dtype == torch.bfloat16 else -9) * float(b2.abs().max()), (mode, v)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,cout,H,W,mode", [
+    (2, 32, 24, 64, "fwd"),       # bias + ELU
+    (2, 32, 37, 70, "res"),       # residual block tail: bias-free conv + addend + ELU; ragged third strip, odd row count
+    (8, 32, 24, 96, "dgrad"),     # data gradient: flipped taps of the transposed weight, addend + activation-gradient operand; many units
+    (1, 17, 5, 32, "fwd"),        # fewer rows than waves (empty ranges); 17 real output channels of 32
+    (1, 32, 256, 512, "dgrad"),   # the call site's own map size (one sample)
+])
+def test_conv_wave32_variant27(B, cout, H, W, mode, dtype):
+    """falnet_conv2d variant 27 (conv3x3_wave32_kernel, csrc/conv_wave.hip: every wave streams its own strip rows, weights resident in registers) on
+    the operand forms of its call sites -- conv0_1's two convolutions forward and as stride-1 data gradients (models/FAL_netB.py:38-47,100) -- against
+    torch-CPU fp32 on the rounded operands and against the weight-stationary kernel (variant 10) it replaces; launches it cannot take are refused."""
+    g = torch.Generator().manual_seed(B * 100 + H + cout)
+    x = torch.randn(B, 32, H, W, generator=g)
+    w = torch.randn(cout, 32, 3, 3, generator=g) * (1.5 / (9 * 32) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = packed(w, b, [32], 1, dtype)
+    x_t = to_nhwc(x, dtype)
+    xr, wref = to_nchw(x_t, 32), w.to(dtype).float()
+    bias_t = torch.zeros(pc.cout_pad, device=DEV)
+    bias_t[:cout] = b.to(DEV)
+    out = torch.full((B, H, W, pc.cout_pad), float("nan"), dtype=dtype, device=DEV)
+    taps, weight = ops.fwd_taps(3), pc.wf
+    if mode == "fwd":
+        kw = dict(bias=bias_t, act=L.ACT_ELU)
+        ref = F.elu(F.conv2d(xr, wref, b, padding=1))
+    elif mode == "res":
+        add = torch.randn(B, cout, H, W, generator=g)
+        add_t = to_nhwc(add, dtype)
+        kw = dict(bias=None, addend=add_t, act=L.ACT_ELU)
+        ref = F.elu(F.conv2d(xr, wref, None, padding=1) + to_nchw(add_t, cout))
+    else:  # x plays the upstream gradient of a cout = 32 -> cin = 32 convolution: conv_transpose with the same weight
+        assert cout == 32
+        add = torch.randn(B, 32, H, W, generator=g)
+        y = F.elu(torch.randn(B, 32, H, W, generator=g))
+        add_t, y_t = to_nhwc(add, dtype), to_nhwc(y, dtype)
+        yr = to_nchw(y_t, 32)
+        kw = dict(bias=None, addend=add_t, actout=y_t, actout_kind=L.ACT_ELU)
+        taps, weight = ops.dgrad_taps_s1(3), pc.wd
+        ref = (F.conv_transpose2d(xr, wref, None, padding=1) + to_nchw(add_t, 32)) * torch.where(yr > 0, torch.ones_like(yr), yr + 1)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        call = ops.conv_call(dtype, [ops.nhwc_src(x_t)], H, W, weight, 32, taps, 9, pc.cout_pad, 1, B, H, W, out, H, W, pc.cout_pad, pc.cout_pad, **kw)
+    finally:
+        ops.AUTOTUNE = old
+    res = {}
+    for variant in (27, 10):
+        call.desc.variant = variant
+        out.fill_(float("nan"))
+        assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) == 0, (variant, L.lib().falnet_last_error())
+        name = C.create_string_buffer(160)
+        assert L.lib().falnet_conv2d_kernel_name(call.ref, name, 160) == 0
+        assert (b"conv3x3_wave32_kernel" in name.value) == (variant == 27), name.value
+        torch.cuda.synchronize()
+        got = to_nchw(out, cout)
+        assert torch.isfinite(out.float()).all(), variant
+        assert rel(got, ref) < TOL[dtype], (variant, rel(got, ref))
+        if pc.cout_pad > cout:
+            assert float(out[..., cout:].float().abs().max()) == 0.0
+        res[variant] = out.float().cpu()
+    assert float((res[27] - res[10]).abs().max()) <= 2.0 ** (-6 if dtype == torch.bfloat16 else -9) * float(res[10].abs().max())
+    # a 64-channel source is not this kernel's
+    x64 = to_nhwc(torch.randn(1, 64, 8, 32), dtype)
+    w64 = torch.randn(32, 64, 3, 3) * 0.05
+    pc64 = packed(w64, None, [64], 1, dtype)
+    o64 = torch.empty(1, 8, 32, 32, dtype=dtype, device=DEV)
+    ops.AUTOTUNE = False
+    try:
+        c64 = ops.conv_call(dtype, [ops.nhwc_src(x64)], 8, 32, pc64.wf, 64, ops.fwd_taps(3), 9, 32, 1, 1, 8, 32, o64, 8, 32, 32, 32)
+    finally:
+        ops.AUTOTUNE = old
+    c64.desc.variant = 27
+    assert L.lib().falnet_conv2d(c64.ref, L.stream_ptr()) == -2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W,keep_full", [(2, 64, 64, 16, 64, True), (1, 64, 128, 24, 40, False), (2, 128, 128, 128, 256, True),
                                                      (1, 256, 256, 16, 32, False), (1, 64, 64, 11, 37, True)])
