@@ -566,6 +566,19 @@ def main():
     if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
         result["allreduce"] = allreduce_report(model, eager_step, args, world, rank, dev, ms)
 
+    phase_ms = None
+    if rank == 0 and not args.no_roofline and args.workload != "stage2" and not graphed:
+        # phase boundaries of the REAL step (all streams live, replayed launch sequences): five HIP events per step on the step's stream, 10 steps,
+        # NOT part of the timed region.  With the per-phase algorithmic FLOPs of the instrumented pass below this is `roofline.phase_tflops`:
+        # where the step delivers its FLOPs and where it does not, without a trace.
+        train.PHASE_MARKS = []
+        for _ in range(10):
+            eager_step()
+        torch.cuda.synchronize()
+        names = ("forward_and_med_head", "label_join_vgg_losses_vgg_adjoint", "backward_three_streams", "allreduce_and_optimiser")
+        if train.PHASE_MARKS and all(len(m) == 5 for m in train.PHASE_MARKS):
+            phase_ms = {n: sorted(m[i].elapsed_time(m[i + 1]) for m in train.PHASE_MARKS)[len(train.PHASE_MARKS) // 2] for i, n in enumerate(names)}
+        train.PHASE_MARKS = None
     if rank == 0 and not args.no_roofline:
         # instrumented pass (NOT part of the timed region): HIP events around every launch
         timer = EventTimer()
@@ -614,6 +627,21 @@ def main():
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12, "ms_per_step": mfma_ms,
                                  "algorithmic_gflop_per_step": mfma_fl / 1e9},
         }
+        if phase_ms is not None:
+            # FLOPs per phase from the instrumented launches of ONE step, cut at the MED head's forward / backward launches and the optimiser
+            n_per_step = len(timer.records) // 3
+            tags = [r[0] for r in timer.records[:n_per_step]]
+            i_hf = max((i for i, t in enumerate(tags) if t.startswith("falnet_med_head_fwd")), default=-1)
+            i_hb = max((i for i, t in enumerate(tags) if t.startswith("falnet_med_head_bwd")), default=-1)
+            if 0 <= i_hf < i_hb:
+                fl = [sum(r[1] for r in timer.records[:i_hf + 1]), sum(r[1] for r in timer.records[i_hf + 1:i_hb]),
+                      sum(r[1] for r in timer.records[i_hb:n_per_step]), 0]
+                # (the label image's VGG pass is LAUNCHED first in the instrumented, serial pass but runs beside the forward: count it there)
+                result["roofline"]["phase_tflops"] = {
+                    n: {"ms": round(ms_, 4), "gflop": round(f / 1e9, 1), "tflops": round(f / (ms_ * 1e-3) / 1e12, 1) if ms_ > 0 else None}
+                    for (n, ms_), f in zip(phase_ms.items(), fl)}
+                result["roofline"]["phase_tflops"]["note"] = ("median of 10 steps outside the timed region, HIP events on the step's stream at the phase boundaries (all streams live); "
+                                                              "algorithmic FLOPs of the launches issued in each phase (weight gradients count in `backward`)")
         if dtype != torch.float32:
             sm = sustained_mfma(dtype, dev)
             result["roofline"]["sustained_mfma"] = sm

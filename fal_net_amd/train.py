@@ -313,9 +313,22 @@ def _stage1_fused(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, ma
             raise
 
 
+PHASE_MARKS = None  # bench.py: a list -> every fused Stage-1 step appends five HIP events recorded on the step's stream at its phase boundaries
+# (start | forward + MED head done | label join, VGG(synth), losses, VGG adjoint done | backward joined | optimiser done)
+
+
+def _mark(marks):
+    if marks is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+
+
 def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_arg, max_disp_arg, optimize):
     from . import loss_functions as LF
     lib = L.lib()
+    marks = None if PHASE_MARKS is None else []
+    _mark(marks)
     B, C, H, W = left.shape
     dev = left.device
     plan = model._plan(B, H, W, dev)
@@ -339,6 +352,7 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
     if a_p > 0 and not joins:
         model._mid_forward_hook = None
         joins.append(vgg_label_async(right))
+    _mark(marks)
     rpan, ldisp = b["p_im0"], b["disp"]
     rt = right.detach().contiguous()
     st = L.stream_ptr()
@@ -382,12 +396,17 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
         L.check(lib.falnet_l1_fwd_bwd_add(L.ptr(rpan), L.ptr(rt), B, C, H * W, 1.0 / n_img, L.ptr(S), L.ptr(seed_l1), L.ptr(vplan.g_in), L.ptr(g_pan), st),
                 "l1_fwd_bwd_add")
         vplan.busy = False
+    _mark(marks)
     plan.run_backward(g_disp if a_sm > 0 else None, g_pan, in_place=True)
+    _mark(marks)
     Sc = torch.empty(3, device=dev)  # a fresh triple per step (callers keep loss tensors across steps); no launch: caching allocator
     L.check(lib.falnet_step_scalars(L.ptr(S), float(a_sm), L.ptr(Sc), st), "step_scalars")  # {rec + a_sm sm, rec, sm}; S -> 0
     out = {"loss": Sc[0], "rec": Sc[1], "sm": Sc[2] if a_sm > 0 else 0, "rpan": rpan, "ldisp": ldisp, "scaler": scaler}
     if optimize:
         opt.step(allreduce_gradients(model), scaler=scaler)
+    _mark(marks)
+    if marks is not None:
+        PHASE_MARKS.append(marks)
     return out
 
 
