@@ -141,6 +141,7 @@ SIGNATURES = {
     "falnet_l1_fwd_bwd": [_P, _P, _I, _I, _L, _F, _P, _P, _P, _P],
     "falnet_l1_fwd_bwd_add": [_P, _P, _I, _I, _L, _F, _P, _P, _P, _P, _P],
     "falnet_mse_fwd_bwd": [_P, _P, _L, _I, _F, _P, _F, _P, _P, _I, _P],
+    "falnet_mse3_fwd_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "falnet_smooth_fwd_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P],
     "falnet_smooth_fwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _I, _P],
     "falnet_smooth_bwd": [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P],

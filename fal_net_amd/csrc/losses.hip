@@ -183,8 +183,26 @@ __global__ __launch_bounds__(RED_THREADS) void mse_fwd_kernel(const T* __restric
     float acc = 0.f;
     const float gs = ga ? 2.f * gsc * (gscale ? gscale[0] : 1.f) : 0.f;
     if constexpr (VEC) {
-        const int64_t n8 = total >> 3;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        // four groups of eight elements per thread and iteration: eight independent 16-B loads in flight before the first use (a grid of RED_BLOCKS
+        // workgroups with one group per thread keeps ~4 MB in flight, half of what HBM's latency x bandwidth wants: 30 us for the 100 MB of slice 1)
+        const int64_t n8 = total >> 3, stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n8; i += 4 * stride) {
+            float d[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) diff8(a + 8 * (i + u * stride), b + 8 * (i + u * stride), d[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += d[u][j] * d[u][j];
+                if (ga) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[u][j] *= gs;
+                    put8(ga + 8 * (i + u * stride), d[u]);
+                }
+            }
+        }
+        for (; i < n8; i += stride) {
             float d[8];
             diff8(a + 8 * i, b + 8 * i, d);
 #pragma unroll
@@ -226,6 +244,54 @@ __global__ __launch_bounds__(RED_THREADS) void mse_bwd_kernel(const T* __restric
     }
 }
 
+// The perceptual term's three slices in ONE launch (loss_functions.py:61-65: sum over the VGG slices of the mean squared difference, each with its
+// own 1 / numel): blocks [begin_k, begin_{k+1}) work on tensor k -- the two small slices are latency-, not bandwidth-bound as launches of their own
+// (10-15 us for 25-50 MB).  VEC layout only (16-B aligned, multiples of 8 elements: NHWC feature maps); value AND gradient, as mse_fwd_kernel with ga.
+struct Mse3Args {
+    const void* a[3];
+    const void* b[3];
+    void* ga[3];
+    int64_t n8[3];
+    float scale_out[3], scale_grad[3];
+    int begin[4];
+};
+template <typename T>
+__global__ __launch_bounds__(RED_THREADS) void mse3_fwd_bwd_kernel(Mse3Args m, float* out, const float* __restrict__ gscale, int det) {
+    __shared__ float red[16];
+    const int k = (int)blockIdx.x >= m.begin[2] ? 2 : ((int)blockIdx.x >= m.begin[1] ? 1 : 0);
+    const T* a = reinterpret_cast<const T*>(m.a[k]);
+    const T* b = reinterpret_cast<const T*>(m.b[k]);
+    T* ga = reinterpret_cast<T*>(m.ga[k]);
+    const float gs = 2.f * m.scale_grad[k] * (gscale ? gscale[0] : 1.f);
+    const int64_t n8 = m.n8[k], stride = (int64_t)(m.begin[k + 1] - m.begin[k]) * blockDim.x;
+    int64_t i = (int64_t)((int)blockIdx.x - m.begin[k]) * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i + 3 * stride < n8; i += 4 * stride) {
+        float d[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) diff8(a + 8 * (i + u * stride), b + 8 * (i + u * stride), d[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += d[u][j] * d[u][j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[u][j] *= gs;
+            put8(ga + 8 * (i + u * stride), d[u]);
+        }
+    }
+    for (; i < n8; i += stride) {
+        float d[8];
+        diff8(a + 8 * i, b + 8 * i, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += d[j] * d[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] *= gs;
+        put8(ga + 8 * i, d);
+    }
+    const float s = block_sum(acc, red);
+    red_finish(out, s * m.scale_out[k], det);
+}
+
 // ------------------------------------------------------------------ edge-aware smoothness (loss_functions.py:70-101)
 struct SmoothArgs {
     const float* img;
@@ -253,10 +319,12 @@ __device__ __forceinline__ float wy_at(const SmoothArgs& s, int b, int y, int x)
     return __expf(-s.gamma * fabsf(g));
 }
 
-// Tiled form: a workgroup stages the grayscale and disparity of a 4 x 64 tile (+ halo 2 / 1) in LDS ONCE and every pixel reads its
+// Tiled form: a workgroup stages the grayscale and disparity of a 16 x 64 tile (+ halo 2 / 1) in LDS ONCE and every pixel reads its
 // neighbours from there -- the first kernels recomputed the gray value of every neighbour from three planar loads with bounds checks
-// (23 loads per pixel forward, 59 backward: 25 us each for 13 MB of input).
-#define SM_TY 4
+// (23 loads per pixel forward, 59 backward: 25 us each for 13 MB of input).  Sixteen rows per tile since round 6 (four per thread): a 4-row tile
+// staged 8 rows of gray for 4 of output behind two barriers (32 us for the fused forward + adjoint at B = 8, 256 x 512).
+#define SM_TY 16
+#define SM_RPT (SM_TY * SM_TX / RED_THREADS)  // rows per thread
 #define SM_TX 64
 #define SM_GW (SM_TX + 4)
 #define SM_GH (SM_TY + 4)
@@ -282,20 +350,24 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_fwd_kernel(SmoothArgs s, f
     const int Wc = s.x1 - s.x0;
     const int tiles_x = (Wc + SM_TX - 1) / SM_TX, tiles_y = (s.H + SM_TY - 1) / SM_TY;
     const int ntiles = s.B * tiles_y * tiles_x;
-    const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
+    const int lx = threadIdx.x % SM_TX, ly0 = threadIdx.x / SM_TX;
     float acc = 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx0 = s.x0 + (tile % tiles_x) * SM_TX, ty0 = ((tile / tiles_x) % tiles_y) * SM_TY, b = tile / (tiles_x * tiles_y);
         __syncthreads();  // previous tile consumed
         smooth_stage_tile(s, b, ty0, tx0, gt, dt);
         __syncthreads();
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x < s.x1 && y < s.H) {
-            const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
-            const float d = dp[0];
-            const float ax = fabsf(d - dp[1]) + fabsf(d - dp[-1]);
-            const float ay = fabsf(d - dp[-SM_DW]) + fabsf(d - dp[SM_DW]);
-            acc += ax * tile_wx(gt, s.gamma, ly, lx) + ay * tile_wy(gt, s.gamma, ly, lx);
+#pragma unroll
+        for (int rr = 0; rr < SM_RPT; ++rr) {
+            const int ly = ly0 + rr * (RED_THREADS / SM_TX);
+            const int x = tx0 + lx, y = ty0 + ly;
+            if (x < s.x1 && y < s.H) {
+                const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
+                const float d = dp[0];
+                const float ax = fabsf(d - dp[1]) + fabsf(d - dp[-1]);
+                const float ay = fabsf(d - dp[-SM_DW]) + fabsf(d - dp[SM_DW]);
+                acc += ax * tile_wx(gt, s.gamma, ly, lx) + ay * tile_wy(gt, s.gamma, ly, lx);
+            }
         }
     }
     const float r = block_sum(acc, red);
@@ -314,30 +386,34 @@ __global__ __launch_bounds__(RED_THREADS) void smooth_bwd_kernel(SmoothArgs s, f
     const float gs = scale * (gscale ? gscale[0] : 1.f);
     const int tiles_x = (s.W + SM_TX - 1) / SM_TX, tiles_y = (s.H + SM_TY - 1) / SM_TY;
     const int ntiles = s.B * tiles_y * tiles_x;
-    const int lx = threadIdx.x % SM_TX, ly = threadIdx.x / SM_TX;
+    const int lx = threadIdx.x % SM_TX, ly0 = threadIdx.x / SM_TX;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx0 = (tile % tiles_x) * SM_TX, ty0 = ((tile / tiles_x) % tiles_y) * SM_TY, b = tile / (tiles_x * tiles_y);
         __syncthreads();
         const bool any = tx0 < s.x1 && tx0 + SM_TX > s.x0;  // block-uniform: tile touches the window
         if (any) smooth_stage_tile(s, b, ty0, tx0, gt, dt);
         __syncthreads();
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= s.W || y >= s.H) continue;
-        float g = 0.f;
-        if (x >= s.x0 && x < s.x1) {
-            const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
-            const float d = dp[0], dl = dp[-1], dr = dp[1], du = dp[-SM_DW], dd = dp[SM_DW];
-            const float wx = tile_wx(gt, s.gamma, ly, lx), wy = tile_wy(gt, s.gamma, ly, lx);
-            g += (sgn(d - dr) + sgn(d - dl)) * wx + (sgn(d - du) + sgn(d - dd)) * wy;
-            if (fwd_out) facc += (fabsf(d - dr) + fabsf(d - dl)) * wx + (fabsf(d - du) + fabsf(d - dd)) * wy;
-            if (x - 1 >= s.x0) g -= sgn(dl - d) * tile_wx(gt, s.gamma, ly, lx - 1);  // left pixel's dx_d  = d[x-1]-d[x]
-            if (x + 1 < s.x1) g -= sgn(dr - d) * tile_wx(gt, s.gamma, ly, lx + 1);   // right pixel's dx1_d = d[x+1]-d[x]
-            if (y - 1 >= 0) g -= sgn(du - d) * tile_wy(gt, s.gamma, ly - 1, lx);     // upper pixel's dy1_d = d[y-1]-d[y]
-            if (y + 1 < s.H) g -= sgn(dd - d) * tile_wy(gt, s.gamma, ly + 1, lx);    // lower pixel's dy_d  = d[y+1]-d[y]
-            g *= gs;
+#pragma unroll
+        for (int rr = 0; rr < SM_RPT; ++rr) {
+            const int ly = ly0 + rr * (RED_THREADS / SM_TX);
+            const int x = tx0 + lx, y = ty0 + ly;
+            if (x >= s.W || y >= s.H) continue;
+            float g = 0.f;
+            if (x >= s.x0 && x < s.x1) {
+                const float* dp = dt + (ly + 1) * SM_DW + lx + 1;
+                const float d = dp[0], dl = dp[-1], dr = dp[1], du = dp[-SM_DW], dd = dp[SM_DW];
+                const float wx = tile_wx(gt, s.gamma, ly, lx), wy = tile_wy(gt, s.gamma, ly, lx);
+                g += (sgn(d - dr) + sgn(d - dl)) * wx + (sgn(d - du) + sgn(d - dd)) * wy;
+                if (fwd_out) facc += (fabsf(d - dr) + fabsf(d - dl)) * wx + (fabsf(d - du) + fabsf(d - dd)) * wy;
+                if (x - 1 >= s.x0) g -= sgn(dl - d) * tile_wx(gt, s.gamma, ly, lx - 1);  // left pixel's dx_d  = d[x-1]-d[x]
+                if (x + 1 < s.x1) g -= sgn(dr - d) * tile_wx(gt, s.gamma, ly, lx + 1);   // right pixel's dx1_d = d[x+1]-d[x]
+                if (y - 1 >= 0) g -= sgn(du - d) * tile_wy(gt, s.gamma, ly - 1, lx);     // upper pixel's dy1_d = d[y-1]-d[y]
+                if (y + 1 < s.H) g -= sgn(dd - d) * tile_wy(gt, s.gamma, ly + 1, lx);    // lower pixel's dy_d  = d[y+1]-d[y]
+                g *= gs;
+            }
+            const int64_t i = ((int64_t)b * s.H + y) * s.W + x;
+            gdisp[i] = accumulate ? gdisp[i] + g : g;
         }
-        const int64_t i = ((int64_t)b * s.H + y) * s.W + x;
-        gdisp[i] = accumulate ? gdisp[i] + g : g;
     }
     if (fwd_out) {  // block-uniform
         __syncthreads();
@@ -787,6 +863,37 @@ extern "C" int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, in
     FALNET_DISPATCH_DTYPE(dtype, MSE_FB_T);
 #undef MSE_FB_T
 #undef MSE_FB
+    FALNET_RETURN_LAUNCH();
+}
+
+extern "C" int falnet_mse3_fwd_bwd(const void* const* a, const void* const* b, const int64_t* numel, const float* scale_out, float* out,
+                                   const float* scale_grad, const float* gscale, void* const* ga, int dtype, void* stream) {
+    FALNET_ENTER(stream);
+    FALNET_DET_SLOT(det_slot, stream);
+    FALNET_CHECK_ARG(a && b && numel && scale_out && out && scale_grad && ga, "mse3_fwd_bwd: bad argument");
+    Mse3Args m;
+    int64_t total = 0;
+    for (int k = 0; k < 3; ++k) {
+        FALNET_CHECK_ARG(a[k] && b[k] && ga[k] && numel[k] > 0 && (numel[k] & 7) == 0 && ((((uintptr_t)a[k] | (uintptr_t)b[k] | (uintptr_t)ga[k]) & 31) == 0),
+                         "mse3_fwd_bwd: tensor %d must be 32-B aligned with a multiple of 8 elements", k);
+        m.a[k] = a[k]; m.b[k] = b[k]; m.ga[k] = ga[k];
+        m.n8[k] = numel[k] >> 3;
+        m.scale_out[k] = scale_out[k]; m.scale_grad[k] = scale_grad[k];
+        total += numel[k];
+    }
+    // RED_BLOCKS workgroups shared out by size, at least 16 each (one atomic / one deterministic slot entry per workgroup as in the single form)
+    int used = 0;
+    for (int k = 0; k < 3; ++k) {
+        m.begin[k] = used;
+        int nb = k == 2 ? RED_BLOCKS - used : (int)((double)numel[k] / (double)total * RED_BLOCKS);
+        if (nb < 16) nb = 16;
+        if (used + nb > RED_BLOCKS - 16 * (2 - k)) nb = RED_BLOCKS - 16 * (2 - k) - used;
+        used += nb;
+    }
+    m.begin[3] = used;
+#define MSE3_L(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(mse3_fwd_bwd_kernel<T>), dim3(used), dim3(RED_THREADS), 0, (hipStream_t)stream, m, out, gscale, det_slot)
+    FALNET_DISPATCH_DTYPE(dtype, MSE3_L);
+#undef MSE3_L
     FALNET_RETURN_LAUNCH();
 }
 

@@ -381,9 +381,18 @@ def _stage1_fused_body(model, opt, left, right, max_disp, a_p, a_sm, min_disp_ar
             Bo, Ho, Wo, Co = o.shape
             sc = 1.0 / o.numel()
             feats.append((o, ln, Bo * Ho * Wo, Co, sc))
-        for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
-            L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(seed_p), L.ptr(go), code, st),
-                    "mse_fwd_bwd")
+        if len(feats) == 3 and all(o.numel() % 8 == 0 and (o.data_ptr() | ln.data_ptr() | go.data_ptr()) % 32 == 0
+                                   for (o, ln, _, _, _), go in zip(feats, vplan.gouts)):
+            # the three slices' value + gradient in ONE launch (the small slices are latency-bound as launches of their own)
+            import ctypes as _C
+            P3, L3, F3 = _C.c_void_p * 3, _C.c_int64 * 3, _C.c_float * 3
+            L.check(lib.falnet_mse3_fwd_bwd(P3(*[f[0].data_ptr() for f in feats]), P3(*[f[1].data_ptr() for f in feats]), L3(*[f[0].numel() for f in feats]),
+                                            F3(*[a_p * f[4] for f in feats]), L.ptr(S), F3(*[f[4] for f in feats]), L.ptr(seed_p),
+                                            P3(*[g.data_ptr() for g in vplan.gouts]), code, st), "mse3_fwd_bwd")
+        else:
+            for (o, ln, npix, Co, sc), go in zip(feats, vplan.gouts):
+                L.check(lib.falnet_mse_fwd_bwd(L.ptr(o), L.ptr(ln), npix, Co, a_p * sc, L.ptr(S), sc, L.ptr(seed_p), L.ptr(go), code, st),
+                        "mse_fwd_bwd")
     x0 = int(0.20 * W)
     sc_sm = 1.0 / (B * H * (W - x0))
     if a_sm > 0:  # Train_Stage1_K.py:255

@@ -391,6 +391,11 @@ int falnet_l1_fwd_bwd_add(const float* a, const float* b, int B, int C, int64_t 
                           const float* gadd, float* ga, void* stream);
 int falnet_mse_fwd_bwd(const void* a, const void* b, int64_t npix, int Cpad, float scale_out, float* out, float scale_grad,
                        const float* gscale, void* ga, int dtype, void* stream);
+/* Three falnet_mse_fwd_bwd in ONE launch (the perceptual term's three VGG slices, loss_functions.py:61-65): tensor k has numel[k] elements (a multiple
+ * of 8, pointers 32-B aligned), out += scale_out[k] * sum (a_k - b_k)^2, ga_k = gscale[0] * 2 * scale_grad[k] * (a_k - b_k).  The pointer / scalar
+ * arrays are HOST arrays of three entries (read at the call). */
+int falnet_mse3_fwd_bwd(const void* const* a, const void* const* b, const int64_t* numel, const float* scale_out, float* out,
+                        const float* scale_grad, const float* gscale, void* const* ga, int dtype, void* stream);
 int falnet_smooth_fwd_bwd(const float* img, const float* disp, int B, int H, int W, int x0, int x1, float gamma, float scale, float* out,
                           const float* gscale, float* gdisp, void* stream);
 /* Tail of a fused step (Train_Stage1_K.py:258 `loss = rec_loss + a_sm * sm_loss`): S = {rec, sm} as accumulated by the *_fwd_bwd entry

@@ -1135,6 +1135,24 @@ def test_losses():
         L.check(lib.falnet_mse_fwd_bwd(L.ptr(xt), L.ptr(yt), 2 * 6 * 8, 64, 0.25 * scm, L.ptr(acc2), scm, L.ptr(seed), L.ptr(gx), L.dtype_code(dtype), L.stream_ptr()))
         assert abs(float(acc2) - 0.25 * float(((x - y) ** 2).mean())) < tol * float(((x - y) ** 2).mean())
         assert rel(to_nchw(gx, 64), 0.5 * 2 * scm * (x - y)) < tol
+    # the three VGG slices' MSE (value + gradient) in ONE launch == three single launches (falnet_mse3_fwd_bwd; sizes of very different magnitude,
+    # one of them smaller than a workgroup's share)
+    import ctypes as _C
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
+        shapes = [(2, 64, 32, 64), (2, 128, 16, 32), (1, 64, 2, 4)]
+        xs, ys = [torch.randn(*sh, generator=g) for sh in shapes], [torch.randn(*sh, generator=g) for sh in shapes]
+        xt, yt = [to_nhwc(t, dtype) for t in xs], [to_nhwc(t, dtype) for t in ys]
+        gs3 = [torch.full_like(t, float("nan")) for t in xt]
+        scs = [1.0 / t.numel() for t in xs]
+        acc2.zero_()
+        P3, L3, F3 = _C.c_void_p * 3, _C.c_int64 * 3, _C.c_float * 3
+        L.check(lib.falnet_mse3_fwd_bwd(P3(*[t.data_ptr() for t in xt]), P3(*[t.data_ptr() for t in yt]), L3(*[t.numel() for t in xt]),
+                                        F3(*[0.25 * s_ for s_ in scs]), L.ptr(acc2), F3(*scs), L.ptr(seed), P3(*[t.data_ptr() for t in gs3]),
+                                        L.dtype_code(dtype), L.stream_ptr()))
+        ref3 = sum(0.25 * float(((to_nchw(xa, xa.shape[3]) - to_nchw(xb, xb.shape[3])) ** 2).mean()) for xa, xb in zip(xt, yt))
+        assert abs(float(acc2) - ref3) < tol * ref3
+        for xa, xb, gq, sc3 in zip(xt, yt, gs3, scs):
+            assert rel(gq.float(), 0.5 * 2 * sc3 * (xa.float() - xb.float())) < tol
     # mse on NHWC, flip, rowmax, mask mix
     for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
         x, y = torch.randn(2, 40, 5, 9, generator=g), torch.randn(2, 40, 5, 9, generator=g)
