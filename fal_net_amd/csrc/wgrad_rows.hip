@@ -1039,6 +1039,8 @@ __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows16_kernel(const f
 
 struct Ws2Item { int u, n, T, t, b, x0, y0; };
 
+// (__launch_bounds__' second argument is HIP's MIN WAVES PER EXECUTION UNIT, not CUDA's blocks per SM: 2 = the eight waves of ONE workgroup on four
+// SIMDs = a 256-register budget -- what a 512-thread workgroup gets anyway; the 132 KiB of LDS allow one workgroup per CU and the bound does not say otherwise)
 template <typename T, int D>
 __global__ __launch_bounds__(WR8_THREADS, 2) void wgrad3x3_rows8s2_kernel(const falnet_wgrad_t p, int w_rows, int ntci, int ntiles, int nstrips) {
     constexpr int NS = D + 1;
