@@ -565,6 +565,12 @@ def main():
 
     if world > 1 or os.environ.get("FALNET_FORCE_DIST") == "1":
         result["allreduce"] = allreduce_report(model, eager_step, args, world, rank, dev, ms)
+    if world > 1:
+        # Everything below runs on rank 0 ONLY (phase marks, the instrumented pass): steps issued there must not issue collectives the other ranks
+        # never join -- they would wait for their peers forever.  The timed region and the all-reduce report are done; from here on the bucket
+        # hooks and allreduce_gradients skip the collective on every rank (the weights may diverge now: nothing below compares them).
+        train._SKIP_ALLREDUCE = True
+        dist.barrier()
 
     phase_ms = None
     if rank == 0 and not args.no_roofline and args.workload != "stage2" and not graphed:

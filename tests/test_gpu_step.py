@@ -593,7 +593,9 @@ def test_bench_two_ranks_reports_allreduce(launch):
     head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541"] \
         if launch == "torchrun" else [sys.executable]
     cmd = head + [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "128",
-           "--no-cpu-baseline", "--no-roofline", "--dtype", "f32"]
+           "--no-cpu-baseline", "--dtype", "f32"] + (["--no-roofline"] if launch == "torchrun" else ["--no-live-traffic"])
+    # (the self-launched form runs rank 0's measurement legs too -- phase marks, the instrumented pass: steps on ONE rank after the timed region, which
+    #  must not issue collectives the other rank never joins)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
@@ -606,6 +608,8 @@ def test_bench_two_ranks_reports_allreduce(launch):
     assert sum(a["buckets_bytes"]) == a["bytes"]
     assert a["isolated_ms"]["whole_buffer"] > 0 and a["ms_per_step_without_collective"] > 0 and np.isfinite(a["exposed_ms"])
     assert abs(d["value"] - 2 * 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]  # whole-job pairs/s = world * batch / step time
+    if launch == "self":
+        assert d["roofline"]["achieved"] > 0 and d["roofline"]["traffic"] is None or isinstance(d["roofline"]["traffic"], dict)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
