@@ -2899,6 +2899,8 @@ bool falnet_conv_up2_dma_applicable(const falnet_conv_t& p);                // d
 int falnet_conv_up2_dma_launch(const falnet_conv_t& p, hipStream_t st);
 bool falnet_conv_wave32_applicable(const falnet_conv_t& p);                 // conv_wave.hip: wave-streaming 32 -> 32 channel kernel (variant 27)
 int falnet_conv_wave32_launch(const falnet_conv_t& p, int flip, hipStream_t st);
+bool falnet_conv_wave64p_applicable(const falnet_conv_t& p);                // conv_wave.hip: wave-streaming 64 -> (<= 4) channel kernel, planar f32 output (variant 29)
+int falnet_conv_wave64p_launch(const falnet_conv_t& p, int flip, hipStream_t st);
 bool falnet_conv_up2d_applicable(const falnet_conv_t& p);                   // deconv data gradient on the low-resolution grid (variant 26)
 int falnet_conv_up2d_launch(const falnet_conv_t& p, hipStream_t st);
 bool falnet_conv_deep_applicable(const falnet_conv_t& p);                   // maps of <= 128 positions: one-shot LDS-DMA, K slices, last-arriver epilogue (variant 19)
@@ -2945,7 +2947,7 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         variant = 1;
     }
     if (g_disable_patch) variant = 1;
-    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || (variant >= 21 && variant <= 27), "conv2d: unknown variant %d", variant);
+    FALNET_CHECK_ARG((variant >= 0 && variant <= 10) || variant == 13 || variant == 15 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || (variant >= 21 && variant <= 27) || variant == 29, "conv2d: unknown variant %d", variant);
     if (variant == 19) {  // levels 5-6: K-sliced one-shot LDS-DMA kernel with the epilogue in the last slice (conv_dma.hip: conv3x3_deep_kernel)
         if (!falnet_conv_deep_applicable(p)) {
             falnet_set_error("conv2d: variant 19 needs a 16-bit nine-tap stride-1/2 launch on maps of at most 128 positions (128 %% (TH TW) == 0), dense NHWC output, "
@@ -2967,6 +2969,17 @@ static int choose_conv_kernel(const falnet_conv_t& p, ConvChoice& c) {
         c.swap = 0;
         c.patch = 4;
         c.bn = 64; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 8; c.nwaves = 8;
+        return 0;
+    }
+    if (variant == 29) {  // wave-streaming kernel for a 64-channel source and <= 4 planar-f32 output channels (conv_wave.hip: conv3x3_wave64p_kernel)
+        if (!(dense3x3 && falnet_conv_wave64p_applicable(p))) {
+            falnet_set_error("conv2d: variant 29 needs a 16-bit dense 3x3 stride-1 launch over ONE 64-channel source at the launch size, planar f32 output of <= 4 channels, no addend / activation-gradient operand / pool / split-K");
+            return -2;
+        }
+        c.flip = flip;
+        c.swap = 0;
+        c.patch = 11;
+        c.bn = 16; c.kcb = 32; c.tps = 9; c.adb = 1; c.th = 1; c.nwaves = 8;
         return 0;
     }
     if (variant == 27) {  // wave-streaming kernel for 32 -> (<= 32) channel layers at full resolution (conv_wave.hip: conv3x3_wave32_kernel)
@@ -3112,7 +3125,9 @@ extern "C" int falnet_conv2d_kernel_name(const falnet_conv_t* pp, char* buf, int
     ConvChoice c;
     if (int r = choose_conv_kernel(*pp, c)) return r;
     const char* t = pp->dtype == FALNET_BF16 ? "DF16b" : pp->dtype == FALNET_F16 ? "DF16_" : "f";
-    if (c.patch == 10)
+    if (c.patch == 11)
+        snprintf(buf, len, "_Z22conv3x3_wave64p_kernelI%sEv13falnet_conv_tiiii", t);
+    else if (c.patch == 10)
         snprintf(buf, len, "_Z21conv3x3_wave32_kernelI%sEv13falnet_conv_tiiii", t);
     else if (c.patch == 9)
         snprintf(buf, len, "_Z25conv2x2_up2d_dma16_kernelI%sEv13falnet_conv_tiii", t);
@@ -3170,6 +3185,7 @@ extern "C" int falnet_conv2d(const falnet_conv_t* pp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ConvChoice c;
     if (int r = choose_conv_kernel(p, c)) return r;
+    if (c.patch == 11) return falnet_conv_wave64p_launch(p, c.flip, st);
     if (c.patch == 10) return falnet_conv_wave32_launch(p, c.flip, st);
     if (c.patch == 9) return falnet_conv_up2d_launch(p, st);
     if (c.patch == 8) return falnet_conv_dma16_launch(p, c.flip, st, c.th);

@@ -208,6 +208,196 @@ __global__ __launch_bounds__(CW_THREADS) void conv3x3_wave32_kernel(const falnet
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// conv3x3_wave64p_kernel (falnet_conv2d variant 29, round 6): the same wave-streaming form for a 64-channel source and at most FOUR output channels
+// written as planar f32 -- the data gradient of VGG19's first convolution with respect to the synthesised view (loss_functions.py:21: 64 -> 3, the
+// last launch of the perceptual term's adjoint; 3.6 GFLOP over a 134 MB gradient tensor: HBM-bound, 60 us on the weight-stationary kernel whose
+// 32-channel output block is 29 / 32 padding).  A wave owns 16-pixel strips (18 x 128-B pixel lines per row = three 8-pixel pieces), keeps the nine taps'
+// weight fragments for ONE 16-row output tile (rows 0 .. 3 real) and both 32-channel halves in 72 registers, the three-row pixel window in 72 more, and
+// issues 18 MFMAs per output row; lanes 0-15 end up with their pixel's (up to) four channels and store 64-B runs per channel plane.
+// LDS image of a row: [pixel][64 channels], the eight 16-B segments of pixel p XOR-ed with p & 7 (on the DMA's source address): conflict-free
+// ds_read_b128 for the (position lane & 15, K block lane >> 4) pattern at column offsets 0..2 and both halves (exhaustive check).
+#define CP_XROW 3072                 // input row: 18 px used of three 8-pixel pieces
+#define CP_RING (CW_NS * CP_XROW)
+
+template <typename T>
+__global__ __launch_bounds__(CW_THREADS) void conv3x3_wave64p_kernel(const falnet_conv_t p, int nstrips, int flip, int RB, int nyb) {
+    static_assert(sizeof(T) == 2, "16-bit operands");
+    __shared__ __attribute__((aligned(1024))) char lds[8 * CP_RING];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned ring = (unsigned)(unsigned long)(cw_lptr_t)lds + wave * CP_RING;
+    const char* const ring_p = lds + wave * CP_RING;
+    const int H = p.OH, W = p.OW, IH = p.IH, IW = p.IW;
+    const int R = p.B * nyb * nstrips * RB;
+    const int nparts = (int)gridDim.x * 8, gp = (int)blockIdx.x * 8 + wave;
+    const int u0 = (int)((int64_t)R * gp / nparts), u1 = (int)((int64_t)R * (gp + 1) / nparts);
+
+    const int lp = lane & 15, lg = lane >> 4;
+    s16x8_t wf[9][2];  // [tap][32-channel half]: A operand rows = output channels 0 .. 15 (no row permutation: the results are read per lane below)
+    {
+        const T* wptr = reinterpret_cast<const T*>(p.weight);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+                wf[t][kc] = *reinterpret_cast<const s16x8_t*>(wptr + ((int64_t)lp * 9 + (flip ? 8 - t : t)) * 64 + 32 * kc + 8 * lg);
+    }
+
+    // ---- per-lane DMA geometry: lane = (pixel pl of an 8-pixel piece, 16-B position seg of its 128-B line); LDS pixel 8 k + pl has pl in its low bits ----
+    const int pl = lane >> 3, seg = lane & 7;
+    const int gseg = seg ^ pl;
+    const char* const zero_page = reinterpret_cast<const char*>(g_cw_zero);
+    const falnet_src_t& S = p.src[0];
+    const int64_t l_sy = S.sy, l_sx = S.sx, l_sb = S.sb;
+    const T* const x_base = reinterpret_cast<const T*>(S.ptr) + 8 * gseg;
+    const unsigned x_rowb = (unsigned)(l_sy * (int)sizeof(T));
+
+    auto load_item = [&](CwItem& c, int u) {
+        c.u = u;
+        const int bs = u / RB, r = u - bs * RB;
+        const int bb = bs / nstrips;
+        c.b = bb / nyb;
+        c.x0 = (bs - bb * nstrips) * 16;
+        c.y0 = (bb - c.b * nyb) * RB + r;
+        c.len = min(RB - r, u1 - u);
+        c.n = max(0, min(c.len, H - c.y0));
+        c.s = 0;
+    };
+    int nst = 0;
+    for (int u = u0; u < u1;) {
+        CwItem t;
+        load_item(t, u);
+        nst += t.n > 0 ? t.n + 2 : 0;
+        u += t.len;
+    }
+    auto first_item = [&](CwItem& c, int u) {
+        load_item(c, u);
+        while (c.n == 0) load_item(c, c.u + c.len);
+    };
+    const char* xptr[3];
+    unsigned xinc[3];
+    auto item_pointers = [&](const CwItem& c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int lpx = 8 * k + pl, xa = c.x0 - 1 + lpx;
+            const bool ok = lpx < 18 && xa >= 0 && xa < IW;
+            xptr[k] = ok ? reinterpret_cast<const char*>(x_base + (int64_t)c.b * l_sb + (int64_t)(c.y0 - 1) * l_sy + (int64_t)xa * l_sx) : zero_page;
+            xinc[k] = ok ? x_rowb : 0u;
+        }
+    };
+    auto issue = [&](const CwItem& c, int slot, bool real) {
+        const unsigned base = ring + slot * CP_XROW;
+        const int i = c.y0 - 1 + c.s;
+        const bool xv = real && i >= 0 && i < IH;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cw_glds16(xv ? xptr[k] : zero_page, base + k * 1024);
+            xptr[k] += xinc[k];
+        }
+    };
+    int offX[3][2];  // [dx][32-channel half]
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int col = dx + lp;
+            offX[dx][kc] = col * 128 + (((4 * kc + lg) ^ (col & 7)) << 4);
+        }
+    s16x8_t xw[3][3][2];  // [window row][dx][half]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xw[r][dx][kc][j] = 0;
+
+    CwItem ci_, cc_;
+    ci_ = CwItem{0, 0, 0, 0, 0, 0, 0};
+    if (nst > 0) {
+        first_item(ci_, u0);
+        item_pointers(ci_);
+    }
+    cc_ = ci_;
+    int issued = 0;
+    auto issue_next = [&](int slot) {
+        const bool real = issued < nst;
+        issue(ci_, slot, real);
+        if (real && ++issued < nst && ++ci_.s == ci_.n + 2) {
+            first_item(ci_, ci_.u + ci_.len);
+            item_pointers(ci_);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < CW_D; ++d) issue_next(d);
+    int slot = 0, islot = CW_D;
+    float* const out = reinterpret_cast<float*>(p.out);
+    const int64_t plane = (int64_t)H * W;
+    float bias4[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) bias4[f] = (p.bias && f < p.Cout) ? p.bias[f] : 0.f;
+    for (int g = 0; g < nst; ++g) {
+        issue_next(islot);
+        islot = islot + 1 == CW_NS ? 0 : islot + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CW_D * CW_PIECES) : "memory");
+        const char* sb = ring_p + slot * CP_XROW;
+        slot = slot + 1 == CW_NS ? 0 : slot + 1;
+        const int s = cc_.s;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                xw[0][dx][kc] = xw[1][dx][kc];
+                xw[1][dx][kc] = xw[2][dx][kc];
+                xw[2][dx][kc] = *reinterpret_cast<const s16x8_t*>(sb + offX[dx][kc]);
+            }
+        if (s >= 2) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) acc = H16<T>::mma16(wf[dy * 3 + dx][kc], xw[dy][dx][kc], acc);
+            // D[4 lg + f][lp]: lanes 0 .. 15 (lg = 0) hold channels 0 .. 3 of position lp
+            const int y = cc_.y0 + s - 2, x = cc_.x0 + lp;
+            if (lg == 0 && x < W) {
+                float* o = out + (int64_t)cc_.b * p.Cout * plane + (int64_t)y * W + x;
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    if (f < p.Cout) o[f * plane] = apply_act(acc[f] + bias4[f], p.act);
+            }
+        }
+        if (g + 1 < nst && ++cc_.s == cc_.n + 2) first_item(cc_, cc_.u + cc_.len);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool falnet_conv_wave64p_applicable(const falnet_conv_t& p) {
+    if (p.dtype != FALNET_BF16 && p.dtype != FALNET_F16) return false;
+    if (p.nsrc != 1 || p.cin_total != 64 || p.src[0].C != 64 || p.src[0].H != p.IH || p.src[0].W != p.IW) return false;
+    if (p.w_rows < 16 || p.w_taps != 9 || p.Cout < 1 || p.Cout > 4 || p.out_layout != FALNET_OUT_PLANAR_F32 || p.pool_out || p.ksplit > 1) return false;
+    if (p.addend || p.actout || p.OW < 16 || !p.out) return false;
+    if ((int64_t)p.B * ((p.OW + 15) / 16) * (p.OH + 32) >= (1ll << 30) || p.src[0].sy * 2 >= (1ll << 31)) return false;
+    return true;
+}
+
+int falnet_conv_wave64p_launch(const falnet_conv_t& p, int flip, hipStream_t st) {
+    const int nstrips = (p.OW + 15) / 16;
+    const int RB = p.OH >= 32 ? 32 : p.OH;
+    const int nyb = (p.OH + RB - 1) / RB;
+    const int64_t units = (int64_t)p.B * nyb * nstrips * RB;
+    int wgs = (int)((units + 8 * RB - 1) / (8 * RB));
+    if (wgs > 256) wgs = 256;
+    if (wgs < 1) wgs = 1;
+#define CP_L(T) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_wave64p_kernel<T>), dim3((unsigned)wgs), dim3(CW_THREADS), 0, st, p, nstrips, flip, RB, nyb)
+    FALNET_DISPATCH_16(p.dtype, CP_L);
+#undef CP_L
+    FALNET_RETURN_LAUNCH();
+}
+
 // dense 3x3 / stride 1 / pad 1 over ONE 32-channel NHWC source at the launch size, packed weight of 32 rows x 9 taps x 32 channels, NHWC output,
 // no fused pool / split-K (the caller has established dense3x3 and the tap order: `flip`)
 bool falnet_conv_wave32_applicable(const falnet_conv_t& p) {

@@ -576,6 +576,8 @@ def _autotune_conv(lib, d, ref, M, w_rows, Cout, reps=3):
                 cands += [(24, 1), (25, 1)]  # ... variants 17 / 20 (4x32 / 8x32 tiles)
         if d.cin_total == 32 and w_rows == 32 and L.ab("FALNET_CONV_WAVE", "1") == "1":
             cands += [(27, 1)]  # wave-streaming kernel: 32 -> 32 channels at full resolution (HBM-bound layers)
+        if d.cin_total == 64 and d.out_layout == L.OUT_PLANAR_F32 and Cout <= 4 and L.ab("FALNET_CONV_WAVE", "1") == "1":
+            cands += [(29, 1)]  # wave-streaming kernel: 64 -> (<= 4) planar-f32 channels (the VGG adjoint's last launch)
         if d.weight_up2:
             cands += [(18, 1)]  # deconv forward in sub-pixel form
         if wgs < int(L.ab("FALNET_SMALL_TILE_MAXWGS", "1024")) and L.ab("FALNET_SMALL_TILE_DMA", "1") == "1":

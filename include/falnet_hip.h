@@ -144,6 +144,8 @@ typedef struct {
                                   27 = wave-streaming kernel for 32 -> (<= 32) channel layers (conv_wave.hip: conv3x3_wave32_kernel): ONE 32-channel
                                   source at the launch size, 32-row packed weight, NHWC output, no pool / split-K; every wave streams its own
                                   32-pixel strip rows through a private LDS-DMA ring (no workgroup barrier), weights resident in registers;
+                                  29 = the same wave-streaming form for ONE 64-channel source and <= 4 output channels written as planar f32, no addend /
+                                  activation-gradient operand (conv_wave.hip: conv3x3_wave64p_kernel: the data gradient of VGG19's first convolution);
                                   -2 is returned when the variant does not apply */
     void* pool_out;            /* optional fused 2x2/stride-2 reduction of the (activated) output: NHWC `dtype`
                                   [B][OH/2][OW/2][out_cstride].  pool_mode 0: max (nn.MaxPool2d(2,2) after the VGG slices,

@@ -369,6 +369,43 @@ def test_conv_wave32_variant27(B, cout, H, W, mode, dtype):
     assert L.lib().falnet_conv2d(c64.ref, L.stream_ptr()) == -2
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W", [(2, 24, 64), (1, 37, 70), (8, 32, 96), (1, 5, 16), (1, 256, 512)])
+def test_conv_wave64p_variant29(B, H, W, dtype):
+    """falnet_conv2d variant 29 (conv3x3_wave64p_kernel, csrc/conv_wave.hip): the data gradient of VGG19's first convolution with respect to the
+    synthesised view (loss_functions.py:21: features[0] is 3 -> 64, so its adjoint is 64 -> 3 with flipped taps of the transposed weight, planar f32
+    output) -- against torch-CPU conv_transpose2d on the rounded operands and against the weight-stationary kernel it replaces; ragged strips, odd
+    sizes, fewer rows than waves."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    gout = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.1  # VGG features[0]: OIHW (64, 3, 3, 3)
+    pc = packed(w, None, [3], 1, dtype)
+    g_t = to_nhwc(gout, dtype)
+    gr, wref = to_nchw(g_t, 64), w.to(dtype).float()
+    ref = F.conv_transpose2d(gr, wref, None, padding=1)
+    out = torch.full((B, 3, H, W), float("nan"), device=DEV)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        call = ops.conv_call(dtype, [ops.nhwc_src(g_t)], H, W, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9, ops.pad_c(3), 1, B, H, W, out, H, W, 3, 0,
+                             out_layout=L.OUT_PLANAR_F32)
+    finally:
+        ops.AUTOTUNE = old
+    res = {}
+    for variant in (29, 10):
+        call.desc.variant = variant
+        out.fill_(float("nan"))
+        assert L.lib().falnet_conv2d(call.ref, L.stream_ptr()) == 0, (variant, L.lib().falnet_last_error())
+        name = C.create_string_buffer(160)
+        assert L.lib().falnet_conv2d_kernel_name(call.ref, name, 160) == 0
+        assert (b"conv3x3_wave64p_kernel" in name.value) == (variant == 29), name.value
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), variant
+        assert rel(out, ref) < TOL[dtype], (variant, rel(out, ref))
+        res[variant] = out.cpu().clone()
+    assert float((res[29] - res[10]).abs().max()) <= 1e-4 * float(res[10].abs().max())  # f32 outputs: only the summation order differs
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W,keep_full", [(2, 64, 64, 16, 64, True), (1, 64, 128, 24, 40, False), (2, 128, 128, 128, 256, True),
                                                      (1, 256, 256, 16, 32, False), (1, 64, 64, 11, 37, True)])

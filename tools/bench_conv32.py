@@ -39,3 +39,30 @@ for H, W in ((256, 512), (192, 640), (384, 1280)):
             t = sorted(ts)[2]
             line += f"  v{v} {t*1e3:6.1f}us {2.0*B*H*W*32*32*9/t/1e9:5.0f}TF"
         print(line, flush=True)
+
+# the VGG adjoint's last launch: 64 -> 3 channels, planar f32 output (variant 29 against the weight-stationary kernel)
+for H, W in ((256, 512), (384, 1280)):
+    w = torch.nn.Parameter(torch.randn(64, 3, 3, 3, device=DEV) * 0.1)
+    pc = ops.PackedConv("t", w, None, [3], 1)
+    pc.alloc(dtype, torch.device(DEV))
+    pc.pack_call()()
+    gout = torch.randn(B, H, W, 64, device=DEV).to(dtype)
+    out = torch.empty(B, 3, H, W, device=DEV)
+    ops.AUTOTUNE = False
+    call = ops.conv_call(dtype, [ops.nhwc_src(gout)], H, W, pc.wd, pc.cout_pad, ops.dgrad_taps_s1(3), 9, ops.pad_c(3), 1, B, H, W, out, H, W, 3, 0, out_layout=L.OUT_PLANAR_F32)
+    line = f"vgg dgrad0 64->3  @{H}x{W}:"
+    for v in (10, 16, 4, 1, 29):
+        call.desc.variant = v
+        if L.lib().falnet_conv2d(call.ref, L.stream_ptr()) != 0:
+            continue
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                L.lib().falnet_conv2d(call.ref, L.stream_ptr())
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 5)
+        line += f"  v{v} {sorted(ts)[2]*1e3:6.1f}us"
+    print(line, flush=True)
