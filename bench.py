@@ -370,6 +370,12 @@ def allreduce_report(model, step, args, world, rank, dev, ms_per_step):
             "xgmi_bound_ms": {"ring_per_link_153GBps": ring_ms, "all_7_links_direct": direct_ms},
             "stream_selftest": next((p.selftest for p in getattr(model, "_plans", {}).values() if getattr(p, "selftest", None)), None),
             "backward_issue": "recorded sequence cut at the bucket hooks (falnet_replay + Python collectives)" if os.environ.get("FALNET_REPLAY", "1") == "1" else "eager",
+            # where the buckets' all-reduces run (train.enable_overlapped_allreduce): as sync collectives on the step's auxiliary stream there is no
+            # stream of the backend's own on the data path, whatever RCCL opens internally -- the step keeps four busy hardware queues at any N
+            "collective_stream": ("auxiliary stream of the step (sync collectives, torch >= 2.8: issued on the caller's current stream)"
+                                  if (train._COMM_ON_AUX and dist.get_backend() == "nccl") else "the backend's own stream (async collectives)"),
+            "busy_hw_queues_of_a_step": 4 if (train._COMM_ON_AUX and dist.get_backend() == "nccl") else 5,
+            "torch_version": torch.__version__,
             "isolated_vs_ring_bound": (ring_ms / iso["whole_buffer"]) if iso["whole_buffer"] > 0 else None}
 
 
